@@ -1,0 +1,49 @@
+"""Synthetic YUV444 frame sequences for tests and bench (no network, no datasets).
+
+Recipe: `rng = np.random.default_rng(seed)`; keyframe of uniform random
+samples; every following frame changes a Bernoulli(p) set of pixels -- a non-zero luma
+residual plus fresh chroma -- so that with threshold 0 the luma mask marks exactly the
+pixels that changed and reconstruction from (mask, values) is exact.
+
+p = P_KSTAR_2_3 makes the reference's parameter rule pick k* = 2.3
+(k = log2((1-p) ln^2 2 / p), improved_video_compressor.py:185).
+"""
+import math
+
+import numpy as np
+
+P_KSTAR_2_3 = 1.0 / (1.0 + 2.0 ** 2.3 / math.log(2.0) ** 2)   # 0.08888997000980829
+
+
+def next_frame(rng, frame, p):
+    """Return a new frame differing from `frame` on a Bernoulli(p) pixel set."""
+    h, w = frame.shape[:2]
+    bits = 8 * frame.dtype.itemsize
+    change = rng.random((h, w)) < p
+    cnt = int(change.sum())
+    out = frame.copy()
+    if bits == 8:
+        resid = rng.integers(1, 256, cnt, dtype=np.uint16)
+        out[change, 0] = ((frame[change, 0].astype(np.uint16) + resid) & 0xFF).astype(np.uint8)
+    else:
+        # residuals in 1..32767: avoids the int16 blind spot |d| == 32768 (np.abs(int16 -32768) < 0)
+        resid = rng.integers(1, 32768, cnt, dtype=np.uint32)
+        out[change, 0] = ((frame[change, 0].astype(np.uint32) + resid) & 0xFFFF).astype(np.uint16)
+    out[change, 1] = rng.integers(0, 1 << bits, cnt, dtype=frame.dtype)
+    out[change, 2] = rng.integers(0, 1 << bits, cnt, dtype=frame.dtype)
+    return out
+
+
+def make_gop(seed, width, height, nframes, p=P_KSTAR_2_3, dtype=np.uint8):
+    """nframes interleaved YUV444 frames of shape (H, W, 3)."""
+    rng = np.random.default_rng(seed)
+    bits = 8 * np.dtype(dtype).itemsize
+    frames = [rng.integers(0, 1 << bits, (height, width, 3), dtype=dtype)]
+    for _ in range(nframes - 1):
+        frames.append(next_frame(rng, frames[-1], p))
+    return frames
+
+
+def make_mask(seed, n, p):
+    """Flat 0/1 uint8 vector with Bernoulli(p) ones (the reference's `binary_input`)."""
+    return (np.random.default_rng(seed).random(n) < p).astype(np.uint8)

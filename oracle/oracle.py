@@ -1,0 +1,358 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy-facing CPU oracle for the hot path.
+
+Wraps oracle/librbf_oracle.so (scalar C restatement, rbf_oracle.c) and restates
+the reference's host-side float64 / numpy / struct code around it.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package never does (it fails loudly if its HIP library is missing).
+
+Parity status: PINNED against tests/golden/ (generated from the reference itself
+by tools/gen_golden.py); see tests/test_oracle_golden.py.
+
+Reference anchors (/root/reference):
+  improved_video_compressor.py:161-196  _calculate_optimal_params   -> optimal_params
+  improved_video_compressor.py:198-266  compress                    -> compress
+  improved_video_compressor.py:268-307  decompress                  -> decompress
+  improved_video_compressor.py:768-847  _calculate_frame_diff       -> frame_diff
+  improved_video_compressor.py:849-909  _apply_frame_diff           -> apply_frame_diff
+  improved_video_compressor.py:911-967  _compress_frame_differences -> pack_frame_differences
+  improved_video_compressor.py:969-1027 _decompress_frame_differences -> unpack_frame_differences
+  fixed_video_compressor.py:217-285     verify_lossless             -> verify_lossless
+  verify_true_lossless.py:338-492       verify_bit_exact            -> verify_bit_exact
+"""
+import ctypes
+import io
+import math
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librbf_oracle.so")
+
+SEEDS_VIDEO = (0x12345678, 0x87654321, 999)
+SEEDS_BLOOM_COMPRESS = (0, 1, 999)
+P_STAR = 0.32453
+
+
+def build(force=False):
+    """Compile the C oracle with gcc (no GPU, no reference sources involved)."""
+    src = os.path.join(_HERE, "rbf_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "librbf_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        u64, u8p, dbl = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_double
+        seeds = ctypes.POINTER(ctypes.c_uint64)
+        L.orc_xxh64.restype = u64
+        L.orc_xxh64.argtypes = [ctypes.c_char_p, ctypes.c_size_t, u64]
+        L.orc_hash_index.restype = u64
+        L.orc_hash_index.argtypes = [u64, u64]
+        L.orc_normalize.restype = dbl
+        L.orc_normalize.argtypes = [u64]
+        L.orc_position.restype = u64
+        L.orc_position.argtypes = [u64, u64, ctypes.c_uint32, u64]
+        L.orc_add_index.restype = None
+        L.orc_add_index.argtypes = [u8p, u64, dbl, seeds, u64]
+        L.orc_check_index.restype = ctypes.c_int
+        L.orc_check_index.argtypes = [u8p, u64, dbl, seeds, u64]
+        L.orc_add_key.restype = None
+        L.orc_add_key.argtypes = [u8p, u64, dbl, seeds, ctypes.c_char_p, ctypes.c_size_t]
+        L.orc_check_key.restype = ctypes.c_int
+        L.orc_check_key.argtypes = [u8p, u64, dbl, seeds, ctypes.c_char_p, ctypes.c_size_t]
+        L.orc_std_add_key.restype = None
+        L.orc_std_add_key.argtypes = [u8p, u64, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        L.orc_std_check_key.restype = ctypes.c_int
+        L.orc_std_check_key.argtypes = [u8p, u64, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        L.orc_compress.restype = u64
+        L.orc_compress.argtypes = [u8p, u64, u64, dbl, seeds, u8p, u8p]
+        L.orc_decompress.restype = None
+        L.orc_decompress.argtypes = [u8p, u64, u8p, u64, dbl, seeds, u8p]
+        L.orc_mask_u8.restype = None
+        L.orc_mask_u8.argtypes = [u8p, u8p, u64, u64, dbl, u8p]
+        L.orc_mask_u16.restype = None
+        L.orc_mask_u16.argtypes = [u8p, u8p, u64, u64, dbl, u8p]
+        _lib = L
+    return _lib
+
+
+def _seeds(seeds):
+    return (ctypes.c_uint64 * 3)(*[int(s) for s in seeds])
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+# ---------------------------------------------------------------- hash level
+def xxh64(data: bytes, seed: int = 0) -> int:
+    return int(lib().orc_xxh64(data, len(data), seed))
+
+
+def hash_index(i: int, seed: int) -> int:
+    return int(lib().orc_hash_index(int(i), int(seed)))
+
+
+def normalize(h: int) -> float:
+    return float(lib().orc_normalize(int(h)))
+
+
+def position(h1, h2, i, size):
+    return int(lib().orc_position(int(h1), int(h2), int(i), int(size)))
+
+
+# ------------------------------------------------------------- filter level
+class RationalFilter:
+    """Byte-per-bit rational Bloom filter (improved_video_compressor.py:39-138)."""
+
+    def __init__(self, size, k_star, seeds=SEEDS_VIDEO):
+        self.size = int(size)
+        self.k_star = float(k_star)
+        self.floor_k = math.floor(k_star)
+        self.p_activation = k_star - self.floor_k
+        self.bit_array = np.zeros(self.size, dtype=np.uint8)
+        self.seeds = tuple(seeds)
+
+    def add_index(self, i):
+        lib().orc_add_index(_ptr(self.bit_array), self.size, self.k_star, _seeds(self.seeds), int(i))
+
+    def check_index(self, i):
+        return bool(lib().orc_check_index(_ptr(self.bit_array), self.size, self.k_star, _seeds(self.seeds), int(i)))
+
+    def add(self, item):
+        key = str(item).encode("utf-8")
+        lib().orc_add_key(_ptr(self.bit_array), self.size, self.k_star, _seeds(self.seeds), key, len(key))
+
+    def contains(self, item):
+        key = str(item).encode("utf-8")
+        return bool(lib().orc_check_key(_ptr(self.bit_array), self.size, self.k_star, _seeds(self.seeds), key, len(key)))
+
+
+def string_filter_seeds(k_star):
+    """rational_bloom_filter.py:100-101,134: seeds 0, 1 and activation seed ceil(k*)."""
+    return (0, 1, math.ceil(k_star))
+
+
+class StandardFilter:
+    """rational_bloom_filter.py:9-41."""
+
+    def __init__(self, m, k):
+        self.size = int(m)
+        self.hash_count = int(k)
+        self.bit_array = np.zeros(self.size, dtype=np.uint8)
+
+    def add(self, item):
+        key = str(item).encode("utf-8")
+        lib().orc_std_add_key(_ptr(self.bit_array), self.size, self.hash_count, key, len(key))
+
+    def contains(self, item):
+        key = str(item).encode("utf-8")
+        return bool(lib().orc_std_check_key(_ptr(self.bit_array), self.size, self.hash_count, key, len(key)))
+
+
+# --------------------------------------------------------- compressor level
+def optimal_params(n, p):
+    """improved_video_compressor.py:161-196: float64 via libm, left-to-right products."""
+    if p <= 0.0001:
+        return 0, 0
+    if p >= P_STAR:
+        return 0, 0
+    q = 1 - p
+    L = math.log(2)
+    k = math.log2(q * (L ** 2) / p)
+    if math.isnan(k) or k <= 0:
+        return 0, 0
+    gamma = 1 / L
+    l = int(p * n * k * gamma)
+    return max(0.1, k), max(1, l)
+
+
+def compress(binary_input, seeds=SEEDS_VIDEO, guard_l_ge_n=True):
+    """improved_video_compressor.py:198-266.  guard_l_ge_n=False gives bloom_compress.py:264."""
+    binary_input = np.ascontiguousarray(binary_input, dtype=np.uint8)
+    n = len(binary_input)
+    ones_count = np.sum(binary_input)
+    p = ones_count / n
+    if p >= P_STAR:
+        return binary_input, [], p, n, 1.0
+    k, l = optimal_params(n, p)
+    if l == 0 or (guard_l_ge_n and l >= n):
+        return binary_input, [], p, n, 1.0
+    bit_array = np.zeros(l, dtype=np.uint8)
+    witness = np.zeros(n, dtype=np.uint8)
+    w = lib().orc_compress(_ptr(binary_input), n, l, float(k), _seeds(seeds), _ptr(bit_array), _ptr(witness))
+    witness = [int(x) for x in witness[:w]]
+    return bit_array, witness, p, n, (l + len(witness)) / n
+
+
+def decompress(bloom_bitmap, witness, n, k, seeds=SEEDS_VIDEO):
+    """improved_video_compressor.py:268-307."""
+    if len(witness) == 0:
+        return bloom_bitmap
+    bloom_bitmap = np.ascontiguousarray(bloom_bitmap, dtype=np.uint8)
+    wit = np.ascontiguousarray(np.asarray(witness, dtype=np.uint8))
+    out = np.zeros(n, dtype=np.uint8)
+    lib().orc_decompress(_ptr(bloom_bitmap), len(bloom_bitmap), _ptr(wit), n, float(k), _seeds(seeds), _ptr(out))
+    return out
+
+
+# -------------------------------------------------------------- frame level
+def residual_mask(prev_y, curr_y, threshold):
+    """improved_video_compressor.py:801,808 incl. the uint16 -> int16 wrap."""
+    prev_y = np.ascontiguousarray(prev_y)
+    curr_y = np.ascontiguousarray(curr_y)
+    assert prev_y.shape == curr_y.shape and prev_y.dtype == curr_y.dtype
+    mask = np.zeros(prev_y.size, dtype=np.uint8)
+    fn = {1: lib().orc_mask_u8, 2: lib().orc_mask_u16}[prev_y.dtype.itemsize]
+    fn(_ptr(prev_y), _ptr(curr_y), prev_y.size, 1, float(threshold), _ptr(mask))
+    return mask.reshape(prev_y.shape)
+
+
+def frame_diff(prev_frame, curr_frame, threshold, yuv_planes=True):
+    """_calculate_frame_diff (:768-847) for direct-YUV H x W x 3 or 2-D frames.
+
+    Returns (mask HxW uint8, changed_values, density).  With yuv_planes the values are
+    uint8 Y,U,V interleaved (:825-829 -- dtype hard-coded uint8 in the reference);
+    otherwise they carry the frame dtype (:832-839 / :842)."""
+    prev_frame = np.asarray(prev_frame)
+    curr_frame = np.asarray(curr_frame)
+    is_color = prev_frame.ndim > 2 and prev_frame.shape[2] > 1
+    if is_color:
+        prev_gray, curr_gray = prev_frame[:, :, 0], curr_frame[:, :, 0]
+    else:
+        prev_gray, curr_gray = prev_frame, curr_frame
+    mask = residual_mask(prev_gray, curr_gray, threshold)
+    rows, cols = np.where(mask == 1)
+    if is_color:
+        vals = curr_frame[rows, cols, :].reshape(-1)
+        if yuv_planes:
+            vals = vals.astype(np.uint8)
+    else:
+        vals = curr_frame[rows, cols].copy()
+    density = np.sum(mask) / mask.size
+    return mask, vals, density
+
+
+def apply_frame_diff(base_frame, diff_mask, changed_values):
+    """_apply_frame_diff (:849-909)."""
+    nxt = np.array(base_frame, copy=True)
+    rows, cols = np.where(diff_mask == 1)
+    if nxt.ndim == 3 and nxt.shape[2] > 1:
+        ch = nxt.shape[2]
+        if len(changed_values) == len(rows) * ch:
+            nxt[rows, cols] = np.asarray(changed_values).reshape(-1, ch)
+    elif len(rows) > 0:
+        nxt[rows, cols] = changed_values
+    return nxt
+
+
+def pack_frame_differences(binary_diff, changed_values, seeds=SEEDS_VIDEO):
+    """_compress_frame_differences (:911-967): the reference's wire blob, float32 k and all."""
+    flat = np.asarray(binary_diff).flatten()
+    bitmap, witness, p, n, _ = compress(flat, seeds)
+    buf = io.BytesIO()
+    buf.write(struct.pack('<f', p))
+    buf.write(struct.pack('<I', n))
+    k, _l = optimal_params(n, p)
+    buf.write(struct.pack('<f', k))
+    buf.write(struct.pack('<I', len(bitmap)))
+    buf.write(struct.pack('<I', len(witness)))
+    bm = np.packbits(bitmap).tobytes()
+    buf.write(struct.pack('<I', len(bm))); buf.write(bm)
+    wb = np.packbits(np.array(witness, dtype=np.uint8)).tobytes()
+    buf.write(struct.pack('<I', len(wb))); buf.write(wb)
+    vb = zlib.compress(np.asarray(changed_values).tobytes(), level=9)
+    buf.write(struct.pack('<I', len(vb)))
+    buf.write(struct.pack('<I', len(changed_values)))
+    buf.write(vb)
+    ratio = (buf.tell() * 8) / (n + len(changed_values) * 8)
+    return buf.getvalue(), ratio
+
+
+def unpack_frame_differences(blob, frame_shape, seeds=SEEDS_VIDEO):
+    """_decompress_frame_differences (:969-1027)."""
+    buf = io.BytesIO(blob)
+    _p = struct.unpack('<f', buf.read(4))[0]
+    n = struct.unpack('<I', buf.read(4))[0]
+    k = struct.unpack('<f', buf.read(4))[0]
+    bl = struct.unpack('<I', buf.read(4))[0]
+    wl = struct.unpack('<I', buf.read(4))[0]
+    sz = struct.unpack('<I', buf.read(4))[0]
+    bitmap = np.unpackbits(np.frombuffer(buf.read(sz), dtype=np.uint8))[:bl]
+    sz = struct.unpack('<I', buf.read(4))[0]
+    witness = np.unpackbits(np.frombuffer(buf.read(sz), dtype=np.uint8))[:wl].tolist()
+    vs = struct.unpack('<I', buf.read(4))[0]
+    vc = struct.unpack('<I', buf.read(4))[0]
+    vals = np.frombuffer(zlib.decompress(buf.read(vs)), dtype=np.uint8)[:vc]
+    flat = decompress(bitmap, witness, n, k, seeds) if wl > 0 else bitmap
+    shape = (frame_shape[0], frame_shape[1]) if (len(frame_shape) == 3 and frame_shape[2] > 1) else frame_shape
+    return np.asarray(flat).reshape(shape), vals
+
+
+# ------------------------------------------------------------ harness level
+def _data(f):
+    return f.data if hasattr(f, 'data') and not isinstance(f, np.ndarray) else f
+
+
+def verify_lossless(original_frames, decompressed_frames):
+    """fixed_video_compressor.py:217-285 result dict."""
+    if len(original_frames) != len(decompressed_frames):
+        return {'lossless': False,
+                'reason': f"Frame count mismatch: {len(original_frames)} vs {len(decompressed_frames)}",
+                'avg_difference': float('inf')}
+    exact, diff_frames, max_diff, max_diff_frame = 0, [], 0, -1
+    for i, (o, d) in enumerate(zip(original_frames, decompressed_frames)):
+        o, d = _data(o), _data(d)
+        if np.array_equal(o, d):
+            exact += 1
+        else:
+            fd = np.mean(np.abs(o.astype(np.float32) - d.astype(np.float32)))
+            diff_frames.append(i)
+            if fd > max_diff:
+                max_diff, max_diff_frame = fd, i
+    ok = exact == len(original_frames)
+    return {'lossless': ok, 'exact_lossless': ok,
+            'avg_difference': 0.0 if not diff_frames else max_diff,
+            'max_difference': max_diff, 'max_diff_frame': max_diff_frame,
+            'exact_frame_matches': exact, 'total_frames': len(original_frames),
+            'diff_frames': diff_frames}
+
+
+def verify_bit_exact(original_frames, decompressed_frames):
+    """verify_true_lossless.py:338-492 result dict (diagnostic image dumps omitted)."""
+    if len(original_frames) != len(decompressed_frames):
+        return {"success": False,
+                "error": f"Frame count mismatch: {len(original_frames)} vs {len(decompressed_frames)}"}
+    exact, diff_frames, details = 0, [], []
+    for i, (o, d) in enumerate(zip(original_frames, decompressed_frames)):
+        o, d = _data(o), _data(d)
+        if o.shape != d.shape:
+            diff_frames.append(i)
+            details.append({"frame": i, "error": f"Shape mismatch: {o.shape} vs {d.shape}"})
+            continue
+        if np.array_equal(o, d):
+            exact += 1
+            continue
+        diff_frames.append(i)
+        diff = np.abs(o.astype(np.int16) - d.astype(np.int16))
+        idx = np.where(diff > 0)
+        ex = []
+        for j in range(min(10, len(idx[0]))):
+            c = tuple(a[j] for a in idx)
+            ex.append({"coordinates": str(c), "original_value": int(o[c]),
+                       "decompressed_value": int(d[c]), "difference": int(diff[c])})
+        details.append({"frame": i, "differences_found": len(idx[0]), "examples": ex})
+    return {"success": exact == len(original_frames), "frames_compared": len(original_frames),
+            "exact_matches": exact, "different_frames": len(diff_frames),
+            "different_frame_indices": diff_frames, "diff_details": details}

@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE itself (build container only).
+
+The reference (/root/reference, pure Python) is imported read-only with an empty `cv2`
+stub (it imports cv2 at module level but the hot path never touches it when frames are
+direct-YUV or 2-D and an explicit threshold is passed).  Nothing from the reference is
+copied: the outputs are data (inputs + expected outputs).  The GPU box has no
+/root/reference; tests read only the committed fixtures.
+
+Usage: python tools/gen_golden.py [--skip-large]
+"""
+import argparse
+import hashlib
+import json
+import math
+import os
+import random
+import sys
+import time
+import types
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+
+import numpy as np  # noqa: E402
+import xxhash  # noqa: E402
+
+import improved_video_compressor as ivc  # noqa: E402  (reference)
+import fixed_video_compressor as fvc  # noqa: E402  (reference)
+import bloom_compress as bc  # noqa: E402  (reference)
+import rational_bloom_filter as rbf  # noqa: E402  (reference)
+import test_bloom_filters as tbf  # noqa: E402  (reference)
+import verify_true_lossless as vtl  # noqa: E402  (reference)
+
+from new_bloom_filter_repo_amd.synthetic import make_gop, make_mask, P_KSTAR_2_3  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def quiet(fn, *a, **k):
+    """Run a chatty reference function with stdout suppressed."""
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+# ------------------------------------------------------------------ G1: XXH64 KATs
+def g1():
+    idx = [0, 1, 7, 9, 10, 12, 99, 100, 345, 999, 1000, 1234, 6789, 9999, 10000, 57599, 65535, 99999,
+           100000, 123456, 999999, 1000000, 2073599, 2073600, 8294399, 9999999, 10000000, 12345678,
+           33177599, 99999999, 100000000, 123456789, 999999999, 1000000000, 2147483647, 2147483648,
+           4294967295]
+    rng = random.Random(1)
+    idx += [rng.randrange(0, 10 ** rng.randint(1, 10)) % (1 << 32) for _ in range(170)]
+    seeds = [0x12345678, 0x87654321, 999, 0, 1] + list(range(2, 14))
+    rows = [[str(i), s, xxhash.xxh64_intdigest(str(i), s)] for i in idx for s in seeds]
+    strs = ["", "a", "abc", "abcd", "abcdefg", "abcdefgh", "abcdefghijk", "x" * 31, "y" * 32, "z" * 33,
+            "The quick brown fox jumps over the lazy dog", "q" * 100]
+    strs += ["".join(rng.choices("abcdefghijklmnopqrstuvwxyz", k=10)) for _ in range(10)]
+    rows += [[s, sd, xxhash.xxh64(s, seed=sd).intdigest()] for s in strs for sd in (0, 1, 2, 999, 2 ** 64 - 1)]
+    json.dump({"generator": "xxhash %s" % xxhash.VERSION, "rows": rows}, open(os.path.join(OUT, "g1_xxh64.json"), "w"))
+    print("G1", len(rows), "KATs")
+
+
+# ------------------------------------------------------------------ G2: optimal params
+def g2():
+    comp = ivc.BloomFilterCompressor()
+    rows = []
+    for n in (57600, 2073600, 8294400, 1000, 64, 4294967295):
+        ones_list = sorted(set(
+            [0, 1, 2, 5, int(n * 1e-4), int(n * 1e-4) + 1, int(n * 0.001), int(n * 0.01), int(n * 0.03),
+             int(n * P_KSTAR_2_3), int(n * P_KSTAR_2_3) + 1, int(n * 0.1), int(n * 0.15), int(n * 0.2), int(n * 0.25),
+             int(n * 0.3), int(n * 0.31), int(n * 0.32), int(n * 0.32453) - 1, int(n * 0.32453), int(n * 0.32453) + 1,
+             int(n * 0.33), int(n * 0.4), int(n * 0.5), n] +
+            [int(n * f) for f in np.linspace(0.0002, 0.3245, 40)]))
+        for ones in ones_list:
+            if ones > n:
+                continue
+            p = np.uint64(ones) / n          # exactly the reference's `np.sum(...) / n` (np.float64)
+            k, l = comp._calculate_optimal_params(n, p)
+            k2, l2 = bc.BloomFilterCompressor._calculate_optimal_params(n, p)
+            assert (k, l) == (k2, l2)
+            rows.append({"n": n, "ones": ones, "p_hex": float(p).hex(), "k_hex": float(k).hex(), "l": int(l)})
+    json.dump({"rows": rows}, open(os.path.join(OUT, "g2_params.json"), "w"))
+    print("G2", len(rows), "param rows")
+
+
+# ------------------------------------------------------------------ G2b: activation decisions
+def g2b():
+    """Reference `_determine_activation` decisions for (k, index) pairs incl. near-threshold hashes."""
+    rows = []
+    rng = random.Random(2)
+    for k in (0.1, 0.5, 1.0, 2.3038118730600234, 3.2062923944339987, 2.9999999999999996, 7.000000000000001, 12.25):
+        f = ivc.RationalBloomFilter(1000, k)
+        idx = [rng.randrange(0, 1 << 32) for _ in range(400)]
+        rows.append({"k_hex": float(k).hex(), "seed": 999, "indices": idx,
+                     "activated": [int(f._determine_activation(i)) for i in idx]})
+    # raw normalisation: h / (2**64 - 1) for edge hashes
+    hs = [0, 1, 2, (1 << 53) - 1, 1 << 53, (1 << 53) + 1, (1 << 63) - 1, 1 << 63, (1 << 64) - 2, (1 << 64) - 1,
+          3805423004476718848, 3805423004476718847] + [rng.randrange(0, 1 << 64) for _ in range(300)]
+    norm = [[h, (h / (2 ** 64 - 1)).hex()] for h in hs]
+    json.dump({"activation": rows, "normalize": norm}, open(os.path.join(OUT, "g2b_activation.json"), "w"))
+    print("G2b activation rows", len(rows), "normalize", len(norm))
+
+
+# ------------------------------------------------------------------ G3: 320x180 compress/decompress
+def ref_string_filter(mask, k, l):
+    """Config 1: rational_bloom_filter.RationalBloomFilter over str(i) keys of the '1' positions."""
+    f = rbf.RationalBloomFilter(l, k)
+    for i in np.flatnonzero(mask):
+        f.add(str(int(i)))
+    passed = np.array([1 if f.contains(str(i)) else 0 for i in range(len(mask))], dtype=np.uint8)
+    return np.array(f.bit_array, dtype=np.uint8), passed, f.ceil_k
+
+
+def g3():
+    W, H = 320, 180
+    n = W * H
+    v = ivc.VideoFrameCompressor(use_direct_yuv=True, num_threads=1)
+    v.bloom_compressor = ivc.BloomFilterCompressor()
+    fx = fvc.FixedVideoCompressor(verbose=False)
+    out = {}
+    meta = []
+    for ci, dens in enumerate([0.001, 0.03, P_KSTAR_2_3, 0.2, 0.31, 0.4, 0.0, 0.00005]):
+        seed = 3000 + ci
+        frames = make_gop(seed, W, H, 2, p=dens)
+        pf, cf = fx.add_yuv_info_to_frame(frames[0]), fx.add_yuv_info_to_frame(frames[1])
+        mask, values, density = v._calculate_frame_diff(pf, cf, threshold=0.0)
+        flat = mask.flatten()
+        key = "c%d" % ci
+        out[key + "_mask"] = np.packbits(flat)
+        out[key + "_values"] = values
+        rec = {"case": key, "seed": seed, "density_req": dens, "W": W, "H": H, "ones": int(flat.sum()),
+               "density_hex": float(density).hex(), "variants": {}}
+        # variant A: improved_video_compressor seeds
+        bm, wit, p, nn, ratio = v.bloom_compressor.compress(flat)
+        k, l = v.bloom_compressor._calculate_optimal_params(nn, p)
+        passthrough = len(wit) == 0
+        rec["variants"]["video"] = {"seeds": [0x12345678, 0x87654321, 999], "k_hex": float(k).hex(), "l": int(l),
+                                    "passthrough": passthrough, "wlen": len(wit), "bits_set": int(np.sum(bm)),
+                                    "ratio_hex": float(ratio).hex(), "p_hex": float(p).hex()}
+        if not passthrough:
+            out[key + "_video_filter"] = np.packbits(bm)
+            out[key + "_video_witness"] = np.packbits(np.array(wit, dtype=np.uint8))
+            dec = v.bloom_compressor.decompress(bm, wit, nn, k)
+            assert np.array_equal(dec, flat)
+        # variant B: bloom_compress.py seeds (0, 1, 999), no l >= n guard
+        bm2, wit2, p2, nn2, ratio2 = quiet(bc.BloomFilterCompressor().compress, flat)
+        k2, l2 = bc.BloomFilterCompressor._calculate_optimal_params(nn2, p2)
+        pt2 = len(wit2) == 0
+        rec["variants"]["bloom_compress"] = {"seeds": [0, 1, 999], "k_hex": float(k2).hex(), "l": int(l2),
+                                             "passthrough": pt2, "wlen": len(wit2), "bits_set": int(np.sum(bm2))}
+        if not pt2:
+            out[key + "_bc_filter"] = np.packbits(bm2)
+            out[key + "_bc_witness"] = np.packbits(np.array(wit2, dtype=np.uint8))
+        # variant C: rational_bloom_filter.py string-keyed filter (seeds 0, 1, ceil_k), same (k, l)
+        if not passthrough:
+            bm3, passed3, ceil_k = ref_string_filter(flat, k, l)
+            rec["variants"]["string"] = {"seeds": [0, 1, int(ceil_k)], "k_hex": float(k).hex(), "l": int(l),
+                                         "bits_set": int(bm3.sum()), "passed": int(passed3.sum())}
+            out[key + "_str_filter"] = np.packbits(bm3)
+            out[key + "_str_passed"] = np.packbits(passed3)
+        meta.append(rec)
+        print("G3", key, "ones", rec["ones"], {kk: (vv.get("l"), vv.get("wlen")) for kk, vv in rec["variants"].items()})
+    np.savez_compressed(os.path.join(OUT, "g3_320x180.npz"), **out)
+    json.dump({"cases": meta}, open(os.path.join(OUT, "g3_320x180.json"), "w"), indent=1)
+
+
+# ------------------------------------------------------------------ G4: full-size digests
+def g4(skip_large):
+    rows = []
+    sizes = [(1920, 1080, 42)] if skip_large else [(1920, 1080, 42), (3840, 2160, 43)]
+    comp = ivc.BloomFilterCompressor()
+    for W, H, seed in sizes:
+        n = W * H
+        x = make_mask(seed, n, P_KSTAR_2_3)
+        t0 = time.time()
+        bm, wit, p, nn, ratio = comp.compress(x)
+        t1 = time.time()
+        k, l = comp._calculate_optimal_params(nn, p)
+        dec = comp.decompress(bm, wit, nn, k)
+        t2 = time.time()
+        assert np.array_equal(dec, x)
+        rows.append({"W": W, "H": H, "seed": seed, "p_req": P_KSTAR_2_3, "ones": int(x.sum()),
+                     "mask_sha256": sha(np.packbits(x)), "k_hex": float(k).hex(), "l": int(l),
+                     "wlen": len(wit), "bits_set": int(bm.sum()),
+                     "filter_sha256": sha(np.packbits(bm)),
+                     "witness_sha256": sha(np.packbits(np.array(wit, dtype=np.uint8))),
+                     "ref_compress_s": round(t1 - t0, 3), "ref_decompress_s": round(t2 - t1, 3)})
+        print("G4", rows[-1])
+    json.dump({"rows": rows, "host": "build container, 1 core, CPython %s" % sys.version.split()[0]},
+              open(os.path.join(OUT, "g4_fullsize.json"), "w"), indent=1)
+
+
+# ------------------------------------------------------------------ G5: uint16 masks
+def g5():
+    v = ivc.VideoFrameCompressor(use_direct_yuv=True, num_threads=1)
+    a = np.array([[40000, 0, 32768, 65535, 100, 0, 65535, 32767, 32768, 1, 12345, 50000]], dtype=np.uint16)
+    b = np.array([[100, 32768, 0, 0, 40000, 0, 65535, 32768, 32767, 0, 12346, 17232]], dtype=np.uint16)
+    rng = np.random.default_rng(5)
+    a2 = rng.integers(0, 65536, (24, 40), dtype=np.uint16)
+    b2 = a2.copy()
+    sel = rng.random((24, 40)) < 0.3
+    b2[sel] = rng.integers(0, 65536, int(sel.sum()), dtype=np.uint16)
+    out = {}
+    rows = []
+    for name, (pa, pb) in {"edge": (a, b), "rand": (a2, b2)}.items():
+        for thr in (0.0, 0.5, 3.0, 10.7, 32766.0, 32767.0):
+            mask, vals, dens = v._calculate_frame_diff(pa, pb, threshold=thr)
+            out["%s_prev" % name] = pa
+            out["%s_curr" % name] = pb
+            out["%s_mask_%s" % (name, str(thr).replace(".", "_"))] = mask
+            rows.append({"name": name, "thr": thr, "ones": int(mask.sum())})
+    # uint8 with fractional / large thresholds
+    a3 = rng.integers(0, 256, (16, 32), dtype=np.uint8)
+    b3 = rng.integers(0, 256, (16, 32), dtype=np.uint8)
+    out["u8_prev"], out["u8_curr"] = a3, b3
+    for thr in (0.0, 0.99, 1.0, 2.5, 3.0, 30.0, 254.0, 255.0, 300.0):
+        mask, _, _ = v._calculate_frame_diff(a3, b3, threshold=thr)
+        out["u8_mask_%s" % str(thr).replace(".", "_")] = mask
+        rows.append({"name": "u8", "thr": thr, "ones": int(mask.sum())})
+    np.savez_compressed(os.path.join(OUT, "g5_masks.npz"), **out)
+    json.dump({"rows": rows}, open(os.path.join(OUT, "g5_masks.json"), "w"), indent=1)
+    print("G5", len(rows))
+
+
+# ------------------------------------------------------------------ G6: string filters, small example
+def g6():
+    random.seed(42)
+    m, n = 10, 5
+    k_star = rbf.RationalBloomFilter.get_optimal_hash_count(m, n)
+    fl, ce = math.floor(k_star), math.ceil(k_star)
+    f1, f2, f3 = rbf.StandardBloomFilter(m, fl), rbf.StandardBloomFilter(m, ce), rbf.RationalBloomFilter(m, k_star)
+    elements = tbf.generate_random_strings(n)
+    for e in elements:
+        f1.add(e); f2.add(e); f3.add(e)
+    tests = tbf.generate_random_strings(100)
+    small = {"m": m, "n": n, "k_star_hex": float(k_star).hex(), "elements": elements,
+             "std_floor": list(f1.bit_array), "std_ceil": list(f2.bit_array), "rational": list(f3.bit_array),
+             "tests": tests, "std_floor_contains": [int(f1.contains(e)) for e in tests],
+             "std_ceil_contains": [int(f2.contains(e)) for e in tests],
+             "rational_contains": [int(f3.contains(e)) for e in tests]}
+    # a larger deterministic one: m=4096, 300 random strings, k*=m/n ln2
+    random.seed(7)
+    m2, n2 = 4096, 300
+    k2 = rbf.RationalBloomFilter.get_optimal_hash_count(m2, n2)
+    g = rbf.RationalBloomFilter(m2, k2)
+    s = rbf.StandardBloomFilter(m2, rbf.StandardBloomFilter.get_optimal_hash_count(m2, n2))
+    el2 = rbf.generate_random_strings(n2)
+    for e in el2:
+        g.add(e); s.add(e)
+    t2 = rbf.generate_random_strings(500)
+    big = {"m": m2, "n": n2, "k_star_hex": float(k2).hex(), "std_k": s.hash_count, "elements": el2,
+           "rational_packed_hex": np.packbits(np.array(g.bit_array, dtype=np.uint8)).tobytes().hex(),
+           "std_packed_hex": np.packbits(np.array(s.bit_array, dtype=np.uint8)).tobytes().hex(),
+           "tests": t2, "rational_contains": [int(g.contains(e)) for e in t2],
+           "std_contains": [int(s.contains(e)) for e in t2]}
+    json.dump({"small": small, "big": big}, open(os.path.join(OUT, "g6_string_filters.json"), "w"))
+    print("G6 small", small["std_floor"], small["std_ceil"], small["rational"])
+
+
+# ------------------------------------------------------------------ G7/G9: blob, values, apply
+def g7_g9():
+    W, H = 64, 48
+    v = ivc.VideoFrameCompressor(use_direct_yuv=True, num_threads=1)
+    v.bloom_compressor = ivc.BloomFilterCompressor()
+    fx = fvc.FixedVideoCompressor(verbose=False)
+    frames = make_gop(7000, W, H, 2, p=0.06)
+    pf, cf = fx.add_yuv_info_to_frame(frames[0]), fx.add_yuv_info_to_frame(frames[1])
+    mask, values, density = v._calculate_frame_diff(pf, cf, threshold=0.0)
+    blob, ratio = v._compress_frame_differences(mask, values)
+    m2, v2 = v._decompress_frame_differences(blob, (H, W, 3))
+    nxt = v._apply_frame_diff(pf, m2, v2)
+    # plain ndarray path (no yuv_info): values carry frame dtype
+    mask_p, values_p, _ = v._calculate_frame_diff(frames[0], frames[1], threshold=0.0)
+    nxt_p = v._apply_frame_diff(frames[0], mask_p, values_p)
+    # grayscale path
+    g0, g1_ = frames[0][:, :, 0].copy(), frames[1][:, :, 0].copy()
+    mask_g, values_g, _ = v._calculate_frame_diff(g0, g1_, threshold=0.0)
+    nxt_g = v._apply_frame_diff(g0, mask_g, values_g)
+    np.savez_compressed(os.path.join(OUT, "g7_g9_frame_codec.npz"),
+                        prev=frames[0], curr=frames[1], mask=mask, values=values,
+                        blob=np.frombuffer(blob, dtype=np.uint8), dec_mask=m2, dec_values=v2,
+                        applied=np.asarray(nxt.data), values_plain=values_p, applied_plain=nxt_p,
+                        mask_gray=mask_g, values_gray=values_g, applied_gray=nxt_g)
+    json.dump({"W": W, "H": H, "seed": 7000, "p": 0.06, "ratio_hex": float(ratio).hex(),
+               "density_hex": float(density).hex(),
+               "mask_roundtrip_equal": bool(np.array_equal(m2, mask)),
+               "applied_equals_curr": bool(np.array_equal(np.asarray(nxt.data), frames[1]))},
+              open(os.path.join(OUT, "g7_g9_frame_codec.json"), "w"), indent=1)
+    print("G7/G9 blob bytes", len(blob), "roundtrip", np.array_equal(m2, mask), np.array_equal(np.asarray(nxt.data), frames[1]))
+
+
+# ------------------------------------------------------------------ G8: verifier dicts
+def g8():
+    def clean(o):
+        if isinstance(o, dict):
+            return {k: clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, (np.floating, float)):
+            return float(o) if math.isfinite(float(o)) else repr(float(o))
+        if isinstance(o, (np.integer,)):
+            return int(o)
+        if isinstance(o, (np.bool_,)):
+            return bool(o)
+        return o
+    fx = fvc.FixedVideoCompressor(verbose=False)
+    frames = make_gop(8000, 32, 24, 3, p=0.1)
+    same = [f.copy() for f in frames]
+    off = [f.copy() for f in frames]
+    off[1][3, 4, 1] ^= 1
+    off[2][0, 0, 0] = (int(off[2][0, 0, 0]) + 7) % 256
+    off[2][5, 6, 2] = (int(off[2][5, 6, 2]) + 100) % 256
+    # NB: the reference unwraps with `hasattr(x, 'data')`, which is also true of a plain ndarray
+    # (memoryview) -> its mean-difference branch raises AttributeError for unequal PLAIN ndarrays.
+    # The YUV path always hands it YUVFrame wrappers, so that is what the fixture pins.
+    wrap = lambda fs: [fx.add_yuv_info_to_frame(f) for f in fs]
+    frames, same, off = wrap(frames), wrap(same), wrap(off)
+    cases = {"identical": (frames, same), "pixels_off": (frames, off), "count_mismatch": (frames, same[:2])}
+    res = {}
+    for name, (a, b) in cases.items():
+        res[name] = {"verify_lossless": clean(fx.verify_lossless(a, b)),
+                     "verify_bit_exact": clean(quiet(vtl.verify_bit_exact, a, b, "YUV", False, None))}
+    json.dump({"seed": 8000, "W": 32, "H": 24, "nframes": 3, "p": 0.1, "results": res},
+              open(os.path.join(OUT, "g8_verify.json"), "w"), indent=1)
+    print("G8", {k: v["verify_lossless"].get("lossless") for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-large", action="store_true", help="skip the 2160p digest (about a minute of reference time)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    steps = {"g1": g1, "g2": g2, "g2b": g2b, "g3": g3, "g4": lambda: g4(a.skip_large), "g5": g5, "g6": g6,
+             "g7": g7_g9, "g8": g8}
+    for name, fn in steps.items():
+        if a.only and name not in a.only.split(","):
+            continue
+        fn()
