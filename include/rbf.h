@@ -1,0 +1,174 @@
+/*
+ * rbf.h -- C ABI of librbf_hip.so: the MI355X (gfx950) rational-Bloom-filter residual coder.
+ *
+ * The reference (ross39/new_bloom_filter_repo) is pure Python and has no FFI layer; its
+ * boundary for this path is a Python class surface.  Each entry point below names the
+ * reference code whose BODY it replaces (file:line under the reference tree); the Python
+ * classes in new_bloom_filter_repo_amd/ keep the reference's names and call these through
+ * ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - Every function returns 0 (RBF_OK) or a negative errno-style code; it never throws and
+ *    never aborts.  rbf_last_error() returns a thread-local, library-owned description of
+ *    the most recent failure on the calling thread.
+ *  - Pointers named *_dev are DEVICE pointers (HIP global memory); everything else is host
+ *    memory owned by the caller.  The library owns what it allocates (context scratch,
+ *    rbf_malloc blocks until rbf_free) and nothing it returns outlives the context.
+ *  - Bit vectors (masks, filters, witnesses) are packed MSB-first per byte, i.e. exactly
+ *    numpy.packbits order: stream bit i lives in byte i>>3 at bit 7-(i&7).  Buffers holding
+ *    them must be padded to a multiple of 8 bytes; pad bits are written as 0.
+ *  - All work of one context is enqueued on ONE HIP stream (the caller's, or one the library
+ *    creates); calls on one context are serialised, different contexts are independent.
+ *    One context per thread.  Calls return after ENQUEUEING unless stated otherwise.
+ *  - Limits: 1 <= n < 2^32 pixels per frame; 1 <= m <= 2^32-1 filter bits; floor_k <= 64.
+ */
+#ifndef RBF_H
+#define RBF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBF_OK        0
+#define RBF_EINVAL  (-22)
+#define RBF_ENOMEM  (-12)
+#define RBF_EIO      (-5)   /* a HIP runtime call failed; see rbf_last_error() */
+#define RBF_ERANGE  (-34)
+
+#define RBF_ABI_VERSION 1
+
+typedef struct rbf_ctx rbf_ctx;
+
+/* One filter's geometry, computed on the HOST (float64 via libm must match CPython's `math`
+ * to the last ulp -- improved_video_compressor.py:181-196 -- so it never runs on the device).
+ *   m          filter length in bits            (l,         improved_video_compressor.py:193)
+ *   floor_k    deterministic hash count         (floor(k*), :57)
+ *   threshold  activate the extra hash iff XXH64(str(i), act_seed) < threshold
+ *              (integer form of `h / (2**64-1) < k* - floor(k*)`, :94-97)                  */
+typedef struct {
+    uint32_t m;
+    uint32_t floor_k;
+    uint64_t threshold;
+} rbf_filter_params;
+
+/* Hash seeds: (0x12345678, 0x87654321, 999) improved_video_compressor.py:62-63,94;
+ * (0, 1, 999) bloom_compress.py:163-164,195; (0, 1, ceil(k*)) rational_bloom_filter.py:100-101,134. */
+typedef struct {
+    uint64_t h1;
+    uint64_t h2;
+    uint64_t act;
+} rbf_seeds;
+
+/* Per-frame results written by encode (device memory, 4 x uint64 per frame). */
+#define RBF_STAT_WITNESS_BITS 0   /* len(witness),            improved_video_compressor.py:253 */
+#define RBF_STAT_FILTER_ONES  1   /* popcount of the filter */
+#define RBF_STAT_RESERVED0    2
+#define RBF_STAT_RESERVED1    3
+#define RBF_STATS_PER_FRAME   4
+
+/* ---- library / context ------------------------------------------------------------------ */
+int rbf_version(void);
+const char *rbf_last_error(void);
+int rbf_device_count(int *count);
+
+/* hip_stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL to let the library create and own a stream. */
+int rbf_ctx_create(int device, void *hip_stream, rbf_ctx **out);
+int rbf_ctx_destroy(rbf_ctx *ctx);
+int rbf_ctx_sync(rbf_ctx *ctx);                       /* blocks until the stream is idle */
+
+/* Device-memory helpers so host code needs no other GPU runtime. */
+int rbf_malloc(rbf_ctx *ctx, size_t bytes, void **out_dev);
+int rbf_free(rbf_ctx *ctx, void *ptr_dev);
+int rbf_memset(rbf_ctx *ctx, void *dst_dev, int value, size_t bytes);            /* async */
+int rbf_memcpy_h2d(rbf_ctx *ctx, void *dst_dev, const void *src, size_t bytes);  /* blocks */
+int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes);  /* blocks */
+
+/* Per-kernel HIP-event timing (bench.py): when enabled every kernel launch is bracketed by
+ * events on the context's stream.  kernel ids: RBF_K_*.  rbf_timing_read blocks. */
+#define RBF_K_MASK    0
+#define RBF_K_INSERT  1
+#define RBF_K_QUERY   2
+#define RBF_K_STITCH  3
+#define RBF_K_EXPAND  4
+#define RBF_K_GATHER  5
+#define RBF_K_SCATTER 6
+#define RBF_K_INDEX   7
+#define RBF_K_COUNT   8
+int rbf_timing_enable(rbf_ctx *ctx, int on);
+int rbf_timing_reset(rbf_ctx *ctx);
+int rbf_timing_read(rbf_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
+
+/* ---- host-side scalar helpers (no GPU) --------------------------------------------------- */
+/* BloomFilterCompressor._calculate_optimal_params with p = ones/n (improved_video_compressor.py:161-196,
+ * :211-212).  Returns k=0,l=0 for the reference's "(0, 0)" cases. */
+int rbf_optimal_params(uint64_t n, uint64_t ones, double *k, uint64_t *l);
+/* floor(k*) and the integer activation threshold T = min{h : RN(h/(2^64-1)) >= k*-floor(k*)}
+ * (improved_video_compressor.py:57-58,94-97). */
+int rbf_activation_threshold(double k_star, uint32_t *floor_k, uint64_t *threshold);
+
+/* ---- A1: residual mask  (VideoFrameCompressor._calculate_frame_diff, :784-808,845) ------- */
+/* mask bit = abs_int16(prev - curr) > thr_floor, with numpy's int16 wrap for 16-bit samples.
+ * Sample (x, y) of a frame is at base + y*row_pitch_bytes + x*pixel_stride_bytes (so the luma
+ * of interleaved YUV444 or a planar plane are both addressable); sample_bytes is 1 or 2.
+ * Frame f of the batch is at frames_dev + f*frame_stride_bytes; mask f (f = 0..nframes-2) is the
+ * mask between frame f and f+1, written at masks_dev + f*mask_stride_bytes; ones_dev[f] gets
+ * np.sum(mask).  mask_stride_bytes must be a multiple of 8 and >= ceil(n/64)*8. */
+int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                            uint32_t nframes, uint32_t width, uint32_t height,
+                            uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                            uint32_t sample_bytes, int32_t thr_floor,
+                            void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev);
+
+/* ---- A4 + A5: insert + query/witness  (BloomFilterCompressor.compress loops, :232-253) --- */
+/* For each frame f: zero filter f, insert every '1' position of mask f
+ * (RationalBloomFilter.add_index, :99-114), then test every position 0..n-1 in order
+ * (check_index, :116-138) and append mask bit i to the witness when it passes.
+ *   masks_dev     nframes packed masks, stride mask_stride_bytes
+ *   params        nframes host structs
+ *   filters_dev   out: nframes packed filters, stride filter_stride_bytes >= ceil(m/64)*8
+ *   witnesses_dev out: nframes packed witnesses, stride witness_stride_bytes >= ceil(n/64)*8
+ *   stats_dev     out: nframes x RBF_STATS_PER_FRAME uint64 */
+int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
+                           uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                           const rbf_seeds *seeds,
+                           void *filters_dev, uint64_t filter_stride_bytes,
+                           void *witnesses_dev, uint64_t witness_stride_bytes,
+                           uint64_t *stats_dev);
+
+/* ---- A6: decode  (BloomFilterCompressor.decompress loop, :286-307) ------------------------ */
+/* out mask bit i = witness[w++] if position i passes the filter, else 0. */
+int rbf_bloom_decode_batch(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_stride_bytes,
+                           const void *witnesses_dev, uint64_t witness_stride_bytes,
+                           uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                           const rbf_seeds *seeds,
+                           void *masks_dev, uint64_t mask_stride_bytes);
+
+/* ---- per-index surface  (RationalBloomFilter.add_index / check_index, :99-138) ----------- */
+/* filter_dev is a packed filter of params->m bits.  indices_dev: count uint32 indices. */
+int rbf_filter_insert_indices(rbf_ctx *ctx, void *filter_dev, const rbf_filter_params *params,
+                              const rbf_seeds *seeds, const uint32_t *indices_dev, uint64_t count);
+/* out_dev[i] = 1 if indices_dev[i] passes, else 0 (one byte per index). */
+int rbf_filter_query_indices(rbf_ctx *ctx, const void *filter_dev, const rbf_filter_params *params,
+                             const rbf_seeds *seeds, const uint32_t *indices_dev, uint64_t count,
+                             uint8_t *out_dev);
+
+/* ---- A2 / A8: changed-value gather / scatter  (:811-842, :886-903) ------------------------ */
+/* Gather, in raster order, the `channels` samples of every pixel whose mask bit is 1 out of
+ * an interleaved frame (sample c of pixel (x,y) at base + y*row_pitch + x*pixel_stride + c*sample_bytes)
+ * into values_dev (count*channels samples); count_dev gets the number of pixels. */
+int rbf_gather_values(rbf_ctx *ctx, const void *frame_dev, uint32_t width, uint32_t height,
+                      uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes, uint32_t sample_bytes,
+                      uint32_t channels, const void *mask_dev, void *values_dev, uint64_t *count_dev);
+/* Inverse: write values back at the mask's '1' pixels (frame_dev is updated in place). */
+int rbf_scatter_values(rbf_ctx *ctx, void *frame_dev, uint32_t width, uint32_t height,
+                       uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes, uint32_t sample_bytes,
+                       uint32_t channels, const void *mask_dev, const void *values_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBF_H */

@@ -1,0 +1,611 @@
+// rbf_api.hip -- C ABI (include/rbf.h) over the gfx950 kernels.  Host side: argument checks,
+// scratch management, launches on the context's single HIP stream, optional per-kernel timing.
+#include "../../include/rbf.h"
+#include "rbf_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace rbf;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(RBF_EIO, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct Timed { int id; hipEvent_t a, b; };
+
+struct rbf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    // scratch (grown on demand, never shrunk)
+    FrameDev *fp_dev = nullptr;      size_t fp_cap = 0;       // bytes
+    // pinned staging ring for the per-batch parameter upload (a slot is reused only after the
+    // copy that read it has completed, so back-to-back batches never block the host)
+    static constexpr int RING = 4;
+    FrameDev *fp_pinned[RING] = {nullptr, nullptr, nullptr, nullptr};
+    size_t fp_pinned_cap[RING] = {0, 0, 0, 0};
+    hipEvent_t fp_event[RING] = {nullptr, nullptr, nullptr, nullptr};
+    bool fp_busy[RING] = {false, false, false, false};
+    int fp_next = 0;
+    uint32_t *seg_bits = nullptr;    size_t seg_bits_cap = 0; // bytes
+    uint32_t *seg_cnt = nullptr;     size_t seg_cnt_cap = 0;
+    uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
+    uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
+    // timing
+    bool timing = false;
+    std::vector<Timed> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[RBF_K_COUNT] = {0};
+    uint64_t launches[RBF_K_COUNT] = {0};
+};
+
+static int grow(void **ptr, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return RBF_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr; *cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(ptr, want));
+    *cap = want;
+    return RBF_OK;
+}
+
+static int set_device(rbf_ctx *ctx)
+{
+    if (!ctx) return fail(RBF_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return RBF_OK;
+}
+
+struct LaunchTimer {
+    rbf_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; bool on;
+    LaunchTimer(rbf_ctx *ctx, int kid) : c(ctx), id(kid), on(ctx->timing)
+    {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        };
+        a = get(); b = get();
+        if (!a || !b) { on = false; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~LaunchTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({id, a, b});
+    }
+};
+
+static int drain_timing(rbf_ctx *ctx)
+{
+    if (ctx->pending.empty()) return RBF_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto &t : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            ctx->total_ms[t.id] += ms;
+            ctx->launches[t.id] += 1;
+        }
+        ctx->pool.push_back(t.a);
+        ctx->pool.push_back(t.b);
+    }
+    ctx->pending.clear();
+    return RBF_OK;
+}
+
+extern "C" {
+
+int rbf_version(void) { return RBF_ABI_VERSION; }
+const char *rbf_last_error(void) { return g_err; }
+
+int rbf_device_count(int *count)
+{
+    if (!count) return fail(RBF_EINVAL, "count is null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return fail(RBF_EIO, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = c;
+    return RBF_OK;
+}
+
+int rbf_ctx_create(int device, void *hip_stream, rbf_ctx **out)
+{
+    if (!out) return fail(RBF_EINVAL, "out is null");
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(RBF_EINVAL, "device %d out of range (have %d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    rbf_ctx *c = new (std::nothrow) rbf_ctx();
+    if (!c) return fail(RBF_ENOMEM, "out of host memory");
+    c->device = device;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(RBF_EIO, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return RBF_OK;
+}
+
+int rbf_ctx_destroy(rbf_ctx *ctx)
+{
+    if (!ctx) return RBF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    if (ctx->fp_dev) (void)hipFree(ctx->fp_dev);
+    for (int k = 0; k < rbf_ctx::RING; ++k) {
+        if (ctx->fp_pinned[k]) (void)hipHostFree(ctx->fp_pinned[k]);
+        if (ctx->fp_event[k]) (void)hipEventDestroy(ctx->fp_event[k]);
+    }
+    if (ctx->seg_bits) (void)hipFree(ctx->seg_bits);
+    if (ctx->seg_cnt) (void)hipFree(ctx->seg_cnt);
+    if (ctx->seg_off) (void)hipFree(ctx->seg_off);
+    if (ctx->pass_words) (void)hipFree(ctx->pass_words);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RBF_OK;
+}
+
+int rbf_ctx_sync(rbf_ctx *ctx)
+{
+    if (int r = set_device(ctx)) return r;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RBF_OK;
+}
+
+int rbf_malloc(rbf_ctx *ctx, size_t bytes, void **out_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!out_dev) return fail(RBF_EINVAL, "out_dev is null");
+    *out_dev = nullptr;
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipMalloc(out_dev, bytes);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RBF_ENOMEM : RBF_EIO, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return RBF_OK;
+}
+
+int rbf_free(rbf_ctx *ctx, void *ptr_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!ptr_dev) return RBF_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(ptr_dev));
+    return RBF_OK;
+}
+
+int rbf_memset(rbf_ctx *ctx, void *dst_dev, int value, size_t bytes)
+{
+    if (int r = set_device(ctx)) return r;
+    if (bytes == 0) return RBF_OK;
+    if (!dst_dev) return fail(RBF_EINVAL, "dst_dev is null");
+    HIP_TRY(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return RBF_OK;
+}
+
+int rbf_memcpy_h2d(rbf_ctx *ctx, void *dst_dev, const void *src, size_t bytes)
+{
+    if (int r = set_device(ctx)) return r;
+    if (bytes == 0) return RBF_OK;
+    if (!dst_dev || !src) return fail(RBF_EINVAL, "null pointer");
+    HIP_TRY(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RBF_OK;
+}
+
+int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes)
+{
+    if (int r = set_device(ctx)) return r;
+    if (bytes == 0) return RBF_OK;
+    if (!dst || !src_dev) return fail(RBF_EINVAL, "null pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RBF_OK;
+}
+
+int rbf_timing_enable(rbf_ctx *ctx, int on)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!on) { if (int r = drain_timing(ctx)) return r; }
+    ctx->timing = on != 0;
+    return RBF_OK;
+}
+
+int rbf_timing_reset(rbf_ctx *ctx)
+{
+    if (int r = set_device(ctx)) return r;
+    if (int r = drain_timing(ctx)) return r;
+    for (int k = 0; k < RBF_K_COUNT; ++k) { ctx->total_ms[k] = 0; ctx->launches[k] = 0; }
+    return RBF_OK;
+}
+
+int rbf_timing_read(rbf_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches)
+{
+    if (int r = set_device(ctx)) return r;
+    if (kernel_id < 0 || kernel_id >= RBF_K_COUNT) return fail(RBF_EINVAL, "kernel id %d", kernel_id);
+    if (int r = drain_timing(ctx)) return r;
+    if (total_ms) *total_ms = ctx->total_ms[kernel_id];
+    if (launches) *launches = ctx->launches[kernel_id];
+    return RBF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host math
+// ------------------------------------------------------------------------------------------
+int rbf_optimal_params(uint64_t n, uint64_t ones, double *k_out, uint64_t *l_out)
+{
+    if (!k_out || !l_out) return fail(RBF_EINVAL, "null output");
+    *k_out = 0.0; *l_out = 0;
+    if (n == 0 || ones > n) return fail(RBF_EINVAL, "need 0 <= ones <= n, n > 0");
+    // np.sum(uint8) / n : both operands become float64 (improved_video_compressor.py:211-212)
+    const double p = (double)ones / (double)n;
+    if (p <= 0.0001) return RBF_OK;                         // :174
+    if (p >= 0.32453) return RBF_OK;                        // :177 (P_STAR)
+    const double q = 1 - p;
+    const double L = std::log(2.0);
+    const double k = std::log2(q * std::pow(L, 2.0) / p);   // :185  (float ** int -> pow)
+    if (std::isnan(k) || k <= 0) return RBF_OK;             // :188
+    const double gamma = 1 / L;
+    const double lf = p * (double)n * k * gamma;            // :193, left-to-right products
+    const uint64_t l = (uint64_t)lf;                        // int(): truncation (lf > 0)
+    *k_out = k > 0.1 ? k : 0.1;                             // max(0.1, k)
+    *l_out = l > 1 ? l : 1;                                 // max(1, l)
+    return RBF_OK;
+}
+
+int rbf_activation_threshold(double k_star, uint32_t *floor_k, uint64_t *threshold)
+{
+    if (!floor_k || !threshold) return fail(RBF_EINVAL, "null output");
+    if (!(k_star >= 0.0) || k_star > 64.0) return fail(RBF_ERANGE, "k* = %g outside [0, 64]", k_star);
+    const double fl = std::floor(k_star);
+    *floor_k = (uint32_t)fl;
+    const double pa = k_star - fl;                          // p_activation, :58
+    if (!(pa > 0.0)) { *threshold = 0; return RBF_OK; }     // `x < 0.0` is never true
+    // RN(h / (2^64-1)) >= pa  <=>  h / (2^64-1) > mid, mid = midpoint of pa and its predecessor
+    // (no tie is possible: mid is dyadic with an odd numerator, 2^64-1 is odd).
+    int ex;
+    const double fr = std::frexp(pa, &ex);                  // pa = fr * 2^ex, fr in [0.5, 1)
+    const uint64_t A = (uint64_t)std::ldexp(fr, 53);        // 2^52 <= A < 2^53
+    const int s = ex - 53 - 2;                              // pa = 4A * 2^s
+    const uint64_t N = (A == (1ull << 52)) ? 4 * A - 1 : 4 * A - 2;   // mid = N * 2^s
+    const int sh = -s;                                      // pa < 1 -> sh >= 55
+    if (sh >= 128) { *threshold = 1; return RBF_OK; }
+    const unsigned __int128 X = (unsigned __int128)N * (unsigned __int128)0xFFFFFFFFFFFFFFFFull;
+    *threshold = (uint64_t)(X >> sh) + 1;                   // floor(mid * (2^64-1)) + 1
+    return RBF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// shared argument plumbing
+// ------------------------------------------------------------------------------------------
+static int upload_params(rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes)
+{
+    const size_t bytes = (size_t)nframes * sizeof(FrameDev);
+    if (int r = grow((void **)&ctx->fp_dev, &ctx->fp_cap, bytes)) return r;
+    const int slot = ctx->fp_next;
+    ctx->fp_next = (slot + 1) % rbf_ctx::RING;
+    if (!ctx->fp_event[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->fp_event[slot], hipEventDisableTiming));
+    if (ctx->fp_busy[slot]) { HIP_TRY(hipEventSynchronize(ctx->fp_event[slot])); ctx->fp_busy[slot] = false; }
+    if (bytes > ctx->fp_pinned_cap[slot]) {
+        if (ctx->fp_pinned[slot]) HIP_TRY(hipHostFree(ctx->fp_pinned[slot]));
+        ctx->fp_pinned[slot] = nullptr; ctx->fp_pinned_cap[slot] = 0;
+        const size_t want = bytes + 16 * sizeof(FrameDev);
+        HIP_TRY(hipHostMalloc((void **)&ctx->fp_pinned[slot], want, hipHostMallocDefault));
+        ctx->fp_pinned_cap[slot] = want;
+    }
+    FrameDev *stage = ctx->fp_pinned[slot];
+    for (uint32_t f = 0; f < nframes; ++f) {
+        if (params[f].m == 0) return fail(RBF_EINVAL, "frame %u: filter length m must be >= 1", f);
+        if (params[f].floor_k > 64) return fail(RBF_ERANGE, "frame %u: floor_k %u > 64", f, params[f].floor_k);
+        FrameDev &d = stage[f];
+        d.m = params[f].m;
+        d.floor_k = params[f].floor_k;
+        d.T = params[f].threshold;
+        d.M = params[f].m >= 2 ? (uint64_t)((((unsigned __int128)1) << 64) / params[f].m) : 0;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->fp_dev, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->fp_event[slot], ctx->stream));
+    ctx->fp_busy[slot] = true;
+    return RBF_OK;
+}
+
+static int check_frame_geometry(uint64_t n, uint32_t nframes, uint64_t mask_stride_bytes)
+{
+    if (n == 0 || n > 0xFFFFFFFFull) return fail(RBF_ERANGE, "n = %llu outside [1, 2^32-1]", (unsigned long long)n);
+    if (nframes == 0) return fail(RBF_EINVAL, "nframes must be >= 1");
+    if (mask_stride_bytes % 8 || mask_stride_bytes < ((n + 63) / 64) * 8)
+        return fail(RBF_EINVAL, "mask stride %llu must be a multiple of 8 and >= %llu", (unsigned long long)mask_stride_bytes,
+                    (unsigned long long)(((n + 63) / 64) * 8));
+    return RBF_OK;
+}
+
+static inline uint64_t nseg_of(uint64_t n) { return (n + SEG_PIXELS - 1) / SEG_PIXELS; }
+
+// ------------------------------------------------------------------------------------------
+// A1
+// ------------------------------------------------------------------------------------------
+int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                            uint32_t nframes, uint32_t width, uint32_t height,
+                            uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                            uint32_t sample_bytes, int32_t thr_floor,
+                            void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!frames_dev || !masks_dev || !ones_dev) return fail(RBF_EINVAL, "null device pointer");
+    if (nframes < 2) return fail(RBF_EINVAL, "need at least 2 frames, got %u", nframes);
+    if (width == 0 || height == 0) return fail(RBF_EINVAL, "empty frame %ux%u", width, height);
+    if (sample_bytes != 1 && sample_bytes != 2) return fail(RBF_EINVAL, "sample_bytes must be 1 or 2, got %u", sample_bytes);
+    if (pixel_stride_bytes < sample_bytes || pixel_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "pixel stride %u incompatible with %u-byte samples", pixel_stride_bytes, sample_bytes);
+    if (row_pitch_bytes < (uint64_t)width * pixel_stride_bytes || row_pitch_bytes % sample_bytes) return fail(RBF_EINVAL, "row pitch %llu too small or misaligned", (unsigned long long)row_pitch_bytes);
+    if (frame_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "frame stride misaligned");
+    const uint64_t n = (uint64_t)width * height;
+    if (int r = check_frame_geometry(n, nframes - 1, mask_stride_bytes)) return r;
+    const uint32_t pairs = nframes - 1;
+    HIP_TRY(hipMemsetAsync(ones_dev, 0, (size_t)pairs * sizeof(uint64_t), ctx->stream));
+    const uint64_t nwords = (n + 63) / 64;
+    uint64_t bx = (nwords + WG_WAVES * 16 - 1) / (WG_WAVES * 16);      // ~16 words per wave
+    if (bx < 1) bx = 1;
+    if (bx > 65535) bx = 65535;
+    dim3 grid((uint32_t)bx, pairs), block(WG_THREADS);
+    {
+        LaunchTimer t(ctx, RBF_K_MASK);
+        if (sample_bytes == 1)
+            hipLaunchKernelGGL(k_residual_mask<uint8_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
+                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev);
+        else
+            hipLaunchKernelGGL(k_residual_mask<uint16_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
+                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// A4 + A5
+// ------------------------------------------------------------------------------------------
+static int check_filter_strides(const rbf_filter_params *params, uint32_t nframes, uint64_t filter_stride_bytes)
+{
+    if (filter_stride_bytes % 8) return fail(RBF_EINVAL, "filter stride must be a multiple of 8");
+    for (uint32_t f = 0; f < nframes; ++f) {
+        const uint64_t need = (((uint64_t)params[f].m + 63) / 64) * 8;
+        if (filter_stride_bytes < need) return fail(RBF_EINVAL, "frame %u: filter stride %llu < %llu", f, (unsigned long long)filter_stride_bytes, (unsigned long long)need);
+    }
+    return RBF_OK;
+}
+
+int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
+                           uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                           const rbf_seeds *seeds,
+                           void *filters_dev, uint64_t filter_stride_bytes,
+                           void *witnesses_dev, uint64_t witness_stride_bytes,
+                           uint64_t *stats_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!masks_dev || !params || !seeds || !filters_dev || !witnesses_dev || !stats_dev) return fail(RBF_EINVAL, "null pointer");
+    if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
+    if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
+    if (witness_stride_bytes % 8 || witness_stride_bytes < ((n + 63) / 64) * 8) return fail(RBF_EINVAL, "witness stride too small or misaligned");
+    if (nframes > 65535) return fail(RBF_ERANGE, "at most 65535 frames per batch");
+    const uint64_t nseg = nseg_of(n);
+    if (int r = upload_params(ctx, params, nframes)) return r;
+    if (int r = grow((void **)&ctx->seg_bits, &ctx->seg_bits_cap, (size_t)nframes * nseg * SEG_WORDS * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * nseg * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * nseg * 8)) return r;
+    const Seeds sd{seeds->h1, seeds->h2, seeds->act};
+
+    HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
+    HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)nframes * witness_stride_bytes, ctx->stream));
+    {
+        const uint64_t nwords32 = (n + 31) / 32;
+        uint64_t bx = (nwords32 + WG_THREADS - 1) / WG_THREADS;
+        if (bx > 65535) bx = 65535;
+        LaunchTimer t(ctx, RBF_K_INSERT);
+        hipLaunchKernelGGL(k_insert, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, ctx->fp_dev, sd,
+                           (uint32_t *)filters_dev, filter_stride_bytes / 4);
+    }
+    {
+        const uint64_t bx = (nseg + WG_WAVES - 1) / WG_WAVES;
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(k_query<true>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, ctx->fp_dev, sd,
+                           (const uint32_t *)filters_dev, filter_stride_bytes / 4,
+                           ctx->seg_bits, ctx->seg_cnt, nseg, (uint64_t *)nullptr);
+    }
+    {
+        LaunchTimer t(ctx, RBF_K_STITCH);
+        hipLaunchKernelGGL(k_stitch_witness, dim3(nframes), dim3(1024), 0, ctx->stream,
+                           ctx->seg_bits, ctx->seg_cnt, ctx->seg_off, nseg,
+                           (uint32_t *)witnesses_dev, witness_stride_bytes / 4,
+                           (const uint32_t *)filters_dev, filter_stride_bytes / 4, ctx->fp_dev, stats_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// A6
+// ------------------------------------------------------------------------------------------
+int rbf_bloom_decode_batch(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_stride_bytes,
+                           const void *witnesses_dev, uint64_t witness_stride_bytes,
+                           uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                           const rbf_seeds *seeds,
+                           void *masks_dev, uint64_t mask_stride_bytes)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!filters_dev || !witnesses_dev || !params || !seeds || !masks_dev) return fail(RBF_EINVAL, "null pointer");
+    if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
+    if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
+    if (witness_stride_bytes % 8) return fail(RBF_EINVAL, "witness stride must be a multiple of 8");
+    if (nframes > 65535) return fail(RBF_ERANGE, "at most 65535 frames per batch");
+    const uint64_t nseg = nseg_of(n);
+    if (int r = upload_params(ctx, params, nframes)) return r;
+    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * nseg * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * nseg * 8)) return r;
+    if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * nseg * SEG_ITERS * 8)) return r;
+    const Seeds sd{seeds->h1, seeds->h2, seeds->act};
+    const uint64_t bx = (nseg + WG_WAVES - 1) / WG_WAVES;
+    {
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(k_query<false>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           (const uint32_t *)nullptr, (uint64_t)0, n, ctx->fp_dev, sd,
+                           (const uint32_t *)filters_dev, filter_stride_bytes / 4,
+                           (uint32_t *)nullptr, ctx->seg_cnt, nseg, ctx->pass_words);
+    }
+    {
+        LaunchTimer t(ctx, RBF_K_STITCH);
+        hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, nseg, (uint64_t *)nullptr);
+    }
+    {
+        LaunchTimer t(ctx, RBF_K_EXPAND);
+        hipLaunchKernelGGL(k_expand_mask, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           ctx->pass_words, ctx->seg_off, nseg, (const uint32_t *)witnesses_dev, witness_stride_bytes / 4,
+                           (uint64_t *)masks_dev, mask_stride_bytes / 8, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-index surface
+// ------------------------------------------------------------------------------------------
+static int one_frame(const rbf_filter_params *p, FrameDev *d)
+{
+    if (!p) return fail(RBF_EINVAL, "params is null");
+    if (p->m == 0) return fail(RBF_EINVAL, "filter length m must be >= 1");
+    if (p->floor_k > 64) return fail(RBF_ERANGE, "floor_k %u > 64", p->floor_k);
+    d->m = p->m; d->floor_k = p->floor_k; d->T = p->threshold;
+    d->M = p->m >= 2 ? (uint64_t)((((unsigned __int128)1) << 64) / p->m) : 0;
+    return RBF_OK;
+}
+
+static uint32_t index_grid(uint64_t count)
+{
+    uint64_t b = (count + WG_THREADS - 1) / WG_THREADS;
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;
+    return (uint32_t)b;
+}
+
+int rbf_filter_insert_indices(rbf_ctx *ctx, void *filter_dev, const rbf_filter_params *params,
+                              const rbf_seeds *seeds, const uint32_t *indices_dev, uint64_t count)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!filter_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
+    FrameDev fd;
+    if (int r = one_frame(params, &fd)) return r;
+    if (count == 0) return RBF_OK;
+    if (!indices_dev) return fail(RBF_EINVAL, "indices_dev is null");
+    {
+        LaunchTimer t(ctx, RBF_K_INDEX);
+        hipLaunchKernelGGL(k_index_insert, dim3(index_grid(count)), dim3(WG_THREADS), 0, ctx->stream,
+                           (uint32_t *)filter_dev, fd, Seeds{seeds->h1, seeds->h2, seeds->act}, indices_dev, count);
+    }
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+int rbf_filter_query_indices(rbf_ctx *ctx, const void *filter_dev, const rbf_filter_params *params,
+                             const rbf_seeds *seeds, const uint32_t *indices_dev, uint64_t count,
+                             uint8_t *out_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!filter_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
+    FrameDev fd;
+    if (int r = one_frame(params, &fd)) return r;
+    if (count == 0) return RBF_OK;
+    if (!indices_dev || !out_dev) return fail(RBF_EINVAL, "null pointer");
+    {
+        LaunchTimer t(ctx, RBF_K_INDEX);
+        hipLaunchKernelGGL(k_index_query, dim3(index_grid(count)), dim3(WG_THREADS), 0, ctx->stream,
+                           (const uint32_t *)filter_dev, fd, Seeds{seeds->h1, seeds->h2, seeds->act}, indices_dev, count, out_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// A2 / A8
+// ------------------------------------------------------------------------------------------
+static int values_common(rbf_ctx *ctx, void *frame_dev, uint32_t width, uint32_t height,
+                         uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes, uint32_t sample_bytes,
+                         uint32_t channels, const void *mask_dev, void *values_dev, uint64_t *count_dev, bool scatter)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!frame_dev || !mask_dev || !values_dev) return fail(RBF_EINVAL, "null device pointer");
+    if (width == 0 || height == 0) return fail(RBF_EINVAL, "empty frame");
+    if (sample_bytes != 1 && sample_bytes != 2) return fail(RBF_EINVAL, "sample_bytes must be 1 or 2");
+    if (channels == 0 || channels > 4) return fail(RBF_EINVAL, "channels must be 1..4");
+    if (pixel_stride_bytes < channels * sample_bytes) return fail(RBF_EINVAL, "pixel stride smaller than channels*sample_bytes");
+    if (row_pitch_bytes < (uint64_t)width * pixel_stride_bytes) return fail(RBF_EINVAL, "row pitch too small");
+    const uint64_t n = (uint64_t)width * height;
+    if (n > 0xFFFFFFFFull) return fail(RBF_ERANGE, "frame too large");
+    const uint64_t nseg = nseg_of(n);
+    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nseg * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nseg * 8)) return r;
+    const uint64_t bx = (nseg + WG_WAVES - 1) / WG_WAVES;
+    LaunchTimer t(ctx, scatter ? RBF_K_SCATTER : RBF_K_GATHER);
+    hipLaunchKernelGGL(k_mask_segment_counts, dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (const uint64_t *)mask_dev, n, ctx->seg_cnt, nseg);
+    hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, nseg, count_dev);
+    if (sample_bytes == 1) {
+        if (scatter) hipLaunchKernelGGL((k_values<uint8_t, true>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint8_t *)values_dev);
+        else hipLaunchKernelGGL((k_values<uint8_t, false>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint8_t *)values_dev);
+    } else {
+        if (scatter) hipLaunchKernelGGL((k_values<uint16_t, true>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint16_t *)values_dev);
+        else hipLaunchKernelGGL((k_values<uint16_t, false>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint16_t *)values_dev);
+    }
+    return RBF_OK;
+}
+
+int rbf_gather_values(rbf_ctx *ctx, const void *frame_dev, uint32_t width, uint32_t height,
+                      uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes, uint32_t sample_bytes,
+                      uint32_t channels, const void *mask_dev, void *values_dev, uint64_t *count_dev)
+{
+    if (!count_dev) return fail(RBF_EINVAL, "count_dev is null");
+    if (int r = values_common(ctx, (void *)frame_dev, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes, channels, mask_dev, values_dev, count_dev, false)) return r;
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+int rbf_scatter_values(rbf_ctx *ctx, void *frame_dev, uint32_t width, uint32_t height,
+                       uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes, uint32_t sample_bytes,
+                       uint32_t channels, const void *mask_dev, const void *values_dev)
+{
+    if (int r = values_common(ctx, frame_dev, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes, channels, mask_dev, (void *)values_dev, nullptr, true)) return r;
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+}  // extern "C"

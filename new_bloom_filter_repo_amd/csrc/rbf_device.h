@@ -1,0 +1,131 @@
+// rbf_device.h -- gfx950 device-side building blocks (wave64, HIP).
+//
+// XXH64 of the decimal ASCII key str(i), modular double hashing without 2^64 wrap, and the
+// MSB-first bit addressing used by every packed bit vector at the ABI.
+// Reference semantics: improved_video_compressor.py:65-97 (see include/rbf.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rbf {
+
+constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL;
+constexpr uint64_t P2 = 0xC2B2AE3D27D4EB4FULL;
+constexpr uint64_t P3 = 0x165667B19E3779F9ULL;
+constexpr uint64_t P4 = 0x85EBCA77C2B2AE63ULL;
+constexpr uint64_t P5 = 0x27D4EB2F165667C5ULL;
+
+constexpr int WAVE = 64;
+
+// Per-frame filter geometry as the kernels see it.
+struct FrameDev {
+    uint32_t m;        // filter bits
+    uint32_t floor_k;  // deterministic probes
+    uint64_t T;        // activation threshold: extra probe iff h_act < T
+    uint64_t M;        // floor(2^64 / m) for m >= 2 (Barrett reciprocal); unused when m == 1
+};
+
+struct Seeds { uint64_t h1, h2, act; };
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+// Packed vectors are MSB-first per byte (numpy.packbits).  In a little-endian 32-bit word the
+// stream bit i sits at position (i & 31) ^ 7.
+__device__ __forceinline__ uint32_t msb_pos(uint32_t i) { return (i & 31u) ^ 7u; }
+__device__ __forceinline__ uint32_t msb_bit(uint32_t i) { return 1u << msb_pos(i); }
+
+// natural (bit i at position i) <-> MSB-first-per-byte, 32- and 64-bit words (an involution).
+__device__ __forceinline__ uint32_t flip_bytes32(uint32_t x) { return __builtin_bswap32(__builtin_bitreverse32(x)); }
+__device__ __forceinline__ uint64_t flip_bytes64(uint64_t x) { return __builtin_bswap64(__builtin_bitreverse64(x)); }
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ uint32_t rank_below(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ---- decimal key -----------------------------------------------------------------------------
+// str(v) as little-endian bytes: byte 0 = most significant digit.  len <= 10 for uint32.
+struct DecKey { uint64_t lo; uint32_t hi; uint32_t len; };
+
+__device__ __forceinline__ DecKey make_key(uint32_t v)
+{
+    DecKey k; k.lo = 0; k.hi = 0; k.len = 0;
+    do {
+        const uint32_t q = v / 10u;
+        const uint32_t d = v - q * 10u;
+        k.hi = (k.hi << 8) | (uint32_t)(k.lo >> 56);
+        k.lo = (k.lo << 8) | (uint64_t)(0x30u + d);
+        v = q;
+        ++k.len;
+    } while (v);
+    return k;
+}
+
+// XXH64(key, seed) for keys shorter than 32 bytes (public xxHash spec, "small input" path).
+__device__ __forceinline__ uint64_t xxh64_key(const DecKey &k, uint64_t seed)
+{
+    uint64_t h = seed + P5 + (uint64_t)k.len;
+    uint64_t rest;
+    uint32_t cnt;
+    if (k.len >= 8) {
+        uint64_t k1 = k.lo * P2;
+        k1 = rotl64(k1, 31) * P1;
+        h ^= k1;
+        h = rotl64(h, 27) * P1 + P4;
+        rest = k.hi; cnt = k.len - 8;              // <= 2 bytes left: no 4-byte round
+    } else if (k.len >= 4) {
+        h ^= (uint64_t)(uint32_t)k.lo * P1;
+        h = rotl64(h, 23) * P2 + P3;
+        rest = k.lo >> 32; cnt = k.len - 4;
+    } else {
+        rest = k.lo; cnt = k.len;
+    }
+    for (uint32_t t = 0; t < cnt; ++t) {
+        h ^= (rest & 0xFFu) * P5;
+        h = rotl64(h, 11) * P1;
+        rest >>= 8;
+    }
+    h ^= h >> 33; h *= P2;
+    h ^= h >> 29; h *= P3;
+    h ^= h >> 32;
+    return h;
+}
+
+// h mod m, exact, via Barrett with M = floor(2^64/m): q in {floor(h/m)-1, floor(h/m)}.
+__device__ __forceinline__ uint32_t mod_m(uint64_t h, uint32_t m, uint64_t M)
+{
+    if (m == 1u) return 0u;
+    const uint64_t q = __umul64hi(h, M);
+    uint64_t r = h - q * (uint64_t)m;
+    if (r >= m) r -= m;
+    return (uint32_t)r;
+}
+
+// The probe sequence of one key: positions (h1 + j*h2) mod m for j = 0..floor_k-1, plus
+// j = floor_k when activated -- evaluated as ((h1 mod m) + j*(h2 mod m)) mod m, which equals the
+// reference's unbounded-integer expression (improved_video_compressor.py:81).
+struct Probe {
+    uint32_t pos;    // current position
+    uint32_t step;   // h2 mod m
+    bool extra;      // activation decision
+};
+
+__device__ __forceinline__ Probe make_probe(uint32_t index, const FrameDev &f, const Seeds &s)
+{
+    const DecKey key = make_key(index);
+    Probe p;
+    p.pos = mod_m(xxh64_key(key, s.h1), f.m, f.M);
+    p.step = mod_m(xxh64_key(key, s.h2), f.m, f.M);
+    p.extra = xxh64_key(key, s.act) < f.T;
+    return p;
+}
+
+__device__ __forceinline__ void advance(Probe &p, uint32_t m)
+{
+    const uint64_t s = (uint64_t)p.pos + (uint64_t)p.step;
+    p.pos = (uint32_t)(s >= m ? s - m : s);
+}
+
+}  // namespace rbf

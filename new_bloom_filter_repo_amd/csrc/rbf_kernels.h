@@ -1,0 +1,416 @@
+// rbf_kernels.h -- gfx950 kernels of the rational-Bloom residual coder (generic path).
+//
+// Work decomposition: a SEGMENT is 1024 consecutive pixels (16 wave-iterations of 64); a wave
+// owns one segment, so every per-segment quantity (pass count, compacted witness bits) is
+// produced without inter-wave communication.  blockIdx.y is the frame of the batch.
+//
+// Bit vectors at rest are MSB-first per byte (see rbf_device.h); the per-segment staging
+// streams that only kernels see are natural order.
+#pragma once
+#include "rbf_device.h"
+
+namespace rbf {
+
+constexpr int SEG_PIXELS = 1024;                 // pixels per segment (one wave)
+constexpr int SEG_ITERS = SEG_PIXELS / WAVE;     // 16
+constexpr int SEG_WORDS = SEG_PIXELS / 32;       // 32 staging dwords per segment
+constexpr int WG_THREADS = 256;
+constexpr int WG_WAVES = WG_THREADS / WAVE;      // 4
+
+// ------------------------------------------------------------------------------------------
+// A1  residual mask: bit = abs_int16(prev - curr) > thr   (improved_video_compressor.py:801,808)
+// ------------------------------------------------------------------------------------------
+template <typename SAMPLE>
+__device__ __forceinline__ bool residual_bit(SAMPLE a, SAMPLE b, int32_t thr)
+{
+    // numpy: astype(int16) wraps uint16; int16 - int16 wraps; np.abs(int16 -32768) stays -32768.
+    const int16_t d = (int16_t)(uint16_t)((uint16_t)a - (uint16_t)b);
+    const int16_t ad = d < 0 ? (int16_t)(uint16_t)(0u - (uint16_t)d) : d;
+    return (int32_t)ad > thr;
+}
+
+template <typename SAMPLE>
+__global__ __launch_bounds__(WG_THREADS) void k_residual_mask(
+    const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t width, uint64_t n,
+    uint64_t row_pitch, uint32_t pixel_stride, int32_t thr,
+    uint64_t *__restrict__ masks, uint64_t mask_stride_words, uint64_t *__restrict__ ones)
+{
+    __shared__ uint32_t wave_ones[WG_WAVES];
+    const uint32_t f = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint8_t *prev = frames + (uint64_t)f * frame_stride;
+    const uint8_t *curr = prev + frame_stride;
+    uint64_t *mask = masks + (uint64_t)f * mask_stride_words;
+    const uint64_t nwords = (n + 63) >> 6;
+    uint32_t cnt = 0;
+    // one 64-pixel word per wave per step, block-contiguous
+    for (uint64_t w = (uint64_t)blockIdx.x * WG_WAVES + wave; w < nwords; w += (uint64_t)gridDim.x * WG_WAVES) {
+        const uint64_t i = w * 64 + lane;
+        bool bit = false;
+        if (i < n) {
+            const uint64_t y = i / width, x = i - y * width;
+            const uint64_t off = y * row_pitch + x * pixel_stride;
+            const SAMPLE a = *(const SAMPLE *)(prev + off);
+            const SAMPLE b = *(const SAMPLE *)(curr + off);
+            bit = residual_bit<SAMPLE>(a, b, thr);
+        }
+        const uint64_t word = __ballot(bit);
+        cnt += __popcll(word);
+        if (lane == 0) mask[w] = flip_bytes64(word);
+    }
+    if (lane == 0) wave_ones[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int k = 0; k < WG_WAVES; ++k) s += wave_ones[k];
+        if (s) atomicAdd((unsigned long long *)&ones[f], (unsigned long long)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A4  insert: every '1' position of the mask sets its probe bits (add_index, :99-114)
+// ------------------------------------------------------------------------------------------
+// Each lane takes one 32-bit mask word; the wave expands the set positions into an LDS list so
+// that the (expensive) hashing runs with all lanes busy although only ~9 % of pixels are set.
+__global__ __launch_bounds__(WG_THREADS) void k_insert(
+    const uint32_t *__restrict__ masks, uint64_t mask_stride_words32, uint64_t n,
+    const FrameDev *__restrict__ fp, Seeds seeds,
+    uint32_t *__restrict__ filters, uint64_t filter_stride_words32)
+{
+    __shared__ uint32_t list[WG_WAVES][WAVE * 32];
+    const uint32_t f = blockIdx.y;
+    const FrameDev fd = fp[f];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t *mask = masks + (uint64_t)f * mask_stride_words32;
+    uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
+    const uint64_t nwords = (n + 31) >> 5;
+    uint32_t *mylist = list[wave];
+
+    for (uint64_t w0 = ((uint64_t)blockIdx.x * WG_WAVES + wave) * WAVE; w0 < nwords;
+         w0 += (uint64_t)gridDim.x * WG_WAVES * WAVE) {
+        const uint64_t w = w0 + lane;
+        uint32_t bits = 0;
+        if (w < nwords) {
+            bits = flip_bytes32(mask[w]);                       // natural order
+            const uint64_t last = n - (w << 5);                 // valid bits in this word
+            if (last < 32) bits &= (1u << last) - 1u;           // ignore pad bits
+        }
+        // exclusive prefix of popcounts across the wave
+        const uint32_t c = __popc(bits);
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += t;
+        }
+        const uint32_t total = __shfl(incl, WAVE - 1);
+        uint32_t off = incl - c;
+        const uint32_t base = (uint32_t)(w << 5);
+        while (bits) {
+            const uint32_t b = __builtin_ctz(bits);
+            mylist[off++] = base + b;
+            bits &= bits - 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t t = lane; t < total; t += WAVE) {
+            Probe p = make_probe(mylist[t], fd, seeds);
+            for (uint32_t j = 0; j < fd.floor_k; ++j) {
+                atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+                advance(p, fd.m);
+            }
+            if (p.extra) atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A5 / A6  query: test every position in order (check_index, :116-138)
+// ------------------------------------------------------------------------------------------
+// ENCODE: the mask bits of passing positions are compacted, per segment, into a natural-order
+//         staging stream (seg_bits) + a pass count (seg_cnt); k_stitch_witness concatenates.
+// DECODE: the 64-bit pass word of every wave-iteration is stored (pass_words) + seg_cnt;
+//         k_expand_mask turns witness bits back into mask bits.
+template <bool ENCODE>
+__global__ __launch_bounds__(WG_THREADS) void k_query(
+    const uint32_t *__restrict__ masks, uint64_t mask_stride_words32, uint64_t n,
+    const FrameDev *__restrict__ fp, Seeds seeds,
+    const uint32_t *__restrict__ filters, uint64_t filter_stride_words32,
+    uint32_t *__restrict__ seg_bits, uint32_t *__restrict__ seg_cnt, uint64_t nseg,
+    uint64_t *__restrict__ pass_words)
+{
+    __shared__ uint32_t wbuf[WG_WAVES][SEG_WORDS];
+    const uint32_t f = blockIdx.y;
+    const FrameDev fd = fp[f];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
+    const bool live = seg < nseg;
+    const uint32_t *mask = ENCODE ? masks + (uint64_t)f * mask_stride_words32 : nullptr;
+    const uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
+    if (ENCODE && lane < SEG_WORDS) wbuf[wave][lane] = 0;
+    __syncthreads();
+
+    uint32_t woff = 0;
+    if (live) {
+        const uint64_t base = seg * SEG_PIXELS;
+        for (int it = 0; it < SEG_ITERS; ++it) {
+            const uint64_t i64 = base + (uint64_t)it * WAVE + lane;
+            const bool valid = i64 < n;
+            const uint32_t i = (uint32_t)i64;
+            bool pass = valid;
+            if (valid) {
+                Probe p = make_probe(i, fd, seeds);
+                for (uint32_t j = 0; j < fd.floor_k; ++j) {
+                    pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
+                    advance(p, fd.m);
+                }
+                if (p.extra) pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
+            }
+            const uint64_t pw = __ballot(pass);
+            if (ENCODE) {
+                if (pass) {
+                    const uint32_t mb = (mask[i >> 5] >> msb_pos(i)) & 1u;
+                    if (mb) {
+                        const uint32_t dst = woff + rank_below(pw);
+                        atomicOr(&wbuf[wave][dst >> 5], 1u << (dst & 31u));
+                    }
+                }
+            } else {
+                if (lane == 0) pass_words[(uint64_t)f * (nseg * SEG_ITERS) + seg * SEG_ITERS + it] = pw;
+            }
+            woff += __popcll(pw);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = woff;
+        if (ENCODE && lane < SEG_WORDS)
+            seg_bits[((uint64_t)f * nseg + seg) * SEG_WORDS + lane] = wbuf[wave][lane];
+    }
+}
+
+// Block-wide exclusive scan helper (blockDim.x == 1024): returns exclusive prefix, *total = sum.
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *smem /*[16]*/, uint32_t *total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += t;
+    }
+    __syncthreads();                     // protect smem reuse across calls
+    if (lane == WAVE - 1) smem[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t s = smem[k];
+        if ((uint32_t)k < wave) wave_off += s;
+        tot += s;
+    }
+    *total = tot;
+    return wave_off + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// witness stitch: exclusive scan of the segment pass counts, then every staging dword is
+// shifted to its final bit offset and OR-ed into the (pre-zeroed) packed witness.
+// One workgroup of 1024 threads per frame.  Also counts the filter's set bits.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_stitch_witness(
+    const uint32_t *__restrict__ seg_bits, const uint32_t *__restrict__ seg_cnt,
+    uint64_t *__restrict__ seg_off, uint64_t nseg,
+    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32,
+    const uint32_t *__restrict__ filters, uint64_t filter_stride_words32,
+    const FrameDev *__restrict__ fp, uint64_t *__restrict__ stats)
+{
+    __shared__ uint32_t smem[16];
+    __shared__ unsigned long long red[16];
+    const uint32_t f = blockIdx.x;
+    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
+    const uint32_t *bits = seg_bits + (uint64_t)f * nseg * SEG_WORDS;
+    uint64_t *off = seg_off + (uint64_t)f * nseg;
+    uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
+
+    uint64_t carry = 0;
+    for (uint64_t s0 = 0; s0 < nseg; s0 += 1024) {
+        const uint64_t s = s0 + threadIdx.x;
+        const uint32_t v = s < nseg ? cnt[s] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_1024(v, smem, &tot);
+        if (s < nseg) off[s] = carry + ex;
+        carry += tot;
+    }
+    __syncthreads();   // off[] written by this block, read below by other threads of the block
+    const uint64_t pieces = nseg * SEG_WORDS;
+    for (uint64_t idx = threadIdx.x; idx < pieces; idx += 1024) {
+        const uint64_t s = idx / SEG_WORDS;
+        const uint32_t d = (uint32_t)(idx % SEG_WORDS);
+        if (32u * d >= cnt[s]) continue;
+        const uint32_t v = bits[idx];
+        if (!v) continue;
+        const uint64_t o = off[s] + 32u * d;
+        const uint32_t sh = (uint32_t)(o & 31u);
+        atomicOr(&wit[o >> 5], flip_bytes32(v << sh));
+        if (sh) {
+            const uint32_t hi = v >> (32u - sh);
+            if (hi) atomicOr(&wit[(o >> 5) + 1], flip_bytes32(hi));
+        }
+    }
+    // popcount of the filter
+    const uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
+    const uint64_t mwords = ((uint64_t)fp[f].m + 31) >> 5;
+    unsigned long long pc = 0;
+    for (uint64_t w = threadIdx.x; w < mwords; w += 1024) pc += __popc(filt[w]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pc += __shfl_down(pc, d);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = pc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        stats[(uint64_t)f * 4 + 0] = carry;
+        stats[(uint64_t)f * 4 + 1] = t;
+        stats[(uint64_t)f * 4 + 2] = 0;
+        stats[(uint64_t)f * 4 + 3] = 0;
+    }
+}
+
+// Scan only (decode): segment offsets into the witness stream.
+__global__ __launch_bounds__(1024) void k_scan_segments(
+    const uint32_t *__restrict__ seg_cnt, uint64_t *__restrict__ seg_off, uint64_t nseg,
+    uint64_t *__restrict__ totals /* nullable: one per frame */)
+{
+    __shared__ uint32_t smem[16];
+    const uint32_t f = blockIdx.x;
+    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
+    uint64_t *off = seg_off + (uint64_t)f * nseg;
+    uint64_t carry = 0;
+    for (uint64_t s0 = 0; s0 < nseg; s0 += 1024) {
+        const uint64_t s = s0 + threadIdx.x;
+        const uint32_t v = s < nseg ? cnt[s] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_1024(v, smem, &tot);
+        if (s < nseg) off[s] = carry + ex;
+        carry += tot;
+    }
+    if (totals && threadIdx.x == 0) totals[f] = carry;
+}
+
+// ------------------------------------------------------------------------------------------
+// A6  expand: out[i] = witness[rank(i)] where position i passes, else 0   (:299-304)
+// One wave per segment; lane = pixel within each of the 16 pass words.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS) void k_expand_mask(
+    const uint64_t *__restrict__ pass_words, const uint64_t *__restrict__ seg_off, uint64_t nseg,
+    const uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32,
+    uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n)
+{
+    const uint32_t f = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
+    if (seg >= nseg) return;
+    const uint64_t *pw = pass_words + (uint64_t)f * nseg * SEG_ITERS + seg * SEG_ITERS;
+    const uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
+    uint64_t *mask = masks + (uint64_t)f * mask_stride_words64;
+    uint64_t o = seg_off[(uint64_t)f * nseg + seg];
+    const uint64_t nwords = (n + 63) >> 6;
+    for (int it = 0; it < SEG_ITERS; ++it) {
+        const uint64_t w = seg * SEG_ITERS + it;
+        if (w >= nwords) break;
+        const uint64_t p = pw[it];
+        bool bit = false;
+        if ((p >> lane) & 1ull) {
+            const uint64_t src = o + rank_below(p);
+            bit = (wit[src >> 5] >> msb_pos((uint32_t)src)) & 1u;
+        }
+        const uint64_t word = __ballot(bit);
+        if (lane == 0) mask[w] = flip_bytes64(word);
+        o += __popcll(p);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-index surface (RationalBloomFilter.add_index / check_index on arbitrary index lists)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS) void k_index_insert(
+    uint32_t *__restrict__ filt, FrameDev fd, Seeds seeds, const uint32_t *__restrict__ idx, uint64_t count)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x) {
+        Probe p = make_probe(idx[t], fd, seeds);
+        for (uint32_t j = 0; j < fd.floor_k; ++j) {
+            atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+            advance(p, fd.m);
+        }
+        if (p.extra) atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+    }
+}
+
+__global__ __launch_bounds__(WG_THREADS) void k_index_query(
+    const uint32_t *__restrict__ filt, FrameDev fd, Seeds seeds, const uint32_t *__restrict__ idx, uint64_t count,
+    uint8_t *__restrict__ out)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x) {
+        Probe p = make_probe(idx[t], fd, seeds);
+        bool pass = true;
+        for (uint32_t j = 0; j < fd.floor_k; ++j) {
+            pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
+            advance(p, fd.m);
+        }
+        if (p.extra) pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
+        out[t] = pass ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A2 / A8  changed-value gather / scatter in raster order (:811-842, :886-903)
+// ------------------------------------------------------------------------------------------
+// segment popcounts of a packed mask (one wave per segment)
+__global__ __launch_bounds__(WG_THREADS) void k_mask_segment_counts(
+    const uint64_t *__restrict__ mask, uint64_t n, uint32_t *__restrict__ seg_cnt, uint64_t nseg)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
+    if (seg >= nseg) return;
+    const uint64_t nwords = (n + 63) >> 6;
+    const uint64_t w = seg * SEG_ITERS + lane;
+    uint32_t c = (lane < SEG_ITERS && w < nwords) ? __popcll(mask[w]) : 0u;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if (lane == 0) seg_cnt[seg] = c;
+}
+
+template <typename SAMPLE, bool SCATTER>
+__global__ __launch_bounds__(WG_THREADS) void k_values(
+    uint8_t *__restrict__ frame, uint32_t width, uint64_t n, uint64_t row_pitch, uint32_t pixel_stride,
+    uint32_t channels, const uint64_t *__restrict__ mask, const uint64_t *__restrict__ seg_off, uint64_t nseg,
+    SAMPLE *__restrict__ values)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
+    if (seg >= nseg) return;
+    const uint64_t nwords = (n + 63) >> 6;
+    uint64_t o = seg_off[seg];
+    for (int it = 0; it < SEG_ITERS; ++it) {
+        const uint64_t w = seg * SEG_ITERS + it;
+        if (w >= nwords) break;
+        const uint64_t p = flip_bytes64(mask[w]);          // natural order
+        if ((p >> lane) & 1ull) {
+            const uint64_t i = w * 64 + lane;
+            const uint64_t y = i / width, x = i - y * width;
+            SAMPLE *px = (SAMPLE *)(frame + y * row_pitch + x * pixel_stride);
+            SAMPLE *v = values + (o + rank_below(p)) * channels;
+            for (uint32_t c = 0; c < channels; ++c) {
+                if (SCATTER) px[c] = v[c]; else v[c] = px[c];
+            }
+        }
+        o += __popcll(p);
+    }
+}
+
+}  // namespace rbf

@@ -1,0 +1,138 @@
+"""Batch-level host driver of the HIP path: numpy in, numpy out, everything in between on the GPU.
+
+`BloomEngine` owns the device buffers of one batch geometry (n pixels, F frames) and exposes
+the three C-ABI stages -- residual masks (A1), insert+query/witness (A4+A5), decode (A6) -- plus
+the host step between them: the float64 parameter math (params.py) that must stay on the host.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as nat
+from . import params as P
+
+
+class BloomEngine:
+    def __init__(self, ctx=None):
+        self.ctx = ctx or nat.default_context()
+        self._bufs = {}
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, nbytes):
+        b = self._bufs.get(name)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = self.ctx.alloc(max(int(nbytes), 8))
+            self._bufs[name] = b
+        return b
+
+    def close(self):
+        for b in self._bufs.values():
+            b.free()
+        self._bufs = {}
+
+    # ------------------------------------------------------------------ A1
+    def residual_masks(self, frames, threshold, luma_only=True):
+        """frames: array (F, H, W[, C]) uint8/uint16 (channel 0 = luma).  Returns
+        (masks_packed uint8 [F-1, stride], ones uint64 [F-1]); masks stay on the device as well
+        (self.masks_dev) for the following encode."""
+        frames = np.ascontiguousarray(frames)
+        if frames.ndim not in (3, 4):
+            raise ValueError("frames must be (F, H, W) or (F, H, W, C)")
+        F, H, W = frames.shape[:3]
+        C = frames.shape[3] if frames.ndim == 4 else 1
+        sb = frames.dtype.itemsize
+        if F < 2:
+            raise ValueError("need at least two frames")
+        n = H * W
+        stride = nat.packed_stride(n)
+        fb = self._buf("frames", frames.nbytes).upload(frames)
+        mb = self._buf("masks", (F - 1) * stride)
+        ob = self._buf("ones", (F - 1) * 8)
+        thr = threshold_floor(threshold)
+        nat.check(nat.lib().rbf_residual_mask_batch(
+            self.ctx.handle, fb.ptr, H * W * C * sb, F, W, H, W * C * sb, C * sb, sb, thr,
+            mb.ptr, stride, ob.ptr))
+        masks = mb.download((F - 1) * stride).reshape(F - 1, stride)
+        ones = ob.download((F - 1) * 8, dtype=np.uint64).copy()
+        self.n, self.mask_stride = n, stride
+        return masks, ones
+
+    # ------------------------------------------------------------------ A4 + A5
+    def upload_masks(self, masks_packed, n):
+        """masks_packed: uint8 [F, >=ceil(n/8)] numpy.packbits rows (pad bits zero)."""
+        masks_packed = np.atleast_2d(np.asarray(masks_packed, dtype=np.uint8))
+        F = masks_packed.shape[0]
+        stride = nat.packed_stride(n)
+        rows = np.zeros((F, stride), dtype=np.uint8)
+        nb = (n + 7) // 8
+        rows[:, :nb] = masks_packed[:, :nb]
+        self._buf("masks", F * stride).upload(rows)
+        self.n, self.mask_stride = n, stride
+        return F
+
+    def encode(self, n, plist, seeds=P.SEEDS_VIDEO, download=True):
+        """Insert + query for the F masks currently in the device mask buffer.
+        plist: F tuples (m, floor_k, T).  Returns list of dicts (filter, witness packed uint8,
+        witness_bits, filter_ones) when download, else None (results stay on the device)."""
+        F = len(plist)
+        stride = nat.packed_stride(n)
+        fstride = max(nat.packed_stride(p[0]) for p in plist)
+        wstride = nat.packed_stride(n)
+        mb = self._bufs["masks"]
+        fb = self._buf("filters", F * fstride)
+        wb = self._buf("witness", F * wstride)
+        sb = self._buf("stats", F * nat.STATS_PER_FRAME * 8)
+        arr = nat.params_array(plist)
+        sd = nat.Seeds(*[int(s) for s in seeds])
+        nat.check(nat.lib().rbf_bloom_encode_batch(
+            self.ctx.handle, mb.ptr, stride, n, F, arr, ctypes.byref(sd),
+            fb.ptr, fstride, wb.ptr, wstride, sb.ptr))
+        self.filter_stride, self.witness_stride, self.nframes = fstride, wstride, F
+        if not download:
+            return None
+        stats = sb.download(F * nat.STATS_PER_FRAME * 8, dtype=np.uint64).reshape(F, nat.STATS_PER_FRAME)
+        filt = fb.download(F * fstride).reshape(F, fstride)
+        wit = wb.download(F * wstride).reshape(F, wstride)
+        out = []
+        for f in range(F):
+            wbits = int(stats[f, 0])
+            out.append({"filter": filt[f, :(plist[f][0] + 7) // 8].copy(),
+                        "witness": wit[f, :(wbits + 7) // 8].copy(),
+                        "witness_bits": wbits, "filter_ones": int(stats[f, 1])})
+        return out
+
+    # ------------------------------------------------------------------ A6
+    def decode(self, n, plist, filters_packed, witnesses_packed, seeds=P.SEEDS_VIDEO):
+        """filters_packed / witnesses_packed: lists of packed uint8 arrays.  Returns masks
+        packed uint8 [F, ceil(n/8)]."""
+        F = len(plist)
+        stride = nat.packed_stride(n)
+        fstride = max(nat.packed_stride(p[0]) for p in plist)
+        wstride = max([nat.packed_stride(len(w) * 8) for w in witnesses_packed] + [8])
+        frows = np.zeros((F, fstride), dtype=np.uint8)
+        wrows = np.zeros((F, wstride), dtype=np.uint8)
+        for f in range(F):
+            fp = np.asarray(filters_packed[f], dtype=np.uint8)
+            wp = np.asarray(witnesses_packed[f], dtype=np.uint8)
+            frows[f, :len(fp)] = fp
+            wrows[f, :len(wp)] = wp
+        fb = self._buf("filters", F * fstride).upload(frows)
+        wb = self._buf("witness", F * wstride).upload(wrows)
+        mb = self._buf("masks", F * stride)
+        arr = nat.params_array(plist)
+        sd = nat.Seeds(*[int(s) for s in seeds])
+        nat.check(nat.lib().rbf_bloom_decode_batch(
+            self.ctx.handle, fb.ptr, fstride, wb.ptr, wstride, n, F, arr, ctypes.byref(sd), mb.ptr, stride))
+        out = mb.download(F * stride).reshape(F, stride)
+        return out[:, :(n + 7) // 8].copy()
+
+
+def threshold_floor(threshold):
+    """int32 t with (d > threshold) == (d > t) for every integer d (float compare, :808)."""
+    if threshold != threshold:           # NaN: comparison is always False
+        return 2 ** 31 - 1
+    import math
+    t = math.floor(threshold)
+    return int(max(-2 ** 31, min(2 ** 31 - 1, t)))

@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the C ABI) vs the committed reference fixtures and the CPU oracle.
+Bit-exact everywhere (integer / bit work).  Run with `-m gpu` on an MI355X."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+from new_bloom_filter_repo_amd import _native as nat
+from new_bloom_filter_repo_amd import params as P
+from new_bloom_filter_repo_amd.engine import BloomEngine
+from new_bloom_filter_repo_amd.synthetic import make_gop, make_mask, P_KSTAR_2_3
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = BloomEngine(nat.Context(0))
+    yield e
+    e.close()
+
+
+def unpack(a, nbits):
+    return np.unpackbits(np.asarray(a, dtype=np.uint8))[:nbits]
+
+
+def encode_one(eng, mask_bits, seeds, guard=True):
+    """Host flow of BloomFilterCompressor.compress for one vector; returns None on passthrough."""
+    n = len(mask_bits)
+    p = np.uint64(mask_bits.sum()) / n
+    if p >= P.P_STAR:
+        return None
+    k, l = P.optimal_params(n, p)
+    if l == 0 or (guard and l >= n):
+        return None
+    pl = [P.filter_params(k, l)]
+    eng.upload_masks(np.packbits(mask_bits)[None, :], n)
+    r = eng.encode(n, pl, seeds)[0]
+    r["k"], r["l"], r["plist"] = k, l, pl
+    return r
+
+
+def test_g3_fixtures_bit_exact(eng):
+    meta = load_json("g3_320x180.json")["cases"]
+    z = load_npz("g3_320x180.npz")
+    checked = 0
+    for rec in meta:
+        n = rec["W"] * rec["H"]
+        mask = unpack(z[rec["case"] + "_mask"], n)
+        for vname, prefix, guard in (("video", "video", True), ("bloom_compress", "bc", False)):
+            v = rec["variants"][vname]
+            r = encode_one(eng, mask, tuple(v["seeds"]), guard)
+            if v["passthrough"]:
+                assert r is None
+                continue
+            assert float(r["k"]).hex() == v["k_hex"] and r["l"] == v["l"]
+            assert r["witness_bits"] == v["wlen"] and r["filter_ones"] == v["bits_set"]
+            assert np.array_equal(r["filter"], z["%s_%s_filter" % (rec["case"], prefix)])
+            assert np.array_equal(r["witness"], z["%s_%s_witness" % (rec["case"], prefix)])
+            dec = eng.decode(n, r["plist"], [r["filter"]], [r["witness"]], tuple(v["seeds"]))
+            assert np.array_equal(unpack(dec[0], n), mask)
+            checked += 1
+        if "string" in rec["variants"]:       # config 1: rational_bloom_filter.py seeds (0, 1, ceil k)
+            v = rec["variants"]["string"]
+            k = float.fromhex(v["k_hex"])
+            assert list(P.string_filter_seeds(k)) == v["seeds"]
+            pl = [P.filter_params(k, v["l"])]
+            eng.upload_masks(np.packbits(mask)[None, :], n)
+            r = eng.encode(n, pl, tuple(v["seeds"]))[0]
+            assert np.array_equal(r["filter"], z[rec["case"] + "_str_filter"])
+            assert r["filter_ones"] == v["bits_set"] and r["witness_bits"] == v["passed"]
+            checked += 1
+    assert checked >= 12
+
+
+def test_residual_mask_vs_oracle_and_fixture(eng, oracle):
+    z = load_npz("g3_320x180.npz")
+    for rec in load_json("g3_320x180.json")["cases"][:5]:
+        frames = np.stack(make_gop(rec["seed"], rec["W"], rec["H"], 2, p=rec["density_req"]))
+        masks, ones = eng.residual_masks(frames, 0.0)
+        n = rec["W"] * rec["H"]
+        assert np.array_equal(masks[0][:n // 8], z[rec["case"] + "_mask"])
+        assert int(ones[0]) == rec["ones"]
+    # thresholds, planar 2-D frames, ragged width (n % 64 != 0)
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 256, (3, 37, 53), dtype=np.uint8)
+    for thr in (0.0, 0.5, 3.0, 17.9, 255.0, -1.0):
+        masks, ones = eng.residual_masks(a, thr)
+        for f in range(2):
+            want = oracle.residual_mask(a[f], a[f + 1], thr).reshape(-1)
+            assert np.array_equal(unpack(masks[f], 37 * 53), want), thr
+            assert int(ones[f]) == int(want.sum())
+
+
+def test_residual_mask_uint16_wrap(eng, oracle):
+    z = load_npz("g5_masks.npz")
+    for r in load_json("g5_masks.json")["rows"]:
+        name, thr = r["name"], r["thr"]
+        prev, curr = z[name + "_prev"], z[name + "_curr"]
+        masks, ones = eng.residual_masks(np.stack([prev, curr]), thr)
+        want = z["%s_mask_%s" % (name, str(thr).replace(".", "_"))]
+        assert np.array_equal(unpack(masks[0], want.size), want.reshape(-1)), (name, thr)
+        assert int(ones[0]) == r["ones"]
+
+
+def test_batch_equals_oracle(eng, oracle):
+    """A ragged batch: 5 frames of 211x97 (n % 1024 != 0, n % 64 != 0), different densities."""
+    W, H = 211, 97
+    n = W * H
+    masks = [make_mask(100 + f, n, p) for f, p in enumerate((0.004, 0.05, P_KSTAR_2_3, 0.2, 0.3))]
+    plist, ks = [], []
+    for m in masks:
+        k, l = P.optimal_params(n, np.uint64(m.sum()) / n)
+        ks.append(k)
+        plist.append(P.filter_params(k, l))
+    eng.upload_masks(np.stack([np.packbits(m) for m in masks]), n)
+    res = eng.encode(n, plist)
+    for f, m in enumerate(masks):
+        bm, wit, p, _, _ = oracle.compress(m)
+        assert np.array_equal(unpack(res[f]["filter"], plist[f][0]), bm)
+        assert res[f]["witness_bits"] == len(wit)
+        assert np.array_equal(unpack(res[f]["witness"], len(wit)), np.array(wit, dtype=np.uint8))
+        assert res[f]["filter_ones"] == int(bm.sum())
+    dec = eng.decode(n, plist, [r["filter"] for r in res], [r["witness"] for r in res])
+    for f, m in enumerate(masks):
+        assert np.array_equal(unpack(dec[f], n), m)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_g4_fullsize_digests(eng, idx):
+    """1920x1080 and 3840x2160 at k* = 2.3: SHA-256 of filter / witness made by the reference."""
+    r = load_json("g4_fullsize.json")["rows"][idx]
+    n = r["W"] * r["H"]
+    x = make_mask(r["seed"], n, r["p_req"])
+    assert hashlib.sha256(np.packbits(x).tobytes()).hexdigest() == r["mask_sha256"]
+    res = encode_one(eng, x, P.SEEDS_VIDEO)
+    assert float(res["k"]).hex() == r["k_hex"] and res["l"] == r["l"]
+    assert res["witness_bits"] == r["wlen"] and res["filter_ones"] == r["bits_set"]
+    assert hashlib.sha256(res["filter"].tobytes()).hexdigest() == r["filter_sha256"]
+    assert hashlib.sha256(res["witness"].tobytes()).hexdigest() == r["witness_sha256"]
+    dec = eng.decode(n, res["plist"], [res["filter"]], [res["witness"]])
+    assert np.array_equal(unpack(dec[0], n), x)          # encode -> decode round trip at full size
+
+
+def test_edge_geometries(eng, oracle):
+    """Tiny vectors, m == 1, floor_k == 0 (k < 1), floor_k large, all-pass and no-pass filters."""
+    for n, p, seed in ((1, 1.0, 1), (63, 0.1, 2), (64, 0.1, 3), (65, 0.2, 4), (1023, 0.05, 5), (1025, 0.3, 6), (4097, 0.001, 7)):
+        m = make_mask(seed, n, p)
+        for k, l in ((0.1, 1), (0.7, 5), (1.0, 3), (2.5, 7), (12.25, 100), (3.2062923944339987, max(1, n // 3))):
+            pl = [P.filter_params(k, l)]
+            eng.upload_masks(np.packbits(m)[None, :], n)
+            r = eng.encode(n, pl)[0]
+            f = oracle.RationalFilter(l, k)
+            for i in np.flatnonzero(m):
+                f.add_index(int(i))
+            assert np.array_equal(unpack(r["filter"], l), f.bit_array), (n, k, l)
+            wit = [int(m[i]) for i in range(n) if f.check_index(i)]
+            assert r["witness_bits"] == len(wit)
+            assert np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8))
+            if len(wit):
+                dec = eng.decode(n, pl, [r["filter"]], [r["witness"]])
+                assert np.array_equal(unpack(dec[0], n), m)
