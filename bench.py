@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the rational-Bloom insert+query path on MI355X.
+
+A step = one pass of the hot path over one GOP resident in HBM: residual masks of the 29
+inter-frames of a 1920x1080 YUV444 30-frame GOP -> ones counts to the host -> filter geometry
+(float64, host) -> Bloom insert -> query + witness compaction (BASELINE.json configs[1], k* = 2.3).
+With N > 1 every rank encodes its own GOP (independent frames shard; weak scaling) and the
+per-frame (filter, witness, stats) records are gathered to rank 0 over RCCL inside the step.
+
+Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel (query) priced at its
+ALGORITHMIC bytes (packed mask in + filter in + witness out) against the 8 TB/s HBM peak, from HIP
+event timings taken inside the timed region; `cpu_baseline` is the CPU oracle (scalar C port of the
+reference algorithm) timed on one host core on the same masks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=30, help="frames per GOP (frames-1 inter-frames are coded)")
+    ap.add_argument("--bits", type=int, default=8, choices=(8, 16))
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of CPU-oracle work (0 = auto, about 10-30 s)")
+    ap.add_argument("--verify", action="store_true", help="check the first frames against the CPU oracle after timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from new_bloom_filter_repo_amd import _native as nat
+    from new_bloom_filter_repo_amd.gop import GopCoder, torch_allocator
+    from new_bloom_filter_repo_amd.synthetic import make_gop, P_KSTAR_2_3
+
+    W, H, F = args.width, args.height, args.frames
+    n, pairs = W * H, F - 1
+    dtype = np.uint8 if args.bits == 8 else np.uint16
+    stream = torch.cuda.current_stream(device)
+    ctx = nat.Context(local_rank, stream.cuda_stream)
+    coder = GopCoder(ctx, W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device))
+    frames = np.stack(make_gop(1000 * 2 + rank, W, H, F, p=P_KSTAR_2_3, dtype=dtype))
+    coder.load_frames(frames)
+
+    gather = world > 1 and not args.no_gather
+    if gather:
+        # padded per-rank records: [filters | witness | stats] as int64 words, gathered to rank 0
+        parts = [coder.filters.tensor, coder.witness.tensor, coder.stats.tensor]
+        gl = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in parts]
+
+    def step():
+        coder.encode()
+        if gather:
+            for t, g in zip(parts, gl):
+                dist.gather(t, g, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if not args.no_kernel_timing:
+        ctx.timing_reset()
+        ctx.timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    ktimes = None
+    if not args.no_kernel_timing:
+        ctx.timing(False)
+        ktimes = ctx.timing_read()
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    res = coder.results()
+    pixels_per_step = pairs * n * world
+    value = pixels_per_step * args.steps / elapsed / 1e6
+
+    out = {
+        "metric": "Mpixels/s Bloom insert+query, 1080p residuals",
+        "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), k*=2.3, threshold 0"
+                               % (W, H, args.bits, F, pairs),
+                   "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather),
+                   "stages": "residual mask -> host params -> insert -> query+witness"},
+    }
+    if rank == 0:
+        l_sum = sum(r["l"] for r in res)
+        w_sum = sum(r["witness_bits"] for r in res)
+        # ALGORITHMIC bytes of the query launch: packed mask in + filter in + witness out
+        alg_bytes = pairs * n / 8 + l_sum / 8 + w_sum / 8
+        if ktimes and ktimes["query"][1]:
+            q_ms = ktimes["query"][0] / ktimes["query"][1]
+            achieved = alg_bytes / (q_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_query", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                               "avg_launch_ms": round(q_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                               "bytes_per_pixel": round(alg_bytes / (pairs * n), 4)}
+            out["kernels_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]}
+        else:
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(res, n, args.cpu_frames)
+        if args.verify:
+            verify(res, n)
+            out["verified_vs_oracle"] = True
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(res, n, nframes):
+    """CPU oracle (scalar C port, oracle/rbf_oracle.c) on the same masks: insert + query/witness."""
+    import ctypes
+    from oracle import oracle as orc
+    L = orc.lib()
+    seeds = (ctypes.c_uint64 * 3)(*orc.SEEDS_VIDEO)
+    nframes = nframes or min(len(res), 29)
+    t_total, px = 0.0, 0
+    for r in res[:nframes]:
+        mask = np.unpackbits(r["mask"])[:n]
+        if r["l"] == 0:
+            continue
+        bit_array = np.zeros(r["l"], dtype=np.uint8)
+        witness = np.zeros(n, dtype=np.uint8)
+        t0 = time.perf_counter()
+        L.orc_compress(mask.ctypes.data, n, r["l"], ctypes.c_double(r["k"]), seeds, bit_array.ctypes.data, witness.ctypes.data)
+        t_total += time.perf_counter() - t0
+        px += n
+    return {"value": round(px / t_total / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": "%d of the step's 1080p masks, insert+query/witness in the scalar C oracle, %.1f s" % (nframes, t_total),
+            "reference_python_mpixels_per_s": 0.38}
+
+
+def verify(res, n):
+    from oracle import oracle as orc
+    for r in res[:2]:
+        mask = np.unpackbits(r["mask"])[:n]
+        bm, wit, p, _, _ = orc.compress(mask)
+        assert np.array_equal(np.unpackbits(r["filter"])[:r["l"]], bm)
+        assert r["witness_bits"] == len(wit)
+        assert np.array_equal(np.unpackbits(r["witness"])[:len(wit)], np.array(wit, dtype=np.uint8))
+
+
+if __name__ == "__main__":
+    main()

@@ -97,8 +97,14 @@ int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes); 
 #define RBF_K_GATHER  5
 #define RBF_K_SCATTER 6
 #define RBF_K_INDEX   7
-#define RBF_K_COUNT   8
+#define RBF_K_REDUCE  8
+#define RBF_K_SCAN    9
+#define RBF_K_COUNT   10
 int rbf_timing_enable(rbf_ctx *ctx, int on);
+/* Testing knob (bit mask): bit 0 = always use the generic (global-memory filter) kernels;
+ * bit 1 = LDS fast path without double-buffering the filter.  0 (default) = pick the fastest
+ * variant that fits: the LDS-resident path needs the batch's largest filter to fit in LDS. */
+int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
 int rbf_timing_reset(rbf_ctx *ctx);
 int rbf_timing_read(rbf_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
 
@@ -109,6 +115,13 @@ int rbf_optimal_params(uint64_t n, uint64_t ones, double *k, uint64_t *l);
 /* floor(k*) and the integer activation threshold T = min{h : RN(h/(2^64-1)) >= k*-floor(k*)}
  * (improved_video_compressor.py:57-58,94-97). */
 int rbf_activation_threshold(double k_star, uint32_t *floor_k, uint64_t *threshold);
+
+/* The host step of BloomFilterCompressor.compress for a batch (:211-225): for frame f with
+ * ones[f] set bits out of n, fill params[f] (and k[f] if k != NULL).  A frame the reference would
+ * NOT Bloom-code (p >= P_STAR, l == 0, or l >= n when guard_l_ge_n != 0) gets params[f].m = 0,
+ * which every batch entry point treats as "skip this frame" (empty witness, filter untouched). */
+int rbf_plan_batch(uint64_t n, const uint64_t *ones, uint32_t nframes, int guard_l_ge_n,
+                   rbf_filter_params *params, double *k);
 
 /* ---- A1: residual mask  (VideoFrameCompressor._calculate_frame_diff, :784-808,845) ------- */
 /* mask bit = abs_int16(prev - curr) > thr_floor, with numpy's int16 wrap for 16-bit samples.
@@ -138,6 +151,21 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
                            void *filters_dev, uint64_t filter_stride_bytes,
                            void *witnesses_dev, uint64_t witness_stride_bytes,
                            uint64_t *stats_dev);
+
+/* ---- A1 + A3 + A4 + A5 for a whole GOP in one call ----------------------------------------- */
+/* residual masks of the nframes-1 consecutive pairs -> ones to the host -> rbf_plan_batch ->
+ * insert + query.  Blocks once in the middle (the parameter math needs the ones counts on the
+ * host); the Bloom kernels are enqueued when it returns.  params_out / k_out (host, nframes-1
+ * entries, nullable) receive the per-frame geometry so the caller can size and label the output.
+ * filter_stride_bytes must cover every planned filter (0.32*n bits always suffices). */
+int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                   uint32_t nframes, uint32_t width, uint32_t height,
+                   uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                   uint32_t sample_bytes, int32_t thr_floor, const rbf_seeds *seeds,
+                   void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                   void *filters_dev, uint64_t filter_stride_bytes,
+                   void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
+                   rbf_filter_params *params_out, double *k_out);
 
 /* ---- A6: decode  (BloomFilterCompressor.decompress loop, :286-307) ------------------------ */
 /* out mask bit i = witness[w++] if position i passes the filter, else 0. */

@@ -14,8 +14,8 @@ RBF_ENOMEM = -12
 RBF_EIO = -5
 RBF_ERANGE = -34
 
-K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX = range(8)
-KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index"]
+K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN = range(10)
+KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan"]
 STATS_PER_FRAME = 4
 
 
@@ -48,9 +48,13 @@ _PROTOS = {
     "rbf_memcpy_d2h": (_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     "rbf_timing_enable": (_int, [_vp, _int]),
     "rbf_timing_reset": (_int, [_vp]),
+    "rbf_ctx_force_generic": (_int, [_vp, _int]),
     "rbf_timing_read": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
     "rbf_optimal_params": (_int, [_u64, _u64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
     "rbf_activation_threshold": (_int, [ctypes.c_double, ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),
+    "rbf_plan_batch": (_int, [_u64, ctypes.POINTER(_u64), _u32, _int, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
+    "rbf_encode_gop": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, ctypes.POINTER(Seeds),
+                              _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
     "rbf_residual_mask_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _vp, _u64, _vp]),
     "rbf_bloom_encode_batch": (_int, [_vp, _vp, _u64, _u64, _u32, ctypes.POINTER(FilterParams), ctypes.POINTER(Seeds),
                                       _vp, _u64, _vp, _u64, _vp]),
@@ -171,6 +175,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def force_generic(self, on):
+        """Testing knob: never use the LDS-resident fast-path kernels."""
+        check(lib().rbf_ctx_force_generic(self.handle, int(on)))
 
     # ---- timing
     def timing(self, on):

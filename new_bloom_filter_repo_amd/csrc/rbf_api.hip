@@ -1,7 +1,7 @@
 // rbf_api.hip -- C ABI (include/rbf.h) over the gfx950 kernels.  Host side: argument checks,
 // scratch management, launches on the context's single HIP stream, optional per-kernel timing.
 #include "../../include/rbf.h"
-#include "rbf_kernels.h"
+#include "rbf_kernels_lds.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -56,6 +56,13 @@ struct rbf_ctx {
     uint32_t *seg_cnt = nullptr;     size_t seg_cnt_cap = 0;
     uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
     uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
+    uint32_t *partials = nullptr;    size_t partials_cap = 0;
+    int force_generic = 0;           // tests: 1 = never use the LDS fast path
+    int single_buffer = 0;           // tests: 1 = fast query path without filter double-buffering
+    // host staging of encode_gop
+    uint64_t *ones_pinned = nullptr; size_t host_cap = 0;
+    std::vector<rbf_filter_params> plan;
+    std::vector<double> plan_k;
     // timing
     bool timing = false;
     std::vector<Timed> pending;
@@ -170,10 +177,12 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
         if (ctx->fp_pinned[k]) (void)hipHostFree(ctx->fp_pinned[k]);
         if (ctx->fp_event[k]) (void)hipEventDestroy(ctx->fp_event[k]);
     }
+    if (ctx->ones_pinned) (void)hipHostFree(ctx->ones_pinned);
     if (ctx->seg_bits) (void)hipFree(ctx->seg_bits);
     if (ctx->seg_cnt) (void)hipFree(ctx->seg_cnt);
     if (ctx->seg_off) (void)hipFree(ctx->seg_off);
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
+    if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RBF_OK;
@@ -243,6 +252,14 @@ int rbf_timing_enable(rbf_ctx *ctx, int on)
     return RBF_OK;
 }
 
+int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
+{
+    if (!ctx) return fail(RBF_EINVAL, "null context");
+    ctx->force_generic = (on & 1) ? 1 : 0;
+    ctx->single_buffer = (on & 2) ? 1 : 0;
+    return RBF_OK;
+}
+
 int rbf_timing_reset(rbf_ctx *ctx)
 {
     if (int r = set_device(ctx)) return r;
@@ -307,6 +324,25 @@ int rbf_activation_threshold(double k_star, uint32_t *floor_k, uint64_t *thresho
     return RBF_OK;
 }
 
+int rbf_plan_batch(uint64_t n, const uint64_t *ones, uint32_t nframes, int guard_l_ge_n,
+                   rbf_filter_params *params, double *k_out)
+{
+    if (!ones || !params) return fail(RBF_EINVAL, "null pointer");
+    for (uint32_t f = 0; f < nframes; ++f) {
+        double k = 0.0; uint64_t l = 0;
+        if (int r = rbf_optimal_params(n, ones[f], &k, &l)) return r;
+        // compress(): `p >= P_STAR` is already (0, 0) in _calculate_optimal_params (:177, :215)
+        const bool skip = (l == 0) || (guard_l_ge_n && l >= n) || l > 0xFFFFFFFFull;
+        params[f].m = 0; params[f].floor_k = 0; params[f].threshold = 0;
+        if (!skip) {
+            params[f].m = (uint32_t)l;
+            if (int r = rbf_activation_threshold(k, &params[f].floor_k, &params[f].threshold)) return r;
+        }
+        if (k_out) k_out[f] = skip ? 0.0 : k;
+    }
+    return RBF_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // shared argument plumbing
 // ------------------------------------------------------------------------------------------
@@ -327,7 +363,6 @@ static int upload_params(rbf_ctx *ctx, const rbf_filter_params *params, uint32_t
     }
     FrameDev *stage = ctx->fp_pinned[slot];
     for (uint32_t f = 0; f < nframes; ++f) {
-        if (params[f].m == 0) return fail(RBF_EINVAL, "frame %u: filter length m must be >= 1", f);
         if (params[f].floor_k > 64) return fail(RBF_ERANGE, "frame %u: floor_k %u > 64", f, params[f].floor_k);
         FrameDev &d = stage[f];
         d.m = params[f].m;
@@ -352,6 +387,46 @@ static int check_frame_geometry(uint64_t n, uint32_t nframes, uint64_t mask_stri
 }
 
 static inline uint64_t nseg_of(uint64_t n) { return (n + SEG_PIXELS - 1) / SEG_PIXELS; }
+
+// Which kernels serve a batch: the LDS-resident fast path needs the largest filter of the batch
+// (plus per-wave staging) to fit one workgroup's 160 KiB of LDS; otherwise the generic kernels
+// probe / set the filter in global memory.
+constexpr size_t LDS_LIMIT = 160 * 1024;
+struct Plan {
+    bool fast_insert, fast_query, double_buffer;
+    uint32_t fwords_max, fwords_even, S;
+    size_t insert_lds_bytes, query_lds_bytes;
+    uint64_t nseg; uint32_t seg_words;
+};
+
+static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n)
+{
+    Plan p{};
+    uint32_t mmax = 0, active = 0;
+    for (uint32_t f = 0; f < nframes; ++f) { if (params[f].m > mmax) mmax = params[f].m; if (params[f].m) ++active; }
+    p.fwords_max = (uint32_t)(((uint64_t)mmax + 31) / 32);
+    p.fwords_even = (p.fwords_max + 1u) & ~1u;
+    p.insert_lds_bytes = (size_t)p.fwords_even * 4 + (size_t)IL_WAVES * IL_QUEUE * 4;
+    const size_t bufbytes = (size_t)((p.fwords_max + 3u) & ~3u) * 4, stagebytes = (size_t)QL_WAVES * QL_SEG_WORDS * 4;
+    p.double_buffer = 2 * bufbytes + stagebytes <= LDS_LIMIT && !ctx->single_buffer;
+    p.query_lds_bytes = (p.double_buffer ? 2 : 1) * bufbytes + stagebytes;
+    p.fast_insert = !ctx->force_generic && mmax > 0 && p.insert_lds_bytes <= LDS_LIMIT;
+    p.fast_query = !ctx->force_generic && mmax > 0 && p.query_lds_bytes <= LDS_LIMIT;
+    // slices per frame so that S * frames ~ one workgroup per CU (256 CUs), at most 32
+    uint32_t S = active ? 256u / active : 1u;
+    if (S < 1) S = 1;
+    if (S > 32) S = 32;
+    p.S = S;
+    p.nseg = p.fast_query ? (n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS : nseg_of(n);
+    p.seg_words = p.fast_query ? (uint32_t)QL_SEG_WORDS : (uint32_t)SEG_WORDS;
+    return p;
+}
+
+static int allow_big_lds(const void *fn)
+{
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    return RBF_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // A1
@@ -418,41 +493,120 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
     if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
     if (witness_stride_bytes % 8 || witness_stride_bytes < ((n + 63) / 64) * 8) return fail(RBF_EINVAL, "witness stride too small or misaligned");
     if (nframes > 65535) return fail(RBF_ERANGE, "at most 65535 frames per batch");
-    const uint64_t nseg = nseg_of(n);
+    const Plan pl = make_plan(ctx, params, nframes, n);
     if (int r = upload_params(ctx, params, nframes)) return r;
-    if (int r = grow((void **)&ctx->seg_bits, &ctx->seg_bits_cap, (size_t)nframes * nseg * SEG_WORDS * 4)) return r;
-    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * nseg * 4)) return r;
-    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * nseg * 8)) return r;
+    if (int r = grow((void **)&ctx->seg_bits, &ctx->seg_bits_cap, (size_t)nframes * pl.nseg * pl.seg_words * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
 
-    HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
     HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)nframes * witness_stride_bytes, ctx->stream));
-    {
+    HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)nframes * RBF_STATS_PER_FRAME * 8, ctx->stream));
+    // ---- insert
+    if (pl.fast_insert) {
+        const uint64_t part_stride = pl.fwords_even;
+        if (int r = grow((void **)&ctx->partials, &ctx->partials_cap, (size_t)nframes * pl.S * part_stride * 4)) return r;
+        if (int r = allow_big_lds((const void *)k_insert_lds)) return r;
+        {
+            LaunchTimer t(ctx, RBF_K_INSERT);
+            hipLaunchKernelGGL(k_insert_lds, dim3(pl.S, nframes), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                               (const uint8_t *)masks_dev, mask_stride_bytes, n, ctx->fp_dev, sd, ctx->partials, part_stride, pl.fwords_max);
+        }
+        {
+            LaunchTimer t(ctx, RBF_K_REDUCE);
+            const uint64_t words = filter_stride_bytes / 4;
+            uint32_t bx = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
+            if (bx < 1) bx = 1;
+            hipLaunchKernelGGL(k_filter_reduce, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                               (const uint32_t *)ctx->partials, part_stride, pl.S, ctx->fp_dev, (uint32_t *)filters_dev, words, stats_dev);
+        }
+    } else {
+        HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
         const uint64_t nwords32 = (n + 31) / 32;
         uint64_t bx = (nwords32 + WG_THREADS - 1) / WG_THREADS;
         if (bx > 65535) bx = 65535;
-        LaunchTimer t(ctx, RBF_K_INSERT);
-        hipLaunchKernelGGL(k_insert, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, ctx->fp_dev, sd,
-                           (uint32_t *)filters_dev, filter_stride_bytes / 4);
+        {
+            LaunchTimer t(ctx, RBF_K_INSERT);
+            hipLaunchKernelGGL(k_insert, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                               (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, ctx->fp_dev, sd,
+                               (uint32_t *)filters_dev, filter_stride_bytes / 4);
+        }
+        {
+            LaunchTimer t(ctx, RBF_K_REDUCE);        // S = 1 in place: only counts the set bits
+            const uint64_t words = filter_stride_bytes / 4;
+            uint32_t bx2 = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
+            if (bx2 < 1) bx2 = 1;
+            hipLaunchKernelGGL(k_filter_reduce, dim3(bx2, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                               (const uint32_t *)filters_dev, words, 1u, ctx->fp_dev, (uint32_t *)filters_dev, words, stats_dev);
+        }
     }
-    {
-        const uint64_t bx = (nseg + WG_WAVES - 1) / WG_WAVES;
+    // ---- query + witness staging
+    if (pl.fast_query) {
+        auto kern = pl.double_buffer ? k_query_lds<true, true> : k_query_lds<true, false>;
+        if (int r = allow_big_lds((const void *)kern)) return r;
+        const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
+                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, nframes, ctx->fp_dev, sd,
+                           (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+                           ctx->seg_bits, ctx->seg_cnt, pl.nseg, (uint64_t *)nullptr);
+    } else {
+        const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
         hipLaunchKernelGGL(k_query<true>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                            (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, ctx->fp_dev, sd,
                            (const uint32_t *)filters_dev, filter_stride_bytes / 4,
-                           ctx->seg_bits, ctx->seg_cnt, nseg, (uint64_t *)nullptr);
+                           ctx->seg_bits, ctx->seg_cnt, pl.nseg, (uint64_t *)nullptr);
+    }
+    // ---- stitch
+    {
+        LaunchTimer t(ctx, RBF_K_SCAN);
+        hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, pl.nseg,
+                           stats_dev, (uint32_t)RBF_STATS_PER_FRAME);
     }
     {
+        const uint64_t pieces = pl.nseg * pl.seg_words;
+        uint64_t bx = (pieces + WG_THREADS * 4 - 1) / (WG_THREADS * 4);
+        if (bx < 1) bx = 1;
+        if (bx > 4096) bx = 4096;
         LaunchTimer t(ctx, RBF_K_STITCH);
-        hipLaunchKernelGGL(k_stitch_witness, dim3(nframes), dim3(1024), 0, ctx->stream,
-                           ctx->seg_bits, ctx->seg_cnt, ctx->seg_off, nseg,
-                           (uint32_t *)witnesses_dev, witness_stride_bytes / 4,
-                           (const uint32_t *)filters_dev, filter_stride_bytes / 4, ctx->fp_dev, stats_dev);
+        hipLaunchKernelGGL(k_stitch_pieces, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           ctx->seg_bits, ctx->seg_cnt, ctx->seg_off, pl.nseg, pl.seg_words == 16 ? 4u : 5u,
+                           (uint32_t *)witnesses_dev, witness_stride_bytes / 4);
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;
+}
+
+int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                   uint32_t nframes, uint32_t width, uint32_t height,
+                   uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                   uint32_t sample_bytes, int32_t thr_floor, const rbf_seeds *seeds,
+                   void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                   void *filters_dev, uint64_t filter_stride_bytes,
+                   void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
+                   rbf_filter_params *params_out, double *k_out)
+{
+    if (int r = rbf_residual_mask_batch(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
+                                        pixel_stride_bytes, sample_bytes, thr_floor, masks_dev, mask_stride_bytes, ones_dev))
+        return r;
+    const uint32_t pairs = nframes - 1;
+    const uint64_t n = (uint64_t)width * height;
+    if (pairs > ctx->host_cap) {
+        if (ctx->ones_pinned) HIP_TRY(hipHostFree(ctx->ones_pinned));
+        ctx->ones_pinned = nullptr; ctx->host_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&ctx->ones_pinned, (size_t)(pairs + 16) * sizeof(uint64_t), hipHostMallocDefault));
+        ctx->plan.resize(pairs + 16);
+        ctx->plan_k.resize(pairs + 16);
+        ctx->host_cap = pairs + 16;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->ones_pinned, ones_dev, (size_t)pairs * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int r = rbf_plan_batch(n, ctx->ones_pinned, pairs, 1, ctx->plan.data(), ctx->plan_k.data())) return r;
+    if (params_out) memcpy(params_out, ctx->plan.data(), (size_t)pairs * sizeof(rbf_filter_params));
+    if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)pairs * sizeof(double));
+    return rbf_bloom_encode_batch(ctx, masks_dev, mask_stride_bytes, n, pairs, ctx->plan.data(), seeds,
+                                  filters_dev, filter_stride_bytes, witnesses_dev, witness_stride_bytes, stats_dev);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -470,28 +624,40 @@ int rbf_bloom_decode_batch(rbf_ctx *ctx, const void *filters_dev, uint64_t filte
     if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
     if (witness_stride_bytes % 8) return fail(RBF_EINVAL, "witness stride must be a multiple of 8");
     if (nframes > 65535) return fail(RBF_ERANGE, "at most 65535 frames per batch");
-    const uint64_t nseg = nseg_of(n);
+    const Plan pl = make_plan(ctx, params, nframes, n);
+    const uint32_t wps = pl.fast_query ? (uint32_t)QL_P : (uint32_t)SEG_ITERS;      // pass words per segment
     if (int r = upload_params(ctx, params, nframes)) return r;
-    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * nseg * 4)) return r;
-    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * nseg * 8)) return r;
-    if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * nseg * SEG_ITERS * 8)) return r;
+    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
+    if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * wps * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
-    const uint64_t bx = (nseg + WG_WAVES - 1) / WG_WAVES;
-    {
+    if (pl.fast_query) {
+        auto kern = pl.double_buffer ? k_query_lds<false, true> : k_query_lds<false, false>;
+        if (int r = allow_big_lds((const void *)kern)) return r;
+        const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
+                           (const uint64_t *)nullptr, (uint64_t)0, n, nframes, ctx->fp_dev, sd,
+                           (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+                           (uint32_t *)nullptr, ctx->seg_cnt, pl.nseg, ctx->pass_words);
+    } else {
+        const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
         hipLaunchKernelGGL(k_query<false>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                            (const uint32_t *)nullptr, (uint64_t)0, n, ctx->fp_dev, sd,
                            (const uint32_t *)filters_dev, filter_stride_bytes / 4,
-                           (uint32_t *)nullptr, ctx->seg_cnt, nseg, ctx->pass_words);
+                           (uint32_t *)nullptr, ctx->seg_cnt, pl.nseg, ctx->pass_words);
     }
     {
-        LaunchTimer t(ctx, RBF_K_STITCH);
-        hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, nseg, (uint64_t *)nullptr);
+        LaunchTimer t(ctx, RBF_K_SCAN);
+        hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, pl.nseg,
+                           (uint64_t *)nullptr, 0u);
     }
     {
+        const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
         LaunchTimer t(ctx, RBF_K_EXPAND);
-        hipLaunchKernelGGL(k_expand_mask, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           ctx->pass_words, ctx->seg_off, nseg, (const uint32_t *)witnesses_dev, witness_stride_bytes / 4,
+        hipLaunchKernelGGL(k_expand_mask_p, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           ctx->pass_words, ctx->seg_off, pl.nseg, wps, (const uint32_t *)witnesses_dev, witness_stride_bytes / 4,
                            (uint64_t *)masks_dev, mask_stride_bytes / 8, n);
     }
     HIP_TRY(hipGetLastError());
@@ -578,7 +744,7 @@ static int values_common(rbf_ctx *ctx, void *frame_dev, uint32_t width, uint32_t
     const uint64_t bx = (nseg + WG_WAVES - 1) / WG_WAVES;
     LaunchTimer t(ctx, scatter ? RBF_K_SCATTER : RBF_K_GATHER);
     hipLaunchKernelGGL(k_mask_segment_counts, dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (const uint64_t *)mask_dev, n, ctx->seg_cnt, nseg);
-    hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, nseg, count_dev);
+    hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, nseg, count_dev, 1u);
     if (sample_bytes == 1) {
         if (scatter) hipLaunchKernelGGL((k_values<uint8_t, true>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint8_t *)values_dev);
         else hipLaunchKernelGGL((k_values<uint8_t, false>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint8_t *)values_dev);

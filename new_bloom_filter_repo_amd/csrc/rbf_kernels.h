@@ -81,6 +81,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_insert(
     const uint32_t f = blockIdx.y;
     const FrameDev fd = fp[f];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (fd.m == 0) return;                                  // frame not Bloom-coded (passthrough)
     const uint32_t *mask = masks + (uint64_t)f * mask_stride_words32;
     uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
     const uint64_t nwords = (n + 31) >> 5;
@@ -149,6 +150,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_query(
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
     const bool live = seg < nseg;
+    if (fd.m == 0) {                                        // passthrough frame: nothing passes
+        if (live && lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = 0;
+        if (!ENCODE && live && lane < SEG_ITERS) pass_words[(uint64_t)f * (nseg * SEG_ITERS) + seg * SEG_ITERS + lane] = 0;
+        return;
+    }
     const uint32_t *mask = ENCODE ? masks + (uint64_t)f * mask_stride_words32 : nullptr;
     const uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
     if (ENCODE && lane < SEG_WORDS) wbuf[wave][lane] = 0;
@@ -217,74 +223,12 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s
     return wave_off + incl - v;
 }
 
-// ------------------------------------------------------------------------------------------
-// witness stitch: exclusive scan of the segment pass counts, then every staging dword is
-// shifted to its final bit offset and OR-ed into the (pre-zeroed) packed witness.
-// One workgroup of 1024 threads per frame.  Also counts the filter's set bits.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_stitch_witness(
-    const uint32_t *__restrict__ seg_bits, const uint32_t *__restrict__ seg_cnt,
-    uint64_t *__restrict__ seg_off, uint64_t nseg,
-    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32,
-    const uint32_t *__restrict__ filters, uint64_t filter_stride_words32,
-    const FrameDev *__restrict__ fp, uint64_t *__restrict__ stats)
-{
-    __shared__ uint32_t smem[16];
-    __shared__ unsigned long long red[16];
-    const uint32_t f = blockIdx.x;
-    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
-    const uint32_t *bits = seg_bits + (uint64_t)f * nseg * SEG_WORDS;
-    uint64_t *off = seg_off + (uint64_t)f * nseg;
-    uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
-
-    uint64_t carry = 0;
-    for (uint64_t s0 = 0; s0 < nseg; s0 += 1024) {
-        const uint64_t s = s0 + threadIdx.x;
-        const uint32_t v = s < nseg ? cnt[s] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan_1024(v, smem, &tot);
-        if (s < nseg) off[s] = carry + ex;
-        carry += tot;
-    }
-    __syncthreads();   // off[] written by this block, read below by other threads of the block
-    const uint64_t pieces = nseg * SEG_WORDS;
-    for (uint64_t idx = threadIdx.x; idx < pieces; idx += 1024) {
-        const uint64_t s = idx / SEG_WORDS;
-        const uint32_t d = (uint32_t)(idx % SEG_WORDS);
-        if (32u * d >= cnt[s]) continue;
-        const uint32_t v = bits[idx];
-        if (!v) continue;
-        const uint64_t o = off[s] + 32u * d;
-        const uint32_t sh = (uint32_t)(o & 31u);
-        atomicOr(&wit[o >> 5], flip_bytes32(v << sh));
-        if (sh) {
-            const uint32_t hi = v >> (32u - sh);
-            if (hi) atomicOr(&wit[(o >> 5) + 1], flip_bytes32(hi));
-        }
-    }
-    // popcount of the filter
-    const uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
-    const uint64_t mwords = ((uint64_t)fp[f].m + 31) >> 5;
-    unsigned long long pc = 0;
-    for (uint64_t w = threadIdx.x; w < mwords; w += 1024) pc += __popc(filt[w]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) pc += __shfl_down(pc, d);
-    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = pc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int k = 0; k < 16; ++k) t += red[k];
-        stats[(uint64_t)f * 4 + 0] = carry;
-        stats[(uint64_t)f * 4 + 1] = t;
-        stats[(uint64_t)f * 4 + 2] = 0;
-        stats[(uint64_t)f * 4 + 3] = 0;
-    }
-}
-
-// Scan only (decode): segment offsets into the witness stream.
+// Exclusive scan of the per-segment pass counts of every frame (one 1024-thread workgroup per
+// frame): seg_off = bit offset of each segment in the frame's witness stream; totals (nullable)
+// gets the stream length at totals[f * totals_stride].
 __global__ __launch_bounds__(1024) void k_scan_segments(
     const uint32_t *__restrict__ seg_cnt, uint64_t *__restrict__ seg_off, uint64_t nseg,
-    uint64_t *__restrict__ totals /* nullable: one per frame */)
+    uint64_t *__restrict__ totals, uint32_t totals_stride)
 {
     __shared__ uint32_t smem[16];
     const uint32_t f = blockIdx.x;
@@ -299,7 +243,7 @@ __global__ __launch_bounds__(1024) void k_scan_segments(
         if (s < nseg) off[s] = carry + ex;
         carry += tot;
     }
-    if (totals && threadIdx.x == 0) totals[f] = carry;
+    if (totals && threadIdx.x == 0) totals[(uint64_t)f * totals_stride] = carry;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,374 @@
+// rbf_kernels_lds.h -- the LDS-resident fast path (filters up to ~1.3 Mbit, i.e. 1080p-class frames).
+//
+// Measured on MI355X (tools/microbench.hip): random dword probes run at ~430 G/s from a 76 KB
+// global region and ~260 G/s from an L2-resident 2 MB one, random global atomicOr at ~25 G/s --
+// while LDS probes / LDS atomics run at >1600 G/s.  So both the filter build (insert) and the
+// filter test (query) keep the whole filter of one frame in LDS:
+//
+//   k_insert_lds   grid (S, F): workgroup (s, f) builds a PARTIAL filter of frame f in LDS from slice
+//                  s of the mask (set positions are compacted through a per-wave LDS queue so the
+//                  hashing always runs with full waves) and stores it; k_filter_reduce ORs the S
+//                  partials -- no global atomics anywhere.
+//   k_query_lds    "frames-inner": a wave owns a segment of P*64 consecutive pixels for the whole
+//                  batch.  The three XXH64 of each pixel index depend only on the index, so they are
+//                  computed ONCE and kept in registers; then for every frame of the batch the
+//                  workgroup stages that frame's filter into LDS and each lane does the per-frame
+//                  part only: two Barrett reductions mod m_f, the LDS probes, ballot + compaction.
+#pragma once
+#include "rbf_kernels.h"
+
+namespace rbf {
+
+constexpr int QL_THREADS = 1024;                   // 16 waves, one workgroup per CU, filter double-buffered in LDS
+constexpr int QL_WAVES = QL_THREADS / WAVE;
+constexpr int QL_P = 8;                            // pixels per lane
+constexpr int QL_SEG_PIXELS = QL_P * WAVE;         // 512
+constexpr int QL_SEG_WORDS = QL_SEG_PIXELS / 32;   // 16 staging dwords per (segment, frame)
+
+constexpr int IL_THREADS = 1024;                   // insert: one workgroup per CU
+constexpr int IL_WAVES = IL_THREADS / WAVE;
+constexpr int IL_QUEUE = 64 + 512;                 // carry (<64) + one wave-step of 64 mask bytes
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------
+// insert
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
+    const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
+    const FrameDev *__restrict__ fp, Seeds seeds,
+    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t fwords_max)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *filt = lds;                                         // [fwords_max (even)]
+    uint32_t *queues = lds + ((fwords_max + 1u) & ~1u);           // [IL_WAVES][IL_QUEUE]
+    const uint32_t f = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+    const FrameDev fd = fp[f];
+    if (fd.m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t fwords = (fd.m + 31u) >> 5;
+    for (uint32_t i = threadIdx.x; i < fwords_max; i += IL_THREADS) filt[i] = 0;
+    __syncthreads();
+
+    const uint8_t *mask = masks + (uint64_t)f * mask_stride_bytes;
+    const uint64_t nbytes = (n + 7) >> 3;
+    const uint64_t groups = (nbytes + 63) >> 6;                    // 64-byte wave steps
+    const uint64_t gper = (groups + S - 1) / S;
+    const uint64_t g0 = (uint64_t)s * gper;
+    const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
+    uint32_t *q = queues + wave * IL_QUEUE;
+    uint32_t qn = 0;                                               // wave-uniform queue length
+
+    auto drain_at = [&](uint32_t first, uint32_t count) {          // hash `count` (<= 64) queued positions
+        if (lane < count) {
+            Probe p = make_probe(q[first + lane], fd, seeds);
+            for (uint32_t j = 0; j < fd.floor_k; ++j) {
+                atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+                advance(p, fd.m);
+            }
+            if (p.extra) atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+        }
+    };
+
+    for (uint64_t g = g0 + wave; g < g1; g += IL_WAVES) {
+        const uint64_t byte = g * 64 + lane;
+        uint32_t bits = 0;
+        if (byte < nbytes) {
+            bits = __builtin_bitreverse32((uint32_t)mask[byte]) >> 24;       // natural order
+            const uint64_t rem = n - byte * 8;
+            if (rem < 8) bits &= (1u << rem) - 1u;
+        }
+        const uint32_t c = __popc(bits);
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += t;
+        }
+        const uint32_t total = __shfl(incl, WAVE - 1);
+        uint32_t off = qn + incl - c;
+        const uint32_t base = (uint32_t)(byte << 3);
+        while (bits) {
+            q[off++] = base + __builtin_ctz(bits);
+            bits &= bits - 1u;
+        }
+        qn += total;
+        wave_lds_fence();
+        while (qn >= WAVE) {                                       // full waves only; order is irrelevant (OR)
+            qn -= WAVE;
+            drain_at(qn, WAVE);
+        }
+        wave_lds_fence();                                          // queue reads done before it is refilled
+    }
+    drain_at(0, qn);
+    __syncthreads();
+    uint32_t *part = partials + ((uint64_t)f * S + s) * part_stride_words32;
+    const uint32_t pairs = (fwords + 1) >> 1;
+    for (uint32_t i = threadIdx.x; i < pairs; i += IL_THREADS)
+        reinterpret_cast<uint2 *>(part)[i] = reinterpret_cast<const uint2 *>(filt)[i];
+}
+
+// OR the S partial filters of every frame into the final packed filter; count its set bits.
+__global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
+    const uint32_t *partials, uint64_t part_stride_words32, uint32_t S,
+    const FrameDev *__restrict__ fp,
+    uint32_t *filters /* may alias partials when S == 1 */, uint64_t filter_stride_words32,
+    uint64_t *__restrict__ stats)
+{
+    __shared__ uint32_t red[WG_WAVES];
+    const uint32_t f = blockIdx.y;
+    const uint32_t m = fp[f].m;
+    const uint32_t fwords = m ? ((m + 31u) >> 5) : 0u;
+    uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
+    uint32_t pc = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x; w < filter_stride_words32; w += (uint64_t)gridDim.x * WG_THREADS) {
+        uint32_t v = 0;
+        if (w < fwords)
+            for (uint32_t s = 0; s < S; ++s) v |= partials[((uint64_t)f * S + s) * part_stride_words32 + w];
+        if (m) filt[w] = v;                                       // passthrough frames: filter untouched
+        pc += __popc(v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pc += __shfl_down(pc, d);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = pc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < WG_WAVES; ++k) t += red[k];
+        if (t) atomicAdd((unsigned long long *)&stats[(uint64_t)f * 4 + 1], (unsigned long long)t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// query, frames-inner
+// ------------------------------------------------------------------------------------------
+// Filter staging by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, no
+// ds_write pass).  LDS destination = wave-uniform base + lane*16; the global source is per lane.
+__device__ __forceinline__ void dma_filter(uint32_t *lds_dst, const uint32_t *src, uint32_t words, uint32_t wave,
+                                           uint32_t lane, uint32_t nwaves)
+{
+    const uint32_t npieces = words >> 2;                      // whole 16-byte pieces
+    const uint32_t nchunks = (npieces + 63u) >> 6;
+    for (uint32_t c = wave; c < nchunks; c += nwaves) {
+        const uint32_t piece = (c << 6) + lane;
+        if (piece < npieces)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (piece << 2)),
+                                             (__attribute__((address_space(3))) void *)(lds_dst + (c << 8)), 16, 0, 0);
+    }
+    const uint32_t tail = words & 3u;                         // 0..3 dwords left: 4-byte DMA
+    if (wave == 0 && lane < tail)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (npieces << 2) + lane),
+                                         (__attribute__((address_space(3))) void *)(lds_dst + (npieces << 2)), 4, 0, 0);
+}
+
+// h mod m for 2 <= m <= 2^30 with three 32x32 multiplies for the quotient estimate:
+// q' = hh*Mh + hi32(hh*Ml) + hi32(hl*Mh) >= floor(h*M/2^64) - 2 >= floor(h/m) - 3, so
+// r' = h - q'*m < 4m <= 2^32 and everything can be carried modulo 2^32.
+__device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t Mh, uint32_t Ml)
+{
+    const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
+    const uint32_t q = hh * Mh + __umulhi(hh, Ml) + __umulhi(hl, Mh);
+    uint32_t r = hl - q * m;
+    r = min(r, r - m);
+    r = min(r, r - m);
+    r = min(r, r - m);
+    return r;
+}
+
+template <bool ENCODE, bool DOUBLE_BUFFER>
+__global__ __launch_bounds__(QL_THREADS) void k_query_lds(
+    const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n, uint32_t nframes,
+    const FrameDev *__restrict__ fp, Seeds seeds,
+    const uint32_t *__restrict__ filters, uint64_t filter_stride_words32, uint32_t fwords_max,
+    uint32_t *__restrict__ seg_bits, uint32_t *__restrict__ seg_cnt, uint64_t nseg,
+    uint64_t *__restrict__ pass_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t bufwords = (fwords_max + 3u) & ~3u;            // 16-byte multiple
+    uint32_t *stage = lds + (DOUBLE_BUFFER ? 2u : 1u) * bufwords; // [QL_WAVES][QL_SEG_WORDS]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * QL_WAVES + wave;
+    const bool live = seg < nseg;
+    const uint64_t base = seg * QL_SEG_PIXELS;
+    const uint64_t nwords64 = (n + 63) >> 6;
+    uint32_t *stg = stage + wave * QL_SEG_WORDS;
+    if (ENCODE && lane < QL_SEG_WORDS) stg[lane] = 0;
+
+    // ---- frame-independent part: the three hashes of my P pixel indices ------------------
+    uint64_t h1[QL_P], h2[QL_P], ha[QL_P];
+    uint32_t validmask = 0;
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) {
+        const uint64_t i = base + (uint64_t)it * WAVE + lane;
+        h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
+        if (live && i < n) {
+            const DecKey key = make_key((uint32_t)i);
+            h1[it] = xxh64_key(key, seeds.h1);
+            h2[it] = xxh64_key(key, seeds.h2);
+            ha[it] = xxh64_key(key, seeds.act);
+            validmask |= 1u << it;
+        }
+    }
+
+    // passthrough frames (m == 0): nothing passes
+    uint32_t f = nframes;
+    for (uint32_t g = nframes; g-- > 0;) {
+        if (fp[g].m == 0) {
+            if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
+            if (!ENCODE && live && lane < QL_P) pass_words[((uint64_t)g * nseg + seg) * QL_P + lane] = 0;
+        } else {
+            f = g;                                                // ends as the FIRST active frame
+        }
+    }
+    auto load_mw = [&](uint32_t g) -> uint64_t {
+        uint64_t v = 0;
+        if (ENCODE && live && lane < QL_P) {
+            const uint64_t w = seg * QL_P + lane;
+            if (w < nwords64) v = masks[(uint64_t)g * mask_stride_words64 + w];
+        }
+        return v;
+    };
+    uint32_t cur = 0;
+    uint64_t mw_next = 0;
+    if (DOUBLE_BUFFER && f < nframes) {
+        mw_next = load_mw(f);
+        dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (fp[f].m + 31u) >> 5, wave, lane, QL_WAVES);
+    }
+    while (f < nframes) {
+        uint32_t fn = f + 1;
+        while (fn < nframes && fp[fn].m == 0) ++fn;               // next active frame
+        const FrameDev fd = fp[f];
+        uint64_t mw;
+        const uint32_t *filt;
+        if (DOUBLE_BUFFER) {
+            __syncthreads();          // DMA(f) has landed for every wave; buffer cur^1 is free again
+            mw = mw_next;
+            filt = lds + cur * bufwords;
+            if (fn < nframes) {
+                mw_next = load_mw(fn);
+                dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
+                           (fp[fn].m + 31u) >> 5, wave, lane, QL_WAVES);
+            }
+            cur ^= 1u;
+        } else {
+            __syncthreads();          // previous frame's probes are done
+            mw = load_mw(f);
+            dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (fd.m + 31u) >> 5, wave, lane, QL_WAVES);
+            __syncthreads();
+            filt = lds;
+        }
+        mw = flip_bytes64(mw);                                     // natural order
+        const bool small = fd.m >= 2u && fd.m <= (1u << 30);
+        const uint32_t Mh = (uint32_t)(fd.M >> 32), Ml = (uint32_t)fd.M;
+
+        uint32_t woff = 0;
+        uint64_t mypw = 0;
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            uint32_t pos, step;
+            if (small) { pos = mod_m_small(h1[it], fd.m, Mh, Ml); step = mod_m_small(h2[it], fd.m, Mh, Ml); }
+            else       { pos = mod_m(h1[it], fd.m, fd.M);         step = mod_m(h2[it], fd.m, fd.M); }
+            const bool extra = ha[it] < fd.T;
+            uint32_t ok = (validmask >> it) & 1u;
+            for (uint32_t j = 0; j < fd.floor_k; ++j) {
+                ok &= filt[pos >> 5] >> msb_pos(pos);
+                if (small) { const uint32_t s2 = pos + step; pos = min(s2, s2 - fd.m); }
+                else { const uint64_t s2 = (uint64_t)pos + step; pos = (uint32_t)(s2 >= fd.m ? s2 - fd.m : s2); }
+            }
+            const uint32_t x = filt[pos >> 5] >> msb_pos(pos);
+            if (extra) ok &= x;
+            const bool pass = ok & 1u;
+            const uint64_t pw = __ballot(pass);
+            if (ENCODE) {
+                const uint64_t w = __shfl(mw, it);
+                if (pass && ((w >> lane) & 1ull)) {
+                    const uint32_t dst = woff + rank_below(pw);
+                    atomicOr(&stg[dst >> 5], 1u << (dst & 31u));
+                }
+            } else {
+                if (lane == (uint32_t)it) mypw = pw;
+            }
+            woff += __popcll(pw);
+        }
+        if (ENCODE) {
+            wave_lds_fence();
+            if (lane < QL_SEG_WORDS) {
+                if (live) seg_bits[((uint64_t)f * nseg + seg) * QL_SEG_WORDS + lane] = stg[lane];
+                stg[lane] = 0;
+            }
+            wave_lds_fence();
+        } else if (live && lane < QL_P) {
+            pass_words[((uint64_t)f * nseg + seg) * QL_P + lane] = mypw;
+        }
+        if (live && lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = woff;
+        f = fn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stitch, wide version: seg_off comes from k_scan_segments; every staging dword of every
+// segment is shifted to its final bit offset and OR-ed into the pre-zeroed packed witness.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS) void k_stitch_pieces(
+    const uint32_t *__restrict__ seg_bits, const uint32_t *__restrict__ seg_cnt,
+    const uint64_t *__restrict__ seg_off, uint64_t nseg, uint32_t seg_words_log2,
+    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32)
+{
+    const uint32_t f = blockIdx.y;
+    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
+    const uint64_t *off = seg_off + (uint64_t)f * nseg;
+    const uint32_t *bits = seg_bits + (((uint64_t)f * nseg) << seg_words_log2);
+    uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
+    const uint64_t pieces = nseg << seg_words_log2;
+    for (uint64_t idx = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x; idx < pieces; idx += (uint64_t)gridDim.x * WG_THREADS) {
+        const uint64_t s = idx >> seg_words_log2;
+        const uint32_t d = (uint32_t)(idx & ((1u << seg_words_log2) - 1u));
+        if (32u * d >= cnt[s]) continue;
+        const uint32_t v = bits[idx];
+        if (!v) continue;
+        const uint64_t o = off[s] + 32u * d;
+        const uint32_t sh = (uint32_t)(o & 31u);
+        atomicOr(&wit[o >> 5], flip_bytes32(v << sh));
+        if (sh) {
+            const uint32_t hi = v >> (32u - sh);
+            if (hi) atomicOr(&wit[(o >> 5) + 1], flip_bytes32(hi));
+        }
+    }
+}
+
+// expand for QL_P-word segments (decode fast path)
+__global__ __launch_bounds__(WG_THREADS) void k_expand_mask_p(
+    const uint64_t *__restrict__ pass_words, const uint64_t *__restrict__ seg_off, uint64_t nseg, uint32_t words_per_seg,
+    const uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32,
+    uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n)
+{
+    const uint32_t f = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
+    if (seg >= nseg) return;
+    const uint64_t *pw = pass_words + ((uint64_t)f * nseg + seg) * words_per_seg;
+    const uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
+    uint64_t *mask = masks + (uint64_t)f * mask_stride_words64;
+    uint64_t o = seg_off[(uint64_t)f * nseg + seg];
+    const uint64_t nwords = (n + 63) >> 6;
+    for (uint32_t it = 0; it < words_per_seg; ++it) {
+        const uint64_t w = seg * words_per_seg + it;
+        if (w >= nwords) break;
+        const uint64_t p = pw[it];
+        bool bit = false;
+        if ((p >> lane) & 1ull) {
+            const uint64_t src = o + rank_below(p);
+            bit = (wit[src >> 5] >> msb_pos((uint32_t)src)) & 1u;
+        }
+        const uint64_t word = __ballot(bit);
+        if (lane == 0) mask[w] = flip_bytes64(word);
+        o += __popcll(p);
+    }
+}
+
+}  // namespace rbf

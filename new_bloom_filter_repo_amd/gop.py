@@ -1,0 +1,96 @@
+"""GOP-level driver: frames resident in HBM -> residual masks -> (host: filter geometry) ->
+Bloom insert + query/witness, one C-ABI call per GOP (rbf_encode_gop).
+
+Device memory comes from an allocator callback so the same code runs on library-owned buffers
+(default) or on torch tensors (bench.py / dist.py pass `torch_allocator`, which lets RCCL move the
+results without a copy)."""
+import ctypes
+
+import numpy as np
+
+from . import _native as nat
+from . import params as P
+
+
+class _OwnedBlock:
+    def __init__(self, buf):
+        self.buf, self.ptr, self.nbytes = buf, buf.ptr, buf.nbytes
+
+    def numpy(self, ctx, nbytes=None):
+        return self.buf.download(nbytes)
+
+
+class _TorchBlock:
+    def __init__(self, t):
+        self.tensor, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
+
+    def numpy(self, ctx, nbytes=None):
+        a = self.tensor.cpu().numpy().view(np.uint8).reshape(-1)
+        return a if nbytes is None else a[:nbytes]
+
+
+def owned_allocator(ctx):
+    return lambda nbytes: _OwnedBlock(ctx.alloc(nbytes))
+
+
+def torch_allocator(device):
+    import torch
+    return lambda nbytes: _TorchBlock(torch.zeros((int(nbytes) + 7) // 8, dtype=torch.int64, device=device))
+
+
+class GopCoder:
+    """Encodes the nframes-1 inter-frame residual masks of one GOP of (H, W, C) frames."""
+
+    def __init__(self, ctx, width, height, nframes, channels=3, sample_bytes=1, seeds=P.SEEDS_VIDEO,
+                 allocator=None, threshold=0.0):
+        from .engine import threshold_floor
+        self.ctx, self.W, self.H, self.F, self.C, self.sb = ctx, width, height, nframes, channels, sample_bytes
+        self.n = width * height
+        self.pairs = nframes - 1
+        self.seeds = nat.Seeds(*[int(s) for s in seeds])
+        self.thr = threshold_floor(threshold)
+        alloc = allocator or owned_allocator(ctx)
+        self.frame_bytes = self.n * channels * sample_bytes
+        self.mask_stride = nat.packed_stride(self.n)
+        self.filter_stride = nat.packed_stride(int(self.n * 0.32) + 64)   # l <= 0.317 n for every density
+        self.witness_stride = nat.packed_stride(self.n)
+        self.frames = alloc(self.frame_bytes * nframes)
+        self.masks = alloc(self.mask_stride * self.pairs)
+        self.ones = alloc(8 * self.pairs)
+        self.filters = alloc(self.filter_stride * self.pairs)
+        self.witness = alloc(self.witness_stride * self.pairs)
+        self.stats = alloc(8 * nat.STATS_PER_FRAME * self.pairs)
+        self.params = (nat.FilterParams * self.pairs)()
+        self.k = (ctypes.c_double * self.pairs)()
+
+    def load_frames(self, frames):
+        frames = np.ascontiguousarray(frames)
+        assert frames.nbytes == self.frame_bytes * self.F, (frames.shape, frames.dtype)
+        nat.check(nat.lib().rbf_memcpy_h2d(self.ctx.handle, self.frames.ptr, frames.ctypes.data, frames.nbytes))
+
+    def encode(self):
+        """Enqueue one full pass; returns after the Bloom kernels are enqueued."""
+        nat.check(nat.lib().rbf_encode_gop(
+            self.ctx.handle, self.frames.ptr, self.frame_bytes, self.F, self.W, self.H,
+            self.W * self.C * self.sb, self.C * self.sb, self.sb, self.thr, ctypes.byref(self.seeds),
+            self.masks.ptr, self.mask_stride, self.ones.ptr,
+            self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr,
+            self.params, self.k))
+
+    def results(self):
+        """Download: list of per-frame dicts (mask/filter/witness packed uint8, counts, k, l)."""
+        self.ctx.sync()
+        masks = self.masks.numpy(self.ctx).reshape(self.pairs, self.mask_stride)
+        filt = self.filters.numpy(self.ctx).reshape(self.pairs, self.filter_stride)
+        wit = self.witness.numpy(self.ctx).reshape(self.pairs, self.witness_stride)
+        stats = self.stats.numpy(self.ctx).view(np.uint64).reshape(self.pairs, nat.STATS_PER_FRAME)
+        ones = self.ones.numpy(self.ctx).view(np.uint64)
+        out = []
+        for f in range(self.pairs):
+            m = int(self.params[f].m)
+            wb = int(stats[f, 0])
+            out.append({"mask": masks[f, :(self.n + 7) // 8].copy(), "ones": int(ones[f]), "k": float(self.k[f]), "l": m,
+                        "floor_k": int(self.params[f].floor_k), "threshold": int(self.params[f].threshold),
+                        "filter": filt[f, :(m + 7) // 8].copy(), "witness": wit[f, :(wb + 7) // 8].copy(),
+                        "witness_bits": wb, "filter_ones": int(stats[f, 1])})
+        return out

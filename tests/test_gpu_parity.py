@@ -14,11 +14,17 @@ from new_bloom_filter_repo_amd.synthetic import make_gop, make_mask, P_KSTAR_2_3
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
-    e = BloomEngine(nat.Context(0))
+@pytest.fixture(scope="module", params=["lds_double_buffer", "lds_single_buffer", "generic"])
+def eng(request):
+    """Every kernel family must be bit-exact: the LDS-resident fast path (default whenever the filter
+    fits in LDS; with and without filter double-buffering) and the generic global-memory path (forced
+    here; what 4K-class filters use)."""
+    ctx = nat.Context(0)
+    ctx.force_generic({"lds_double_buffer": 0, "lds_single_buffer": 2, "generic": 1}[request.param])
+    e = BloomEngine(ctx)
     yield e
     e.close()
+    ctx.close()
 
 
 def unpack(a, nbits):
