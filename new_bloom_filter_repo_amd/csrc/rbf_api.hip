@@ -393,7 +393,7 @@ static inline uint64_t nseg_of(uint64_t n) { return (n + SEG_PIXELS - 1) / SEG_P
 // probe / set the filter in global memory.
 constexpr size_t LDS_LIMIT = 160 * 1024;
 struct Plan {
-    bool fast_insert, fast_query, double_buffer;
+    bool fast_insert, fast_query, double_buffer, small_m;
     uint32_t fwords_max, fwords_even, S;
     size_t insert_lds_bytes, query_lds_bytes;
     uint64_t nseg; uint32_t seg_words;
@@ -403,7 +403,12 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
 {
     Plan p{};
     uint32_t mmax = 0, active = 0;
-    for (uint32_t f = 0; f < nframes; ++f) { if (params[f].m > mmax) mmax = params[f].m; if (params[f].m) ++active; }
+    p.small_m = true;
+    for (uint32_t f = 0; f < nframes; ++f) {
+        if (params[f].m > mmax) mmax = params[f].m;
+        if (params[f].m) ++active;
+        if (params[f].m == 1 || params[f].m > (1u << 30)) p.small_m = false;
+    }
     p.fwords_max = (uint32_t)(((uint64_t)mmax + 31) / 32);
     p.fwords_even = (p.fwords_max + 1u) & ~1u;
     p.insert_lds_bytes = (size_t)p.fwords_even * 4 + (size_t)IL_WAVES * IL_QUEUE * 4;
@@ -450,18 +455,41 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
     const uint32_t pairs = nframes - 1;
     HIP_TRY(hipMemsetAsync(ones_dev, 0, (size_t)pairs * sizeof(uint64_t), ctx->stream));
     const uint64_t nwords = (n + 63) / 64;
-    uint64_t bx = (nwords + WG_WAVES * 16 - 1) / (WG_WAVES * 16);      // ~16 words per wave
-    if (bx < 1) bx = 1;
-    if (bx > 65535) bx = 65535;
-    dim3 grid((uint32_t)bx, pairs), block(WG_THREADS);
-    {
+    // Fast path: flat frames, 16-byte aligned, whole 1024-pixel segments; the generic kernel does the rest.
+    uint64_t fast_segs = 0;
+    const bool flat = row_pitch_bytes == (uint64_t)width * pixel_stride_bytes;
+    const bool known = (sample_bytes == 1 && (pixel_stride_bytes == 1 || pixel_stride_bytes == 3)) ||
+                       (sample_bytes == 2 && (pixel_stride_bytes == 2 || pixel_stride_bytes == 6));
+    if (!ctx->force_generic && flat && known && frame_stride_bytes % 16 == 0 && ((uintptr_t)frames_dev % 16) == 0 &&
+        (size_t)pairs * 4 <= 48 * 1024)
+        fast_segs = n / 1024;
+    if (fast_segs) {
+        const uint32_t bx = (uint32_t)((fast_segs + WG_WAVES - 1) / WG_WAVES);
+        const size_t lds = (size_t)pairs * 4;
+        LaunchTimer t(ctx, RBF_K_MASK);
+#define RBF_MASK_GOP(S, PB) hipLaunchKernelGGL((k_residual_mask_gop<S, PB>), dim3(bx), dim3(WG_THREADS), lds, ctx->stream,          \
+                               (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, (uint16_t *)masks_dev, \
+                               mask_stride_bytes / 2, ones_dev)
+        if (sample_bytes == 1 && pixel_stride_bytes == 1) RBF_MASK_GOP(uint8_t, 1);
+        else if (sample_bytes == 1) RBF_MASK_GOP(uint8_t, 3);
+        else if (pixel_stride_bytes == 2) RBF_MASK_GOP(uint16_t, 2);
+        else RBF_MASK_GOP(uint16_t, 6);
+#undef RBF_MASK_GOP
+    }
+    const uint64_t first_word = fast_segs * 16;
+    if (first_word < nwords) {
+        const uint64_t rest = nwords - first_word;
+        uint64_t bx = (rest + WG_WAVES * 16 - 1) / (WG_WAVES * 16);      // ~16 words per wave
+        if (bx < 1) bx = 1;
+        if (bx > 65535) bx = 65535;
+        dim3 grid((uint32_t)bx, pairs), block(WG_THREADS);
         LaunchTimer t(ctx, RBF_K_MASK);
         if (sample_bytes == 1)
             hipLaunchKernelGGL(k_residual_mask<uint8_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
-                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev);
+                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev, first_word);
         else
             hipLaunchKernelGGL(k_residual_mask<uint16_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
-                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev);
+                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev, first_word);
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;
@@ -542,7 +570,8 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
     }
     // ---- query + witness staging
     if (pl.fast_query) {
-        auto kern = pl.double_buffer ? k_query_lds<true, true> : k_query_lds<true, false>;
+        auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<true, true, true> : k_query_lds<true, true, false>)
+                                     : (pl.small_m ? k_query_lds<true, false, true> : k_query_lds<true, false, false>);
         if (int r = allow_big_lds((const void *)kern)) return r;
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
@@ -632,7 +661,8 @@ int rbf_bloom_decode_batch(rbf_ctx *ctx, const void *filters_dev, uint64_t filte
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * wps * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
     if (pl.fast_query) {
-        auto kern = pl.double_buffer ? k_query_lds<false, true> : k_query_lds<false, false>;
+        auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<false, true, true> : k_query_lds<false, true, false>)
+                                     : (pl.small_m ? k_query_lds<false, false, true> : k_query_lds<false, false, false>);
         if (int r = allow_big_lds((const void *)kern)) return r;
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);

@@ -33,7 +33,7 @@ template <typename SAMPLE>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t width, uint64_t n,
     uint64_t row_pitch, uint32_t pixel_stride, int32_t thr,
-    uint64_t *__restrict__ masks, uint64_t mask_stride_words, uint64_t *__restrict__ ones)
+    uint64_t *__restrict__ masks, uint64_t mask_stride_words, uint64_t *__restrict__ ones, uint64_t first_word)
 {
     __shared__ uint32_t wave_ones[WG_WAVES];
     const uint32_t f = blockIdx.y;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask(
     const uint64_t nwords = (n + 63) >> 6;
     uint32_t cnt = 0;
     // one 64-pixel word per wave per step, block-contiguous
-    for (uint64_t w = (uint64_t)blockIdx.x * WG_WAVES + wave; w < nwords; w += (uint64_t)gridDim.x * WG_WAVES) {
+    for (uint64_t w = first_word + (uint64_t)blockIdx.x * WG_WAVES + wave; w < nwords; w += (uint64_t)gridDim.x * WG_WAVES) {
         const uint64_t i = w * 64 + lane;
         bool bit = false;
         if (i < n) {

@@ -180,7 +180,8 @@ __device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t
     return r;
 }
 
-template <bool ENCODE, bool DOUBLE_BUFFER>
+// SMALL_M: every filter of the batch has 2 <= m <= 2^30 (host-checked) -> cheap reductions.
+template <bool ENCODE, bool DOUBLE_BUFFER, bool SMALL_M>
 __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n, uint32_t nframes,
     const FrameDev *__restrict__ fp, Seeds seeds,
@@ -263,30 +264,41 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
             filt = lds;
         }
         mw = flip_bytes64(mw);                                     // natural order
-        const bool small = fd.m >= 2u && fd.m <= (1u << 30);
-        const uint32_t Mh = (uint32_t)(fd.M >> 32), Ml = (uint32_t)fd.M;
+        // frame geometry is wave-uniform: keep it in SGPRs so every branch below is scalar
+        const uint32_t m = __builtin_amdgcn_readfirstlane(fd.m);
+        const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
+        const uint32_t Mh = __builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32));
+        const uint32_t Ml = __builtin_amdgcn_readfirstlane((uint32_t)fd.M);
+        // (the builtin returns int: go through uint32_t or the low half sign-extends)
+        const uint32_t Thi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.T >> 32));
+        const uint32_t Tlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.T);
+        const uint64_t T = ((uint64_t)Thi << 32) | Tlo;
+        const uint64_t M = ((uint64_t)Mh << 32) | Ml;
+        const uint32_t mw_lo = (uint32_t)mw, mw_hi = (uint32_t)(mw >> 32);
 
         uint32_t woff = 0;
         uint64_t mypw = 0;
 #pragma unroll
         for (int it = 0; it < QL_P; ++it) {
             uint32_t pos, step;
-            if (small) { pos = mod_m_small(h1[it], fd.m, Mh, Ml); step = mod_m_small(h2[it], fd.m, Mh, Ml); }
-            else       { pos = mod_m(h1[it], fd.m, fd.M);         step = mod_m(h2[it], fd.m, fd.M); }
-            const bool extra = ha[it] < fd.T;
+            if (SMALL_M) { pos = mod_m_small(h1[it], m, Mh, Ml); step = mod_m_small(h2[it], m, Mh, Ml); }
+            else         { pos = mod_m(h1[it], m, M);            step = mod_m(h2[it], m, M); }
+            const bool extra = ha[it] < T;
             uint32_t ok = (validmask >> it) & 1u;
-            for (uint32_t j = 0; j < fd.floor_k; ++j) {
+            for (uint32_t j = 0; j < fk; ++j) {
                 ok &= filt[pos >> 5] >> msb_pos(pos);
-                if (small) { const uint32_t s2 = pos + step; pos = min(s2, s2 - fd.m); }
-                else { const uint64_t s2 = (uint64_t)pos + step; pos = (uint32_t)(s2 >= fd.m ? s2 - fd.m : s2); }
+                if (SMALL_M) { const uint32_t s2 = pos + step; pos = min(s2, s2 - m); }
+                else { const uint64_t s2 = (uint64_t)pos + step; pos = (uint32_t)(s2 >= m ? s2 - m : s2); }
             }
             const uint32_t x = filt[pos >> 5] >> msb_pos(pos);
-            if (extra) ok &= x;
+            ok &= extra ? x : 1u;
             const bool pass = ok & 1u;
             const uint64_t pw = __ballot(pass);
             if (ENCODE) {
-                const uint64_t w = __shfl(mw, it);
-                if (pass && ((w >> lane) & 1ull)) {
+                const uint32_t w_hi = __builtin_amdgcn_readlane(mw_hi, it), w_lo = __builtin_amdgcn_readlane(mw_lo, it);
+                const uint64_t w = ((uint64_t)w_hi << 32) | w_lo;
+                const uint64_t tp = pw & w;                        // passes whose mask bit is 1 (wave-uniform)
+                if ((tp >> lane) & 1ull) {
                     const uint32_t dst = woff + rank_below(pw);
                     atomicOr(&stg[dst >> 5], 1u << (dst & 31u));
                 }
@@ -369,6 +381,81 @@ __global__ __launch_bounds__(WG_THREADS) void k_expand_mask_p(
         if (lane == 0) mask[w] = flip_bytes64(word);
         o += __popcll(p);
     }
+}
+
+}  // namespace rbf
+
+namespace rbf {
+
+// ------------------------------------------------------------------------------------------
+// A1 fast path: residual masks of a whole GOP, every frame read from HBM exactly once.
+// ------------------------------------------------------------------------------------------
+// Frames must be flat (row pitch == width * pixel stride), so a frame is an array of n pixels of
+// PIXEL_BYTES each whose first sample is the luma.  A lane owns 16 consecutive pixels for the
+// whole GOP: it keeps the previous frame's 16*PIXEL_BYTES bytes in registers, streams the next
+// frame's with 16-byte loads (two frames of prefetch in flight), and emits its 16 mask bits as one
+// MSB-first uint16, so a wave writes 128 contiguous bytes per frame and needs no ballot.
+template <typename SAMPLE, int PIXEL_BYTES>
+struct LanePixels {
+    static constexpr int DW = 16 * PIXEL_BYTES / 4;            // dwords per lane per frame
+    uint32_t d[DW];
+    __device__ __forceinline__ void load(const uint8_t *p)
+    {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
+#pragma unroll
+        for (int i = 0; i < DW / 4; ++i) {
+            const u32x4 v = __builtin_nontemporal_load(q + i);   // streamed once: keep it out of the caches
+            d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+        }
+    }
+    __device__ __forceinline__ uint32_t luma(int k) const     // sample 0 of pixel k
+    {
+        const int byte = k * PIXEL_BYTES;
+        const uint32_t w = d[byte >> 2];
+        if (sizeof(SAMPLE) == 1) return (w >> (8 * (byte & 3))) & 0xFFu;
+        return (w >> (8 * (byte & 3))) & 0xFFFFu;              // 2-byte samples are 2-byte aligned
+    }
+};
+
+template <typename SAMPLE, int PIXEL_BYTES>
+__global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
+    const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t nframes, uint64_t nsegs /* of 1024 px */,
+    int32_t thr, uint16_t *__restrict__ masks, uint64_t mask_stride_u16, uint64_t *__restrict__ ones)
+{
+    extern __shared__ uint32_t cnt[];                          // [nframes-1] per-workgroup ones
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
+    for (uint32_t i = threadIdx.x; i + 1 < nframes; i += WG_THREADS) cnt[i] = 0;
+    __syncthreads();
+    if (seg < nsegs) {
+        using LP = LanePixels<SAMPLE, PIXEL_BYTES>;
+        const uint64_t lane_off = (seg * 1024 + (uint64_t)lane * 16) * PIXEL_BYTES;
+        const uint8_t *p = frames + lane_off;
+        uint16_t *out = masks + seg * 64 + lane;
+        LP prev, cur, nxt;
+        prev.load(p);
+        if (nframes > 1) cur.load(p + frame_stride);
+        for (uint32_t f = 1; f < nframes; ++f) {
+            if (f + 1 < nframes) nxt.load(p + (uint64_t)(f + 1) * frame_stride);
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool b = residual_bit<SAMPLE>((SAMPLE)prev.luma(k), (SAMPLE)cur.luma(k), thr);
+                bits |= (b ? 1u : 0u) << (k ^ 7);             // MSB-first within each byte
+            }
+            out[(uint64_t)(f - 1) * mask_stride_u16] = (uint16_t)bits;
+            uint32_t c = __popc(bits);
+#pragma unroll
+            for (int dlt = 32; dlt >= 1; dlt >>= 1) c += __shfl_down(c, dlt);
+            if (lane == 0 && c) atomicAdd(&cnt[f - 1], c);
+            prev = cur;
+            cur = nxt;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i + 1 < nframes; i += WG_THREADS)
+        if (cnt[i]) atomicAdd((unsigned long long *)&ones[i], (unsigned long long)cnt[i]);
 }
 
 }  // namespace rbf

@@ -110,6 +110,27 @@ def test_residual_mask_uint16_wrap(eng, oracle):
         assert int(ones[0]) == r["ones"]
 
 
+@pytest.mark.parametrize("dtype,channels", [(np.uint8, 1), (np.uint8, 3), (np.uint16, 1), (np.uint16, 3)])
+def test_residual_mask_gop_layouts(eng, oracle, dtype, channels):
+    """GOP-streaming mask kernel (16-byte aligned flat frames) + generic tail, every sample layout,
+    5 frames, thresholds incl. the int16 wrap region for 16-bit samples."""
+    W, H, F = 112, 75, 5                      # n = 8400 = 8 segments of 1024 + a 208-pixel tail
+    rng = np.random.default_rng(1234)
+    hi = 256 if dtype == np.uint8 else 65536
+    shape = (F, H, W) if channels == 1 else (F, H, W, channels)
+    frames = rng.integers(0, hi, shape, dtype=dtype)
+    frames[1:][rng.random(frames[1:].shape) < 0.7] = 0      # plenty of equal / extreme pairs
+    frames[2] = frames[1]                                   # an all-zero mask
+    for thr in (0.0, 2.5, 100.0, 32767.0, -3.0):
+        masks, ones = eng.residual_masks(frames, thr)
+        for f in range(F - 1):
+            a = frames[f] if channels == 1 else frames[f][:, :, 0]
+            b = frames[f + 1] if channels == 1 else frames[f + 1][:, :, 0]
+            want = oracle.residual_mask(a, b, thr).reshape(-1)
+            assert np.array_equal(unpack(masks[f], W * H), want), (thr, f)
+            assert int(ones[f]) == int(want.sum())
+
+
 def test_batch_equals_oracle(eng, oracle):
     """A ragged batch: 5 frames of 211x97 (n % 1024 != 0, n % 64 != 0), different densities."""
     W, H = 211, 97

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of tools/profile.sh: per-kernel time stats and PMC counters per launch."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def short(name):
+    name = name.split("(")[0]
+    for tok in ("void rbf::", "rbf::"):
+        name = name.replace(tok, "")
+    return name[:60]
+
+
+for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    print("== kernel stats:", os.path.relpath(f, root))
+    for row in csv.DictReader(open(f)):
+        print("  %-60s calls %5s  avg %10.1f ns  total %12s ns  %5s%%" % (
+            short(row.get("Name", "")), row.get("Calls"), float(row.get("AverageNs", 0)), row.get("TotalDurationNs"), row.get("Percentage")))
+
+for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(set)
+        for row in csv.DictReader(open(f)):
+            k = short(row.get("Kernel_Name", ""))
+            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            cnt[k].add(row.get("Dispatch_Id"))
+        print("== counters (mean per launch):", os.path.relpath(f, root))
+        for k in acc:
+            n = max(1, len(cnt[k]))
+            print("  %-60s launches %d" % (k, n))
+            for c, v in sorted(acc[k].items()):
+                print("      %-24s %16.1f" % (c, v / n))
