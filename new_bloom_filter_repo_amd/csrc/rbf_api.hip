@@ -43,15 +43,6 @@ struct rbf_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     // scratch (grown on demand, never shrunk)
-    FrameDev *fp_dev = nullptr;      size_t fp_cap = 0;       // bytes
-    // pinned staging ring for the per-batch parameter upload (a slot is reused only after the
-    // copy that read it has completed, so back-to-back batches never block the host)
-    static constexpr int RING = 4;
-    FrameDev *fp_pinned[RING] = {nullptr, nullptr, nullptr, nullptr};
-    size_t fp_pinned_cap[RING] = {0, 0, 0, 0};
-    hipEvent_t fp_event[RING] = {nullptr, nullptr, nullptr, nullptr};
-    bool fp_busy[RING] = {false, false, false, false};
-    int fp_next = 0;
     uint32_t *seg_bits = nullptr;    size_t seg_bits_cap = 0; // bytes
     uint32_t *seg_cnt = nullptr;     size_t seg_cnt_cap = 0;
     uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
@@ -59,8 +50,10 @@ struct rbf_ctx {
     uint32_t *partials = nullptr;    size_t partials_cap = 0;
     int force_generic = 0;           // tests: 1 = never use the LDS fast path
     int single_buffer = 0;           // tests: 1 = fast query path without filter double-buffering
-    // host staging of encode_gop
+    // host staging of encode_gop: device-visible pinned block [flag | ones...] the GPU publishes into
     uint64_t *ones_pinned = nullptr; size_t host_cap = 0;
+    uint64_t *ones_mapped_dev = nullptr;     // device address of the same block
+    uint64_t publish_token = 0;
     std::vector<rbf_filter_params> plan;
     std::vector<double> plan_k;
     // timing
@@ -172,11 +165,6 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
-    if (ctx->fp_dev) (void)hipFree(ctx->fp_dev);
-    for (int k = 0; k < rbf_ctx::RING; ++k) {
-        if (ctx->fp_pinned[k]) (void)hipHostFree(ctx->fp_pinned[k]);
-        if (ctx->fp_event[k]) (void)hipEventDestroy(ctx->fp_event[k]);
-    }
     if (ctx->ones_pinned) (void)hipHostFree(ctx->ones_pinned);
     if (ctx->seg_bits) (void)hipFree(ctx->seg_bits);
     if (ctx->seg_cnt) (void)hipFree(ctx->seg_cnt);
@@ -346,33 +334,17 @@ int rbf_plan_batch(uint64_t n, const uint64_t *ones, uint32_t nframes, int guard
 // ------------------------------------------------------------------------------------------
 // shared argument plumbing
 // ------------------------------------------------------------------------------------------
-static int upload_params(rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes)
+static int fill_table(const rbf_filter_params *params, uint32_t count, FrameTable *tab)
 {
-    const size_t bytes = (size_t)nframes * sizeof(FrameDev);
-    if (int r = grow((void **)&ctx->fp_dev, &ctx->fp_cap, bytes)) return r;
-    const int slot = ctx->fp_next;
-    ctx->fp_next = (slot + 1) % rbf_ctx::RING;
-    if (!ctx->fp_event[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->fp_event[slot], hipEventDisableTiming));
-    if (ctx->fp_busy[slot]) { HIP_TRY(hipEventSynchronize(ctx->fp_event[slot])); ctx->fp_busy[slot] = false; }
-    if (bytes > ctx->fp_pinned_cap[slot]) {
-        if (ctx->fp_pinned[slot]) HIP_TRY(hipHostFree(ctx->fp_pinned[slot]));
-        ctx->fp_pinned[slot] = nullptr; ctx->fp_pinned_cap[slot] = 0;
-        const size_t want = bytes + 16 * sizeof(FrameDev);
-        HIP_TRY(hipHostMalloc((void **)&ctx->fp_pinned[slot], want, hipHostMallocDefault));
-        ctx->fp_pinned_cap[slot] = want;
-    }
-    FrameDev *stage = ctx->fp_pinned[slot];
-    for (uint32_t f = 0; f < nframes; ++f) {
+    memset(tab, 0, sizeof *tab);
+    for (uint32_t f = 0; f < count; ++f) {
         if (params[f].floor_k > 64) return fail(RBF_ERANGE, "frame %u: floor_k %u > 64", f, params[f].floor_k);
-        FrameDev &d = stage[f];
+        FrameDev &d = tab->f[f];
         d.m = params[f].m;
         d.floor_k = params[f].floor_k;
         d.T = params[f].threshold;
         d.M = params[f].m >= 2 ? (uint64_t)((((unsigned __int128)1) << 64) / params[f].m) : 0;
     }
-    HIP_TRY(hipMemcpyAsync(ctx->fp_dev, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->fp_event[slot], ctx->stream));
-    ctx->fp_busy[slot] = true;
     return RBF_OK;
 }
 
@@ -508,28 +480,26 @@ static int check_filter_strides(const rbf_filter_params *params, uint32_t nframe
     return RBF_OK;
 }
 
-int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
-                           uint64_t n, uint32_t nframes, const rbf_filter_params *params,
-                           const rbf_seeds *seeds,
-                           void *filters_dev, uint64_t filter_stride_bytes,
-                           void *witnesses_dev, uint64_t witness_stride_bytes,
-                           uint64_t *stats_dev)
+// one chunk of at most MAX_BATCH frames (the geometry table rides in the kernel arguments)
+static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
+                        uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                        const rbf_seeds *seeds,
+                        void *filters_dev, uint64_t filter_stride_bytes,
+                        void *witnesses_dev, uint64_t witness_stride_bytes,
+                        uint64_t *stats_dev, bool outputs_zeroed)
 {
-    if (int r = set_device(ctx)) return r;
-    if (!masks_dev || !params || !seeds || !filters_dev || !witnesses_dev || !stats_dev) return fail(RBF_EINVAL, "null pointer");
-    if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
-    if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
-    if (witness_stride_bytes % 8 || witness_stride_bytes < ((n + 63) / 64) * 8) return fail(RBF_EINVAL, "witness stride too small or misaligned");
-    if (nframes > 65535) return fail(RBF_ERANGE, "at most 65535 frames per batch");
     const Plan pl = make_plan(ctx, params, nframes, n);
-    if (int r = upload_params(ctx, params, nframes)) return r;
+    FrameTable tab;
+    if (int r = fill_table(params, nframes, &tab)) return r;
     if (int r = grow((void **)&ctx->seg_bits, &ctx->seg_bits_cap, (size_t)nframes * pl.nseg * pl.seg_words * 4)) return r;
     if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
 
-    HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)nframes * witness_stride_bytes, ctx->stream));
-    HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)nframes * RBF_STATS_PER_FRAME * 8, ctx->stream));
+    if (!outputs_zeroed) {
+        HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)nframes * witness_stride_bytes, ctx->stream));
+        HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)nframes * RBF_STATS_PER_FRAME * 8, ctx->stream));
+    }
     // ---- insert
     if (pl.fast_insert) {
         const uint64_t part_stride = pl.fwords_even;
@@ -538,7 +508,7 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
         {
             LaunchTimer t(ctx, RBF_K_INSERT);
             hipLaunchKernelGGL(k_insert_lds, dim3(pl.S, nframes), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
-                               (const uint8_t *)masks_dev, mask_stride_bytes, n, ctx->fp_dev, sd, ctx->partials, part_stride, pl.fwords_max);
+                               (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.fwords_max);
         }
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);
@@ -546,7 +516,7 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
             uint32_t bx = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx < 1) bx = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)ctx->partials, part_stride, pl.S, ctx->fp_dev, (uint32_t *)filters_dev, words, stats_dev);
+                               (const uint32_t *)ctx->partials, part_stride, pl.S, tab, (uint32_t *)filters_dev, words, stats_dev);
         }
     } else {
         HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
@@ -556,7 +526,7 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
         {
             LaunchTimer t(ctx, RBF_K_INSERT);
             hipLaunchKernelGGL(k_insert, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, ctx->fp_dev, sd,
+                               (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, tab, sd,
                                (uint32_t *)filters_dev, filter_stride_bytes / 4);
         }
         {
@@ -565,7 +535,7 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
             uint32_t bx2 = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx2 < 1) bx2 = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx2, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)filters_dev, words, 1u, ctx->fp_dev, (uint32_t *)filters_dev, words, stats_dev);
+                               (const uint32_t *)filters_dev, words, 1u, tab, (uint32_t *)filters_dev, words, stats_dev);
         }
     }
     // ---- query + witness staging
@@ -576,14 +546,14 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
         hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, nframes, ctx->fp_dev, sd,
+                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, nframes, tab, sd,
                            (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                            ctx->seg_bits, ctx->seg_cnt, pl.nseg, (uint64_t *)nullptr);
     } else {
         const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
         hipLaunchKernelGGL(k_query<true>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, ctx->fp_dev, sd,
+                           (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, tab, sd,
                            (const uint32_t *)filters_dev, filter_stride_bytes / 4,
                            ctx->seg_bits, ctx->seg_cnt, pl.nseg, (uint64_t *)nullptr);
     }
@@ -607,6 +577,50 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
     return RBF_OK;
 }
 
+static int encode_batch_impl(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
+                             uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                             const rbf_seeds *seeds,
+                             void *filters_dev, uint64_t filter_stride_bytes,
+                             void *witnesses_dev, uint64_t witness_stride_bytes,
+                             uint64_t *stats_dev, bool outputs_zeroed)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!masks_dev || !params || !seeds || !filters_dev || !witnesses_dev || !stats_dev) return fail(RBF_EINVAL, "null pointer");
+    if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
+    if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
+    if (witness_stride_bytes % 8 || witness_stride_bytes < ((n + 63) / 64) * 8) return fail(RBF_EINVAL, "witness stride too small or misaligned");
+    for (uint32_t f0 = 0; f0 < nframes; f0 += MAX_BATCH) {
+        const uint32_t cnt = nframes - f0 < (uint32_t)MAX_BATCH ? nframes - f0 : (uint32_t)MAX_BATCH;
+        if (int r = encode_chunk(ctx, (const uint8_t *)masks_dev + (uint64_t)f0 * mask_stride_bytes, mask_stride_bytes, n, cnt, params + f0, seeds,
+                                 (uint8_t *)filters_dev + (uint64_t)f0 * filter_stride_bytes, filter_stride_bytes,
+                                 (uint8_t *)witnesses_dev + (uint64_t)f0 * witness_stride_bytes, witness_stride_bytes,
+                                 stats_dev + (uint64_t)f0 * RBF_STATS_PER_FRAME, outputs_zeroed))
+            return r;
+    }
+    return RBF_OK;
+}
+
+int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
+                           uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                           const rbf_seeds *seeds,
+                           void *filters_dev, uint64_t filter_stride_bytes,
+                           void *witnesses_dev, uint64_t witness_stride_bytes,
+                           uint64_t *stats_dev)
+{
+    return encode_batch_impl(ctx, masks_dev, mask_stride_bytes, n, nframes, params, seeds, filters_dev, filter_stride_bytes,
+                             witnesses_dev, witness_stride_bytes, stats_dev, false);
+}
+
+// copies the ones counts into the device-visible pinned block and raises its flag word
+__global__ void k_publish_ones(const uint64_t *__restrict__ ones, uint64_t *host_block, uint32_t count, uint64_t token)
+{
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x)
+        __hip_atomic_store(&host_block[1 + i], ones[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&host_block[0], token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
                    uint32_t nframes, uint32_t width, uint32_t height,
                    uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
@@ -616,46 +630,62 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
                    void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
                    rbf_filter_params *params_out, double *k_out)
 {
+    if (!filters_dev || !witnesses_dev || !stats_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
     if (int r = rbf_residual_mask_batch(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
                                         pixel_stride_bytes, sample_bytes, thr_floor, masks_dev, mask_stride_bytes, ones_dev))
         return r;
     const uint32_t pairs = nframes - 1;
     const uint64_t n = (uint64_t)width * height;
+    if (witness_stride_bytes % 8 || witness_stride_bytes < ((n + 63) / 64) * 8) return fail(RBF_EINVAL, "witness stride too small or misaligned");
     if (pairs > ctx->host_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->ones_pinned) HIP_TRY(hipHostFree(ctx->ones_pinned));
         ctx->ones_pinned = nullptr; ctx->host_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&ctx->ones_pinned, (size_t)(pairs + 16) * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&ctx->ones_pinned, (size_t)(pairs + 17) * sizeof(uint64_t), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&ctx->ones_mapped_dev, ctx->ones_pinned, 0));
+        ctx->ones_pinned[0] = 0;
         ctx->plan.resize(pairs + 16);
         ctx->plan_k.resize(pairs + 16);
         ctx->host_cap = pairs + 16;
     }
-    HIP_TRY(hipMemcpyAsync(ctx->ones_pinned, ones_dev, (size_t)pairs * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (int r = rbf_plan_batch(n, ctx->ones_pinned, pairs, 1, ctx->plan.data(), ctx->plan_k.data())) return r;
+    // The GPU publishes the counts straight into host memory; meanwhile the output buffers are
+    // cleared, so the only thing between the mask kernel and the Bloom kernels is the host's
+    // float64 parameter math.
+    const uint64_t token = ++ctx->publish_token;
+    hipLaunchKernelGGL(k_publish_ones, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)ones_dev, ctx->ones_mapped_dev, pairs, token);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)pairs * witness_stride_bytes, ctx->stream));
+    HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)pairs * RBF_STATS_PER_FRAME * 8, ctx->stream));
+    volatile uint64_t *flag = ctx->ones_pinned;
+    for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != token; ++spins) {
+        if ((spins & 0xFFFF) == 0xFFFF) {                    // every ~65k polls make sure the stream is still alive
+            hipError_t q = hipStreamQuery(ctx->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(RBF_EIO, "stream failed while waiting for the mask kernel: %s", hipGetErrorString(q));
+            if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != token)
+                return fail(RBF_EIO, "mask kernel finished without publishing its counts");
+        }
+        __builtin_ia32_pause();
+    }
+    if (int r = rbf_plan_batch(n, ctx->ones_pinned + 1, pairs, 1, ctx->plan.data(), ctx->plan_k.data())) return r;
     if (params_out) memcpy(params_out, ctx->plan.data(), (size_t)pairs * sizeof(rbf_filter_params));
     if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)pairs * sizeof(double));
-    return rbf_bloom_encode_batch(ctx, masks_dev, mask_stride_bytes, n, pairs, ctx->plan.data(), seeds,
-                                  filters_dev, filter_stride_bytes, witnesses_dev, witness_stride_bytes, stats_dev);
+    return encode_batch_impl(ctx, masks_dev, mask_stride_bytes, n, pairs, ctx->plan.data(), seeds,
+                             filters_dev, filter_stride_bytes, witnesses_dev, witness_stride_bytes, stats_dev, true);
 }
 
 // ------------------------------------------------------------------------------------------
 // A6
 // ------------------------------------------------------------------------------------------
-int rbf_bloom_decode_batch(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_stride_bytes,
-                           const void *witnesses_dev, uint64_t witness_stride_bytes,
-                           uint64_t n, uint32_t nframes, const rbf_filter_params *params,
-                           const rbf_seeds *seeds,
-                           void *masks_dev, uint64_t mask_stride_bytes)
+static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_stride_bytes,
+                        const void *witnesses_dev, uint64_t witness_stride_bytes,
+                        uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                        const rbf_seeds *seeds,
+                        void *masks_dev, uint64_t mask_stride_bytes)
 {
-    if (int r = set_device(ctx)) return r;
-    if (!filters_dev || !witnesses_dev || !params || !seeds || !masks_dev) return fail(RBF_EINVAL, "null pointer");
-    if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
-    if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
-    if (witness_stride_bytes % 8) return fail(RBF_EINVAL, "witness stride must be a multiple of 8");
-    if (nframes > 65535) return fail(RBF_ERANGE, "at most 65535 frames per batch");
     const Plan pl = make_plan(ctx, params, nframes, n);
     const uint32_t wps = pl.fast_query ? (uint32_t)QL_P : (uint32_t)SEG_ITERS;      // pass words per segment
-    if (int r = upload_params(ctx, params, nframes)) return r;
+    FrameTable tab;
+    if (int r = fill_table(params, nframes, &tab)) return r;
     if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * wps * 8)) return r;
@@ -667,14 +697,14 @@ int rbf_bloom_decode_batch(rbf_ctx *ctx, const void *filters_dev, uint64_t filte
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
         hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                           (const uint64_t *)nullptr, (uint64_t)0, n, nframes, ctx->fp_dev, sd,
+                           (const uint64_t *)nullptr, (uint64_t)0, n, nframes, tab, sd,
                            (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                            (uint32_t *)nullptr, ctx->seg_cnt, pl.nseg, ctx->pass_words);
     } else {
         const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
         hipLaunchKernelGGL(k_query<false>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           (const uint32_t *)nullptr, (uint64_t)0, n, ctx->fp_dev, sd,
+                           (const uint32_t *)nullptr, (uint64_t)0, n, tab, sd,
                            (const uint32_t *)filters_dev, filter_stride_bytes / 4,
                            (uint32_t *)nullptr, ctx->seg_cnt, pl.nseg, ctx->pass_words);
     }
@@ -691,6 +721,27 @@ int rbf_bloom_decode_batch(rbf_ctx *ctx, const void *filters_dev, uint64_t filte
                            (uint64_t *)masks_dev, mask_stride_bytes / 8, n);
     }
     HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+int rbf_bloom_decode_batch(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_stride_bytes,
+                           const void *witnesses_dev, uint64_t witness_stride_bytes,
+                           uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                           const rbf_seeds *seeds,
+                           void *masks_dev, uint64_t mask_stride_bytes)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!filters_dev || !witnesses_dev || !params || !seeds || !masks_dev) return fail(RBF_EINVAL, "null pointer");
+    if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
+    if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
+    if (witness_stride_bytes % 8) return fail(RBF_EINVAL, "witness stride must be a multiple of 8");
+    for (uint32_t f0 = 0; f0 < nframes; f0 += MAX_BATCH) {
+        const uint32_t cnt = nframes - f0 < (uint32_t)MAX_BATCH ? nframes - f0 : (uint32_t)MAX_BATCH;
+        if (int r = decode_chunk(ctx, (const uint8_t *)filters_dev + (uint64_t)f0 * filter_stride_bytes, filter_stride_bytes,
+                                 (const uint8_t *)witnesses_dev + (uint64_t)f0 * witness_stride_bytes, witness_stride_bytes, n, cnt,
+                                 params + f0, seeds, (uint8_t *)masks_dev + (uint64_t)f0 * mask_stride_bytes, mask_stride_bytes))
+            return r;
+    }
     return RBF_OK;
 }
 

@@ -27,6 +27,11 @@ struct FrameDev {
 
 struct Seeds { uint64_t h1, h2, act; };
 
+// A batch's geometry travels BY VALUE in the kernel-argument segment (3 KiB of the 4 KiB limit):
+// no upload, no device buffer, and the per-frame fields arrive through scalar loads.
+constexpr int MAX_BATCH = 128;
+struct FrameTable { FrameDev f[MAX_BATCH]; };
+
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
 // Packed vectors are MSB-first per byte (numpy.packbits).  In a little-endian 32-bit word the

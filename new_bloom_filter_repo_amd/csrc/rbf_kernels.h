@@ -74,12 +74,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask(
 // that the (expensive) hashing runs with all lanes busy although only ~9 % of pixels are set.
 __global__ __launch_bounds__(WG_THREADS) void k_insert(
     const uint32_t *__restrict__ masks, uint64_t mask_stride_words32, uint64_t n,
-    const FrameDev *__restrict__ fp, Seeds seeds,
+    const FrameTable tab, Seeds seeds,
     uint32_t *__restrict__ filters, uint64_t filter_stride_words32)
 {
     __shared__ uint32_t list[WG_WAVES][WAVE * 32];
     const uint32_t f = blockIdx.y;
-    const FrameDev fd = fp[f];
+    const FrameDev fd = tab.f[f];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (fd.m == 0) return;                                  // frame not Bloom-coded (passthrough)
     const uint32_t *mask = masks + (uint64_t)f * mask_stride_words32;
@@ -139,14 +139,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_insert(
 template <bool ENCODE>
 __global__ __launch_bounds__(WG_THREADS) void k_query(
     const uint32_t *__restrict__ masks, uint64_t mask_stride_words32, uint64_t n,
-    const FrameDev *__restrict__ fp, Seeds seeds,
+    const FrameTable tab, Seeds seeds,
     const uint32_t *__restrict__ filters, uint64_t filter_stride_words32,
     uint32_t *__restrict__ seg_bits, uint32_t *__restrict__ seg_cnt, uint64_t nseg,
     uint64_t *__restrict__ pass_words)
 {
     __shared__ uint32_t wbuf[WG_WAVES][SEG_WORDS];
     const uint32_t f = blockIdx.y;
-    const FrameDev fd = fp[f];
+    const FrameDev fd = tab.f[f];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
     const bool live = seg < nseg;

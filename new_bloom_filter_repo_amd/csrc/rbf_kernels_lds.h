@@ -41,14 +41,14 @@ __device__ __forceinline__ void wave_lds_fence()
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
-    const FrameDev *__restrict__ fp, Seeds seeds,
+    const FrameTable tab, Seeds seeds,
     uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t fwords_max)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *filt = lds;                                         // [fwords_max (even)]
     uint32_t *queues = lds + ((fwords_max + 1u) & ~1u);           // [IL_WAVES][IL_QUEUE]
     const uint32_t f = blockIdx.y, s = blockIdx.x, S = gridDim.x;
-    const FrameDev fd = fp[f];
+    const FrameDev fd = tab.f[f];
     if (fd.m == 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t fwords = (fd.m + 31u) >> 5;
@@ -116,13 +116,13 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
 // OR the S partial filters of every frame into the final packed filter; count its set bits.
 __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
     const uint32_t *partials, uint64_t part_stride_words32, uint32_t S,
-    const FrameDev *__restrict__ fp,
+    const FrameTable tab,
     uint32_t *filters /* may alias partials when S == 1 */, uint64_t filter_stride_words32,
     uint64_t *__restrict__ stats)
 {
     __shared__ uint32_t red[WG_WAVES];
     const uint32_t f = blockIdx.y;
-    const uint32_t m = fp[f].m;
+    const uint32_t m = tab.f[f].m;
     const uint32_t fwords = m ? ((m + 31u) >> 5) : 0u;
     uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
     uint32_t pc = 0;
@@ -184,7 +184,7 @@ __device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t
 template <bool ENCODE, bool DOUBLE_BUFFER, bool SMALL_M>
 __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n, uint32_t nframes,
-    const FrameDev *__restrict__ fp, Seeds seeds,
+    const FrameTable tab, Seeds seeds,
     const uint32_t *__restrict__ filters, uint64_t filter_stride_words32, uint32_t fwords_max,
     uint32_t *__restrict__ seg_bits, uint32_t *__restrict__ seg_cnt, uint64_t nseg,
     uint64_t *__restrict__ pass_words)
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     // passthrough frames (m == 0): nothing passes
     uint32_t f = nframes;
     for (uint32_t g = nframes; g-- > 0;) {
-        if (fp[g].m == 0) {
+        if (tab.f[g].m == 0) {
             if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
             if (!ENCODE && live && lane < QL_P) pass_words[((uint64_t)g * nseg + seg) * QL_P + lane] = 0;
         } else {
@@ -238,12 +238,12 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     uint64_t mw_next = 0;
     if (DOUBLE_BUFFER && f < nframes) {
         mw_next = load_mw(f);
-        dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (fp[f].m + 31u) >> 5, wave, lane, QL_WAVES);
+        dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (tab.f[f].m + 31u) >> 5, wave, lane, QL_WAVES);
     }
     while (f < nframes) {
         uint32_t fn = f + 1;
-        while (fn < nframes && fp[fn].m == 0) ++fn;               // next active frame
-        const FrameDev fd = fp[f];
+        while (fn < nframes && tab.f[fn].m == 0) ++fn;               // next active frame
+        const FrameDev fd = tab.f[f];
         uint64_t mw;
         const uint32_t *filt;
         if (DOUBLE_BUFFER) {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
             if (fn < nframes) {
                 mw_next = load_mw(fn);
                 dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
-                           (fp[fn].m + 31u) >> 5, wave, lane, QL_WAVES);
+                           (tab.f[fn].m + 31u) >> 5, wave, lane, QL_WAVES);
             }
             cur ^= 1u;
         } else {
