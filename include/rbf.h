@@ -87,8 +87,9 @@ int rbf_memset(rbf_ctx *ctx, void *dst_dev, int value, size_t bytes);           
 int rbf_memcpy_h2d(rbf_ctx *ctx, void *dst_dev, const void *src, size_t bytes);  /* blocks */
 int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes);  /* blocks */
 
-/* Per-kernel HIP-event timing (bench.py): when enabled every kernel launch is bracketed by
- * events on the context's stream.  kernel ids: RBF_K_*.  rbf_timing_read blocks. */
+/* Per-kernel HIP-event timing (bench.py): launches of the selected kernels are bracketed by
+ * events on the context's stream.  `on`: 0 = off, 1 = every kernel, otherwise a bit mask with
+ * bit RBF_K_* set for each kernel to time.  rbf_timing_read blocks until the stream is idle. */
 #define RBF_K_MASK    0
 #define RBF_K_INSERT  1
 #define RBF_K_QUERY   2

@@ -182,7 +182,8 @@ class Context:
 
     # ---- timing
     def timing(self, on):
-        check(lib().rbf_timing_enable(self.handle, 1 if on else 0))
+        """on: False/0 off, True/1 every kernel, or an int bit mask of kernel ids (1 << K_QUERY ...)."""
+        check(lib().rbf_timing_enable(self.handle, int(on)))
 
     def timing_reset(self):
         check(lib().rbf_timing_reset(self.handle))

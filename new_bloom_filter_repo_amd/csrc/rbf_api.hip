@@ -57,7 +57,7 @@ struct rbf_ctx {
     std::vector<rbf_filter_params> plan;
     std::vector<double> plan_k;
     // timing
-    bool timing = false;
+    uint32_t timing = 0;             // bit k: bracket launches of kernel id k with HIP events
     std::vector<Timed> pending;
     std::vector<hipEvent_t> pool;
     double total_ms[RBF_K_COUNT] = {0};
@@ -84,7 +84,7 @@ static int set_device(rbf_ctx *ctx)
 
 struct LaunchTimer {
     rbf_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; bool on;
-    LaunchTimer(rbf_ctx *ctx, int kid) : c(ctx), id(kid), on(ctx->timing)
+    LaunchTimer(rbf_ctx *ctx, int kid) : c(ctx), id(kid), on((ctx->timing >> kid) & 1u)
     {
         if (!on) return;
         auto get = [&]() {
@@ -236,7 +236,7 @@ int rbf_timing_enable(rbf_ctx *ctx, int on)
 {
     if (int r = set_device(ctx)) return r;
     if (!on) { if (int r = drain_timing(ctx)) return r; }
-    ctx->timing = on != 0;
+    ctx->timing = on == 1 ? 0xFFFFFFFFu : (uint32_t)on;
     return RBF_OK;
 }
 

@@ -148,22 +148,52 @@ __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
 // query, frames-inner
 // ------------------------------------------------------------------------------------------
 // Filter staging by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, no
-// ds_write pass).  LDS destination = wave-uniform base + lane*16; the global source is per lane.
+// ds_write pass).  LDS destination = M0 (wave-uniform base) + lane*16; the global source is per lane.
+//
+// The DMA is issued from inline asm ON PURPOSE: when hipcc sees the builtin it cannot tell the DMA's
+// LDS destination (the *other* buffer) from the probes' source, so it drains vmcnt(0) in front of
+// every LDS access of the compute phase and the double buffering buys nothing (measured: 35 us of
+// a 183 us launch).  Asm DMAs are invisible to its scoreboard; completion is waited for explicitly
+// with dma_wait_all() right before the workgroup barrier that hands the buffer over.
+__device__ __forceinline__ void dma16(const uint32_t *gsrc, uint32_t lds_byte_addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void dma4(const uint32_t *gsrc, uint32_t lds_byte_addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t lds_addr_of(const uint32_t *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)p;
+}
+
 __device__ __forceinline__ void dma_filter(uint32_t *lds_dst, const uint32_t *src, uint32_t words, uint32_t wave,
                                            uint32_t lane, uint32_t nwaves)
 {
+    const uint32_t base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds_dst));
     const uint32_t npieces = words >> 2;                      // whole 16-byte pieces
     const uint32_t nchunks = (npieces + 63u) >> 6;
     for (uint32_t c = wave; c < nchunks; c += nwaves) {
         const uint32_t piece = (c << 6) + lane;
-        if (piece < npieces)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (piece << 2)),
-                                             (__attribute__((address_space(3))) void *)(lds_dst + (c << 8)), 16, 0, 0);
+        if (piece < npieces) dma16(src + (piece << 2), __builtin_amdgcn_readfirstlane(base + (c << 10)));
     }
     const uint32_t tail = words & 3u;                         // 0..3 dwords left: 4-byte DMA
-    if (wave == 0 && lane < tail)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (npieces << 2) + lane),
-                                         (__attribute__((address_space(3))) void *)(lds_dst + (npieces << 2)), 4, 0, 0);
+    if (wave == 0 && lane < tail) dma4(src + (npieces << 2) + lane, __builtin_amdgcn_readfirstlane(base + (npieces << 4)));
 }
 
 // h mod m for 2 <= m <= 2^30 with three 32x32 multiplies for the quotient estimate:
@@ -180,8 +210,60 @@ __device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t
     return r;
 }
 
+// One frame's pass over a wave's QL_P x 64 pixels: reductions mod m, LDS probes, ballot, witness
+// compaction.  FK >= 0: floor(k*) known at compile time (fully unrolled probes); FK < 0: runtime fk.
+// AB (ablation mask, tools/bench_query.hip only; 0 in the library): 1 = no reductions, 2 = no LDS
+// probes, 4 = no compaction, 8 = no filter staging, 16 = no hashing.
+template <bool ENCODE, bool SMALL_M, int FK, int AB = 0>
+__device__ __forceinline__ void frame_pass(
+    const uint64_t (&h1)[QL_P], const uint64_t (&h2)[QL_P], const uint64_t (&ha)[QL_P], uint32_t validmask,
+    const uint32_t *filt, uint32_t m, uint64_t M, uint64_t T, uint32_t fk_rt,
+    uint32_t mw_lo, uint32_t mw_hi, uint32_t lane, uint32_t *stg, uint32_t &woff, uint64_t &mypw)
+{
+    const uint32_t Mh = (uint32_t)(M >> 32), Ml = (uint32_t)M;
+    const uint32_t fk = FK >= 0 ? (uint32_t)FK : fk_rt;
+    // Phase 1 -- branch-free for FK >= 0, so the scheduler can interleave the QL_P independent
+    // dependency chains (reductions -> LDS probes -> ballot) instead of running them one by one.
+    uint64_t pw[QL_P];
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) {
+        uint32_t pos, step;
+        if (AB & 1) { pos = (uint32_t)h1[it] & 0x7FFFFu; step = (uint32_t)h2[it] & 0x3FFFFu; }
+        else if (SMALL_M) { pos = mod_m_small(h1[it], m, Mh, Ml); step = mod_m_small(h2[it], m, Mh, Ml); }
+        else         { pos = mod_m(h1[it], m, M);            step = mod_m(h2[it], m, M); }
+        const bool extra = ha[it] < T;
+        uint32_t ok = (validmask >> it) & 1u;
+#pragma unroll
+        for (uint32_t j = 0; j < fk; ++j) {
+            ok &= ((AB & 2) ? (pos * 0x9E3779B1u) : filt[pos >> 5]) >> msb_pos(pos);
+            if (SMALL_M) { const uint32_t s2 = pos + step; pos = min(s2, s2 - m); }
+            else { const uint64_t s2 = (uint64_t)pos + step; pos = (uint32_t)(s2 >= m ? s2 - m : s2); }
+        }
+        const uint32_t x = ((AB & 2) ? (pos * 0x85EBCA77u) : filt[pos >> 5]) >> msb_pos(pos);
+        ok &= extra ? x : 1u;
+        pw[it] = __ballot((ok & 1u) != 0);
+    }
+    // Phase 2 -- order-preserving compaction of the mask bits of the passing positions.
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) {
+        if (AB & 4) { woff += (uint32_t)pw[it] & 1u; continue; }
+        if (ENCODE) {
+            const uint32_t w_hi = __builtin_amdgcn_readlane(mw_hi, it), w_lo = __builtin_amdgcn_readlane(mw_lo, it);
+            const uint64_t w = ((uint64_t)w_hi << 32) | w_lo;
+            const uint64_t tp = pw[it] & w;                    // passes whose mask bit is 1 (wave-uniform)
+            if ((tp >> lane) & 1ull) {
+                const uint32_t dst = woff + rank_below(pw[it]);
+                atomicOr(&stg[dst >> 5], 1u << (dst & 31u));
+            }
+        } else {
+            if (lane == (uint32_t)it) mypw = pw[it];
+        }
+        woff += __popcll(pw[it]);
+    }
+}
+
 // SMALL_M: every filter of the batch has 2 <= m <= 2^30 (host-checked) -> cheap reductions.
-template <bool ENCODE, bool DOUBLE_BUFFER, bool SMALL_M>
+template <bool ENCODE, bool DOUBLE_BUFFER, bool SMALL_M, int AB = 0>
 __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n, uint32_t nframes,
     const FrameTable tab, Seeds seeds,
@@ -193,7 +275,8 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     const uint32_t bufwords = (fwords_max + 3u) & ~3u;            // 16-byte multiple
     uint32_t *stage = lds + (DOUBLE_BUFFER ? 2u : 1u) * bufwords; // [QL_WAVES][QL_SEG_WORDS]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t seg = (uint64_t)blockIdx.x * QL_WAVES + wave;
+    const uint32_t nwaves = blockDim.x >> 6;                      // 16 (one workgroup per CU) or 8 (two per CU)
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
     const bool live = seg < nseg;
     const uint64_t base = seg * QL_SEG_PIXELS;
     const uint64_t nwords64 = (n + 63) >> 6;
@@ -208,10 +291,13 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
         const uint64_t i = base + (uint64_t)it * WAVE + lane;
         h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
         if (live && i < n) {
-            const DecKey key = make_key((uint32_t)i);
-            h1[it] = xxh64_key(key, seeds.h1);
-            h2[it] = xxh64_key(key, seeds.h2);
-            ha[it] = xxh64_key(key, seeds.act);
+            if (AB & 16) { h1[it] = i * P1; h2[it] = i * P2 + seeds.h2; ha[it] = i * P3; }
+            else {
+                const DecKey key = make_key((uint32_t)i);
+                h1[it] = xxh64_key(key, seeds.h1);
+                h2[it] = xxh64_key(key, seeds.h2);
+                ha[it] = xxh64_key(key, seeds.act);
+            }
             validmask |= 1u << it;
         }
     }
@@ -238,28 +324,34 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     uint64_t mw_next = 0;
     if (DOUBLE_BUFFER && f < nframes) {
         mw_next = load_mw(f);
-        dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (tab.f[f].m + 31u) >> 5, wave, lane, QL_WAVES);
+        if (!(AB & 8)) dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (tab.f[f].m + 31u) >> 5, wave, lane, nwaves);
     }
     while (f < nframes) {
+        f = __builtin_amdgcn_readfirstlane(f);                    // frame indices are wave-uniform: scalar table loads
         uint32_t fn = f + 1;
         while (fn < nframes && tab.f[fn].m == 0) ++fn;               // next active frame
+        fn = __builtin_amdgcn_readfirstlane(fn);
         const FrameDev fd = tab.f[f];
         uint64_t mw;
         const uint32_t *filt;
         if (DOUBLE_BUFFER) {
-            __syncthreads();          // DMA(f) has landed for every wave; buffer cur^1 is free again
+            if (!(AB & 32)) {
+            dma_wait_all();           // my share of DMA(f) has landed ...
+            __syncthreads();          // ... and everyone's; buffer cur^1 is free again
+            }
             mw = mw_next;
             filt = lds + cur * bufwords;
             if (fn < nframes) {
                 mw_next = load_mw(fn);
-                dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
-                           (tab.f[fn].m + 31u) >> 5, wave, lane, QL_WAVES);
+                if (!(AB & 8)) dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
+                                          (tab.f[fn].m + 31u) >> 5, wave, lane, nwaves);
             }
             cur ^= 1u;
         } else {
             __syncthreads();          // previous frame's probes are done
             mw = load_mw(f);
-            dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (fd.m + 31u) >> 5, wave, lane, QL_WAVES);
+            if (!(AB & 8)) dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (fd.m + 31u) >> 5, wave, lane, nwaves);
+            dma_wait_all();
             __syncthreads();
             filt = lds;
         }
@@ -278,35 +370,16 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
 
         uint32_t woff = 0;
         uint64_t mypw = 0;
-#pragma unroll
-        for (int it = 0; it < QL_P; ++it) {
-            uint32_t pos, step;
-            if (SMALL_M) { pos = mod_m_small(h1[it], m, Mh, Ml); step = mod_m_small(h2[it], m, Mh, Ml); }
-            else         { pos = mod_m(h1[it], m, M);            step = mod_m(h2[it], m, M); }
-            const bool extra = ha[it] < T;
-            uint32_t ok = (validmask >> it) & 1u;
-            for (uint32_t j = 0; j < fk; ++j) {
-                ok &= filt[pos >> 5] >> msb_pos(pos);
-                if (SMALL_M) { const uint32_t s2 = pos + step; pos = min(s2, s2 - m); }
-                else { const uint64_t s2 = (uint64_t)pos + step; pos = (uint32_t)(s2 >= m ? s2 - m : s2); }
-            }
-            const uint32_t x = filt[pos >> 5] >> msb_pos(pos);
-            ok &= extra ? x : 1u;
-            const bool pass = ok & 1u;
-            const uint64_t pw = __ballot(pass);
-            if (ENCODE) {
-                const uint32_t w_hi = __builtin_amdgcn_readlane(mw_hi, it), w_lo = __builtin_amdgcn_readlane(mw_lo, it);
-                const uint64_t w = ((uint64_t)w_hi << 32) | w_lo;
-                const uint64_t tp = pw & w;                        // passes whose mask bit is 1 (wave-uniform)
-                if ((tp >> lane) & 1ull) {
-                    const uint32_t dst = woff + rank_below(pw);
-                    atomicOr(&stg[dst >> 5], 1u << (dst & 31u));
-                }
-            } else {
-                if (lane == (uint32_t)it) mypw = pw;
-            }
-            woff += __popcll(pw);
+        // floor(k*) is a small integer: straight-line code for the common values lets the compiler
+        // issue every LDS probe of all QL_P pixels back to back instead of one round trip at a time.
+        switch (fk) {
+        case 1: frame_pass<ENCODE, SMALL_M, 1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
+        case 2: frame_pass<ENCODE, SMALL_M, 2, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
+        case 3: frame_pass<ENCODE, SMALL_M, 3, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
+        case 4: frame_pass<ENCODE, SMALL_M, 4, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
+        default: frame_pass<ENCODE, SMALL_M, -1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
         }
+        if (AB & 64) { f = fn; continue; }
         if (ENCODE) {
             wave_lds_fence();
             if (lane < QL_SEG_WORDS) {
