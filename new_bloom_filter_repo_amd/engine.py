@@ -136,3 +136,95 @@ def threshold_floor(threshold):
     import math
     t = math.floor(threshold)
     return int(max(-2 ** 31, min(2 ** 31 - 1, t)))
+
+
+class DeviceFilter:
+    """One packed Bloom filter of m bits living in device memory (RationalBloomFilter's storage)."""
+
+    def __init__(self, ctx, m):
+        self.ctx, self.m = ctx, int(m)
+        self.nbytes = nat.packed_stride(self.m)
+        self.buf = ctx.alloc(self.nbytes).zero()
+
+    def _params(self, floor_k, threshold):
+        return nat.FilterParams(self.m, int(floor_k), int(threshold))
+
+    def insert(self, indices, floor_k, threshold, seeds):
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        if idx.size == 0:
+            return
+        ib = self.ctx.alloc(idx.nbytes).upload(idx)
+        p, sd = self._params(floor_k, threshold), nat.Seeds(*[int(s) for s in seeds])
+        nat.check(nat.lib().rbf_filter_insert_indices(self.ctx.handle, self.buf.ptr, ctypes.byref(p), ctypes.byref(sd), ib.ptr, idx.size))
+        ib.free()
+
+    def query(self, indices, floor_k, threshold, seeds):
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        if idx.size == 0:
+            return np.zeros(0, dtype=bool)
+        ib = self.ctx.alloc(idx.nbytes).upload(idx)
+        ob = self.ctx.alloc(idx.size)
+        p, sd = self._params(floor_k, threshold), nat.Seeds(*[int(s) for s in seeds])
+        nat.check(nat.lib().rbf_filter_query_indices(self.ctx.handle, self.buf.ptr, ctypes.byref(p), ctypes.byref(sd), ib.ptr, idx.size, ob.ptr))
+        out = ob.download(idx.size).astype(bool)
+        ib.free(); ob.free()
+        return out
+
+    def bits(self):
+        """np.uint8[m], one byte per bit (the reference's `bit_array`)."""
+        return np.unpackbits(self.buf.download(self.nbytes))[:self.m]
+
+    def set_bits(self, bit_array):
+        bit_array = np.asarray(bit_array, dtype=np.uint8).reshape(-1)
+        if bit_array.size != self.m:
+            raise ValueError("bit_array must have %d entries" % self.m)
+        row = np.zeros(self.nbytes, dtype=np.uint8)
+        pk = np.packbits(bit_array)
+        row[:pk.size] = pk
+        self.buf.upload(row)
+
+    def free(self):
+        self.buf.free()
+
+
+def gather_values(ctx, frame, mask_packed):
+    """Changed-pixel values of `frame` (H, W[, C]) at the mask's '1' pixels, raster order (A2)."""
+    frame = np.ascontiguousarray(frame)
+    H, W = frame.shape[:2]
+    C = frame.shape[2] if frame.ndim == 3 else 1
+    sb = frame.dtype.itemsize
+    n = H * W
+    fb = ctx.alloc(frame.nbytes).upload(frame)
+    row = np.zeros(nat.packed_stride(n), dtype=np.uint8)
+    row[:(n + 7) // 8] = np.asarray(mask_packed, dtype=np.uint8)[:(n + 7) // 8]
+    mb = ctx.alloc(row.nbytes).upload(row)
+    vb = ctx.alloc(max(frame.nbytes, 8))
+    cb = ctx.alloc(8)
+    nat.check(nat.lib().rbf_gather_values(ctx.handle, fb.ptr, W, H, W * C * sb, C * sb, sb, C, mb.ptr, vb.ptr, cb.ptr))
+    cnt = int(cb.download(8, dtype=np.uint64)[0])
+    vals = vb.download(cnt * C * sb).view(frame.dtype).copy()
+    for b in (fb, mb, vb, cb):
+        b.free()
+    return vals
+
+
+def scatter_values(ctx, frame, mask_packed, values):
+    """Copy of `frame` with `values` written at the mask's '1' pixels, raster order (A8)."""
+    frame = np.ascontiguousarray(frame)
+    H, W = frame.shape[:2]
+    C = frame.shape[2] if frame.ndim == 3 else 1
+    sb = frame.dtype.itemsize
+    n = H * W
+    values = np.ascontiguousarray(values, dtype=frame.dtype).reshape(-1)
+    fb = ctx.alloc(frame.nbytes).upload(frame)
+    row = np.zeros(nat.packed_stride(n), dtype=np.uint8)
+    row[:(n + 7) // 8] = np.asarray(mask_packed, dtype=np.uint8)[:(n + 7) // 8]
+    mb = ctx.alloc(row.nbytes).upload(row)
+    vb = ctx.alloc(max(values.nbytes, 8))
+    if values.nbytes:
+        vb.upload(values)
+    nat.check(nat.lib().rbf_scatter_values(ctx.handle, fb.ptr, W, H, W * C * sb, C * sb, sb, C, mb.ptr, vb.ptr))
+    out = fb.download(frame.nbytes).view(frame.dtype).reshape(frame.shape).copy()
+    for b in (fb, mb, vb):
+        b.free()
+    return out

@@ -1,0 +1,253 @@
+"""Frame-level codecs around the GPU Bloom path.
+
+* FixedVideoCompressor -- the zlib keyframe codec and the YUV frame wrapper the product surface
+  uses (fixed_video_compressor.py:15-334).  Plain host Python: keyframes are not on the hot path.
+* VideoFrameCompressor -- the inter-frame residual codec (improved_video_compressor.py:768-1027):
+  luma residual mask (A1), changed-value gather (A2), Bloom+witness coding of the mask (A3-A5),
+  the wire record (A7) and the inverse (A6, A8).  In the reference these methods read
+  `self.bloom_compressor`, which nothing ever assigns; here the constructor wires it.
+
+Deliberate, documented divergences from the reference record format:
+  - k travels as float64 ('<d'), not float32: with float32 the decoder's activation threshold
+    differs from the encoder's and roughly 1 in 130 1080p frames would desynchronise the witness.
+    `wire_format="reference"` reproduces the reference bytes exactly (tests pin it to fixture G7).
+  - changed values keep the frame dtype (the reference hard-codes uint8, which truncates 16-bit video).
+"""
+import io
+import struct
+import zlib
+
+import numpy as np
+
+from . import _native as nat
+from . import params as P
+from .bloom_compressor import BloomFilterCompressor
+from .engine import BloomEngine, gather_values, scatter_values
+
+
+# ----------------------------------------------------------------------------- YUV wrapper
+class YUVFrame:
+    """ndarray-like wrapper carrying contiguous copies of the three planes
+    (FixedVideoCompressor.add_yuv_info_to_frame, fixed_video_compressor.py:287-334)."""
+
+    def __init__(self, frame):
+        frame = np.asarray(frame)
+        self.data = frame
+        self.yuv_info = {"format": "YUV444",
+                         "y_plane": frame[:, :, 0].copy(),
+                         "u_plane": frame[:, :, 1].copy(),
+                         "v_plane": frame[:, :, 2].copy()}
+        self.shape, self.dtype, self.nbytes = frame.shape, frame.dtype, frame.nbytes
+
+    def __array__(self, dtype=None, copy=None):
+        return self.data if dtype is None else self.data.astype(dtype)
+
+    def copy(self):
+        return YUVFrame(self.data.copy())
+
+    def __getitem__(self, key):
+        return self.data[key]
+
+    def __setitem__(self, key, value):
+        self.data[key] = value
+
+    def tobytes(self):
+        return self.data.tobytes()
+
+    def astype(self, dtype):
+        return self.data.astype(dtype)
+
+    def flatten(self):
+        return self.data.flatten()
+
+    def reshape(self, *a, **k):
+        return self.data.reshape(*a, **k)
+
+    @property
+    def size(self):
+        return self.data.size
+
+    @property
+    def T(self):
+        return self.data.T
+
+
+def frame_data(frame):
+    """The ndarray behind a frame (YUVFrame or ndarray)."""
+    return frame.data if isinstance(frame, YUVFrame) else np.asarray(frame)
+
+
+# ----------------------------------------------------------------------------- keyframes
+class FixedVideoCompressor:
+    """Per-frame zlib-9 codec, byte-compatible with the reference's keyframe record:
+    '<III' height width itemsize | '<I' len | zlib(frame) | '<B' has_yuv [| planes ...]."""
+
+    def __init__(self, verbose=True):
+        self.verbose = verbose
+
+    def compress_frame(self, frame):
+        arr = frame_data(frame)
+        body = zlib.compress(arr.tobytes(), level=9)
+        out = [struct.pack("<III", arr.shape[0], arr.shape[1], arr.dtype.itemsize),
+               struct.pack("<I", len(body)), body]
+        has_info = hasattr(frame, "yuv_info")
+        out.append(struct.pack("<B", 1 if has_info else 0))
+        if has_info:
+            fmt = frame.yuv_info.get("format", "YUV444").encode("utf-8")
+            out += [struct.pack("<H", len(fmt)), fmt]
+            for key in ("y_plane", "u_plane", "v_plane"):
+                plane = frame.yuv_info[key]
+                z = zlib.compress(plane.tobytes(), level=9)
+                out += [struct.pack("<I", len(z)), z, struct.pack("<II", *plane.shape)]
+        return b"".join(out)
+
+    def decompress_frame(self, blob):
+        h, w, item = struct.unpack_from("<III", blob, 0)
+        (size,) = struct.unpack_from("<I", blob, 12)
+        raw = zlib.decompress(blob[16:16 + size])
+        dtype = {1: np.uint8, 2: np.uint16}.get(item, np.float32)
+        gray = h * w * item
+        if len(raw) > gray and len(raw) % gray == 0:
+            return np.frombuffer(raw, dtype=dtype).reshape(h, w, len(raw) // gray)
+        return np.frombuffer(raw, dtype=dtype).reshape(h, w)
+
+    def compress_video(self, frames):
+        if self.verbose:
+            print(f"Compressing {len(frames)} frames")
+        return [self.compress_frame(f) for f in frames]
+
+    def decompress_video(self, blobs):
+        if self.verbose:
+            print(f"Decompressing {len(blobs)} frames")
+        return [self.decompress_frame(b) for b in blobs]
+
+    def verify_lossless(self, original_frames, decompressed_frames):
+        from .verify import verify_lossless
+        res = verify_lossless(original_frames, decompressed_frames)
+        if self.verbose and "exact_frame_matches" in res:
+            print(f"Lossless verification: {'SUCCESS' if res['lossless'] else 'FAILED'}")
+            print(f"Exact frame matches: {res['exact_frame_matches']}/{res['total_frames']}")
+        return res
+
+    def add_yuv_info_to_frame(self, yuv_frame):
+        return YUVFrame(yuv_frame)
+
+
+# ----------------------------------------------------------------------------- inter-frames
+class VideoFrameCompressor:
+    def __init__(self, noise_tolerance=10.0, keyframe_interval=30, min_diff_threshold=3.0,
+                 max_diff_threshold=30.0, bloom_threshold_modifier=1.0, num_threads=None,
+                 use_direct_yuv=False, verbose=False, wire_format="f64", ctx=None):
+        self.noise_tolerance = noise_tolerance
+        self.keyframe_interval = keyframe_interval
+        self.min_diff_threshold = min_diff_threshold
+        self.max_diff_threshold = max_diff_threshold
+        self.bloom_threshold_modifier = bloom_threshold_modifier
+        self.use_direct_yuv = use_direct_yuv
+        self.verbose = verbose
+        self.num_threads = max(1, num_threads or 1)            # kept for signature parity; the GPU does the work
+        if wire_format not in ("f64", "reference"):
+            raise ValueError("wire_format must be 'f64' or 'reference'")
+        self.wire_format = wire_format
+        self._ctx = ctx or nat.default_context()
+        self.bloom_compressor = BloomFilterCompressor(verbose=False, ctx=self._ctx)
+        self._engine = BloomEngine(self._ctx)
+
+    # ---- A1 + A2
+    def _luma_pair(self, prev_frame, curr_frame):
+        a, b = frame_data(prev_frame), frame_data(curr_frame)
+        if a.shape != b.shape or a.dtype != b.dtype:
+            raise ValueError("frames must have the same shape and dtype")
+        if a.dtype not in (np.uint8, np.uint16):
+            raise ValueError("8- or 16-bit unsigned samples expected")
+        is_color = a.ndim > 2 and a.shape[2] > 1
+        if is_color and not (self.use_direct_yuv and a.shape[2] >= 3):
+            raise NotImplementedError("BGR/RGB input needs OpenCV's BGR2GRAY (improved_video_compressor.py:794); "
+                                      "pass YUV frames with use_direct_yuv=True or 2-D luma frames")
+        return a, b, is_color
+
+    def _calculate_frame_diff(self, prev_frame, curr_frame, threshold=None):
+        """(binary_diff HxW uint8, changed_values, density) -- improved_video_compressor.py:768-847."""
+        if threshold is None:
+            raise NotImplementedError("the noise-adaptive threshold needs a 5x5 median blur (cv2.medianBlur, :738); "
+                                      "pass an explicit threshold (0.0 for lossless coding)")
+        a, b, is_color = self._luma_pair(prev_frame, curr_frame)
+        masks, ones = self._engine.residual_masks(np.stack([a, b]), threshold)
+        h, w = a.shape[:2]
+        n = h * w
+        packed = masks[0][:(n + 7) // 8]
+        values = gather_values(self._ctx, b, packed)
+        binary_diff = np.unpackbits(packed)[:n].reshape(h, w)
+        density = np.uint64(ones[0]) / binary_diff.size
+        return binary_diff, values, density
+
+    # ---- A8
+    def _apply_frame_diff(self, base_frame, diff_mask, changed_values):
+        """improved_video_compressor.py:849-909 (color frames are left untouched when the value
+        count does not match, exactly as the reference's `if len(changed_values) == expected_values`)."""
+        base = frame_data(base_frame)
+        mask = np.asarray(diff_mask, dtype=np.uint8)
+        ch = base.shape[2] if base.ndim == 3 else 1
+        count = int(mask.sum())
+        if len(changed_values) != count * ch:
+            if base.ndim == 3 and ch > 1:
+                out = base.copy()
+                return YUVFrame(out) if isinstance(base_frame, YUVFrame) else out
+            raise ValueError("changed_values does not match the mask")
+        out = scatter_values(self._ctx, base, np.packbits(mask.reshape(-1)), np.asarray(changed_values).astype(base.dtype))
+        return YUVFrame(out) if isinstance(base_frame, YUVFrame) else out
+
+    # ---- A3-A5 + A7
+    def _compress_frame_differences(self, binary_diff, changed_values):
+        """(record bytes, ratio) -- improved_video_compressor.py:911-967."""
+        flat = np.asarray(binary_diff).flatten()
+        bitmap, witness, p, n, _ = self.bloom_compressor.compress(flat)
+        k, _l = self.bloom_compressor._calculate_optimal_params(n, p)
+        buf = io.BytesIO()
+        buf.write(struct.pack("<f", p))
+        buf.write(struct.pack("<I", n))
+        buf.write(struct.pack("<f" if self.wire_format == "reference" else "<d", k))
+        buf.write(struct.pack("<I", len(bitmap)))
+        buf.write(struct.pack("<I", len(witness)))
+        bm = np.packbits(bitmap).tobytes()
+        buf.write(struct.pack("<I", len(bm))); buf.write(bm)
+        wb = np.packbits(np.array(witness, dtype=np.uint8)).tobytes()
+        buf.write(struct.pack("<I", len(wb))); buf.write(wb)
+        vals = np.asarray(changed_values)
+        vz = zlib.compress(vals.tobytes(), level=9)
+        buf.write(struct.pack("<I", len(vz)))
+        buf.write(struct.pack("<I", len(vals)))
+        buf.write(vz)
+        ratio = (buf.tell() * 8) / (n + len(vals) * 8)
+        return buf.getvalue(), ratio
+
+    def _decompress_frame_differences(self, compressed_data, frame_shape, dtype=np.uint8):
+        """(binary_diff, changed_values) -- improved_video_compressor.py:969-1027."""
+        mv = memoryview(compressed_data)
+        off = 0
+
+        def take(fmt):
+            nonlocal off
+            v = struct.unpack_from(fmt, mv, off)[0]
+            off += struct.calcsize(fmt)
+            return v
+        _p = take("<f")
+        n = take("<I")
+        k = take("<f" if self.wire_format == "reference" else "<d")
+        bitmap_len = take("<I")
+        witness_len = take("<I")
+        size = take("<I")
+        bitmap = np.unpackbits(np.frombuffer(mv[off:off + size], dtype=np.uint8))[:bitmap_len]
+        off += size
+        size = take("<I")
+        witness = np.unpackbits(np.frombuffer(mv[off:off + size], dtype=np.uint8))[:witness_len].tolist()
+        off += size
+        vsize = take("<I")
+        vcount = take("<I")
+        values = np.frombuffer(zlib.decompress(mv[off:off + vsize]), dtype=dtype)[:vcount]
+        flat = self.bloom_compressor.decompress(bitmap, witness, n, k) if witness_len > 0 else bitmap
+        if len(frame_shape) == 3 and frame_shape[2] > 1:
+            shape = (frame_shape[0], frame_shape[1])
+        else:
+            shape = tuple(frame_shape)
+        return np.asarray(flat).reshape(shape), values

@@ -1,0 +1,175 @@
+"""ImprovedVideoCompressor -- the product surface (improved_video_compressor.py:309-669), with the
+inter-frame route the reference never wired in: frame t is a keyframe iff t % keyframe_interval == 0
+(zlib, FixedVideoCompressor); every other frame is coded as a luma residual mask against frame t-1
+through the GPU Bloom path (VideoFrameCompressor).
+
+Losslessness is kept unconditional, as the reference promises ("True Lossless"): an inter-frame is
+only emitted when applying its record to frame t-1 reproduces frame t bit for bit (the luma mask at
+threshold 0 must cover every changed pixel); otherwise that frame falls back to a keyframe.
+
+Container: all-keyframe streams are written exactly as the reference does -- 'BFVC' | <I frames |
+(<I len | record)* (:398-406) -- so either implementation reads them.  Streams with inter-frames use
+magic 'BFV2' and prefix every record with a type byte (1 = keyframe, 2 = inter-frame), following the
+type-byte precedent of VideoFrameCompressor.compress_frame (:1053).
+"""
+import os
+import struct
+import time
+
+import numpy as np
+
+from .frame_codec import FixedVideoCompressor, VideoFrameCompressor, YUVFrame, frame_data
+
+KEY, INTER = 1, 2
+
+
+class ImprovedVideoCompressor:
+    def __init__(self, noise_tolerance=10.0, keyframe_interval=30, min_diff_threshold=3.0,
+                 max_diff_threshold=30.0, bloom_threshold_modifier=1.0, batch_size=30,
+                 num_threads=None, use_direct_yuv=False, verbose=False, ctx=None):
+        self.noise_tolerance = noise_tolerance
+        self.keyframe_interval = max(1, int(keyframe_interval))
+        self.min_diff_threshold = min_diff_threshold
+        self.max_diff_threshold = max_diff_threshold
+        self.bloom_threshold_modifier = bloom_threshold_modifier
+        self.batch_size = batch_size
+        self.use_direct_yuv = use_direct_yuv
+        self.verbose = verbose
+        self.compressor = FixedVideoCompressor(verbose=verbose)
+        self._ctx = ctx
+        self._inter = None
+        self.last_compressed_frames = None       # [(type, record bytes)] of the last compress_video call
+
+    @property
+    def inter(self):
+        if self._inter is None:
+            self._inter = VideoFrameCompressor(keyframe_interval=self.keyframe_interval, use_direct_yuv=True,
+                                               verbose=False, ctx=self._ctx)
+        return self._inter
+
+    # ------------------------------------------------------------------ encode
+    def _encode_inter(self, prev, curr):
+        """Record bytes for frame `curr` against `prev`, or None when a keyframe is needed."""
+        a, b = frame_data(prev), frame_data(curr)
+        if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (np.uint8, np.uint16):
+            return None
+        if a.ndim == 3 and a.shape[2] < 3:
+            return None
+        mask, values, _ = self.inter._calculate_frame_diff(a, b, threshold=0.0)
+        changed = (a != b)
+        if changed.ndim == 3:
+            changed = changed.any(axis=2)
+        if np.any(changed & (mask == 0)):        # chroma moved where luma did not: not representable
+            return None
+        record, _ = self.inter._compress_frame_differences(mask, values)
+        return struct.pack("<B", b.dtype.itemsize) + record
+
+    def compress_video(self, frames, output_path=None, input_color_space="BGR"):
+        if not frames:
+            raise ValueError("No frames provided for compression")
+        start = time.time()
+        yuv = input_color_space.upper() == "YUV"
+        if yuv:
+            self.use_direct_yuv = True
+            for i in range(len(frames)):
+                if not hasattr(frames[i], "yuv_info"):
+                    frames[i] = self.compressor.add_yuv_info_to_frame(frames[i])
+        original_size = sum(f.nbytes for f in frames)
+        records = []
+        for t, frame in enumerate(frames):
+            rec = None
+            if yuv and t % self.keyframe_interval != 0:
+                rec = self._encode_inter(frames[t - 1], frame)
+            records.append((INTER, rec) if rec is not None else (KEY, self.compressor.compress_frame(frame)))
+        self.last_compressed_frames = records
+        keyframes = sum(1 for ty, _ in records if ty == KEY)
+        blob = self._container(records)
+        if output_path:
+            os.makedirs(os.path.dirname(os.path.abspath(output_path)), exist_ok=True)
+            with open(output_path, "wb") as f:
+                f.write(blob)
+        compressed_size = len(blob)
+        ratio = compressed_size / original_size
+        elapsed = time.time() - start
+        results = {"frame_count": len(frames), "original_size": original_size, "compressed_size": compressed_size,
+                   "compression_ratio": ratio, "space_savings": 1.0 - ratio, "compression_time": elapsed,
+                   "frames_per_second": len(frames) / elapsed if elapsed > 0 else float("inf"),
+                   "keyframes": keyframes, "keyframe_ratio": keyframes / len(frames),
+                   "output_path": output_path, "color_space": input_color_space, "overall_ratio": ratio}
+        if self.verbose:
+            print("\\nCompression Results:")
+            print(f"Original Size: {original_size / (1024 * 1024):.2f} MB")
+            print(f"Compressed Size: {compressed_size / (1024 * 1024):.2f} MB")
+            print(f"Compression Ratio: {ratio:.4f}")
+            print(f"Keyframes: {keyframes} ({results['keyframe_ratio'] * 100:.1f}%)")
+        return results
+
+    @staticmethod
+    def _container(records):
+        all_key = all(ty == KEY for ty, _ in records)
+        out = [b"BFVC" if all_key else b"BFV2", struct.pack("<I", len(records))]
+        for ty, rec in records:
+            body = rec if all_key else struct.pack("<B", ty) + rec
+            out += [struct.pack("<I", len(body)), body]
+        return b"".join(out)
+
+    # ------------------------------------------------------------------ decode
+    @staticmethod
+    def _parse_container(blob):
+        magic = blob[:4]
+        if magic not in (b"BFVC", b"BFV2"):
+            raise ValueError(f"Invalid file format: {magic}")
+        (count,) = struct.unpack_from("<I", blob, 4)
+        off, records = 8, []
+        for _ in range(count):
+            (size,) = struct.unpack_from("<I", blob, off)
+            body = blob[off + 4: off + 4 + size]
+            off += 4 + size
+            records.append((KEY, body) if magic == b"BFVC" else (body[0], body[1:]))
+        return records
+
+    def decompress_video(self, input_path=None, output_path=None, compressed_frames=None, metadata=None):
+        start = time.time()
+        records = None
+        if input_path and os.path.exists(input_path):
+            with open(input_path, "rb") as f:
+                records = self._parse_container(f.read())
+        elif compressed_frames:
+            records = [r if isinstance(r, tuple) else (KEY, r) for r in compressed_frames]
+        if not records:
+            raise ValueError("No compressed frames provided")
+        frames = []
+        for ty, rec in records:
+            if ty == KEY:
+                frames.append(self.compressor.decompress_frame(rec))
+            elif ty == INTER:
+                if not frames:
+                    raise ValueError("inter-frame without a preceding keyframe")
+                base = frames[-1]
+                dtype = np.uint8 if rec[0] == 1 else np.uint16
+                mask, values = self.inter._decompress_frame_differences(rec[1:], base.shape, dtype=dtype)
+                frames.append(self.inter._apply_frame_diff(base, mask, values))
+            else:
+                raise ValueError(f"unknown record type {ty}")
+        if output_path:
+            self.save_frames_as_video(frames, output_path)
+        if self.verbose:
+            print(f"Decompressed {len(frames)} frames in {time.time() - start:.2f} seconds")
+        return frames
+
+    def verify_lossless(self, original_frames, decompressed_frames):
+        return self.compressor.verify_lossless(original_frames, decompressed_frames)
+
+    # ------------------------------------------------------------------ video file I/O (OpenCV, out of scope)
+    def save_frames_as_video(self, frames, output_path, fps=30):
+        if not frames:
+            raise ValueError("No frames provided")
+        raise RuntimeError("writing video files needs OpenCV (cv2.VideoWriter, improved_video_compressor.py:525-581), "
+                           "which is outside this package's scope; frames are returned as arrays")
+
+    def extract_frames_from_video(self, video_path, max_frames=0, target_fps=None, scale_factor=1.0,
+                                  output_color_space="BGR"):
+        if not os.path.exists(video_path):
+            raise ValueError(f"Video file not found: {video_path}")
+        raise RuntimeError("reading video files needs OpenCV (cv2.VideoCapture, improved_video_compressor.py:583-669), "
+                           "which is outside this package's scope; pass frames as arrays")

@@ -1,0 +1,131 @@
+"""GPU: the reference's class surface on the HIP path -- RationalBloomFilter, BloomFilterCompressor,
+VideoFrameCompressor (wire record, gather / scatter), ImprovedVideoCompressor round trips."""
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+import new_bloom_filter_repo_amd as pkg
+from new_bloom_filter_repo_amd import _native as nat
+from new_bloom_filter_repo_amd import params as P
+from new_bloom_filter_repo_amd.synthetic import make_gop, make_mask, next_frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = nat.Context(0)
+    yield c
+    c.close()
+
+
+def test_rational_bloom_filter_class(ctx, oracle):
+    for size, k, seeds in ((1000, 2.3038118730600234, None), (13183, 3.2062923944339987, None), (10, 1.3862943611198906, (0, 1, 2)),
+                           (1, 0.1, None), (7, 12.25, (5, 6, 7))):
+        f = pkg.RationalBloomFilter(size, k, seeds=seeds, ctx=ctx)
+        o = oracle.RationalFilter(size, k, seeds or P.SEEDS_VIDEO)
+        assert (f.size, f.k_star, f.floor_k, f.p_activation) == (o.size, o.k_star, o.floor_k, o.p_activation)
+        if seeds is None:
+            assert (f.h1_seed, f.h2_seed) == (0x12345678, 0x87654321)
+        items = [0, 1, 9, 10, 4242, 99999, 100000, 2073599, 8294399, 12345678, 4294967295]
+        for i in items[:6]:
+            f.add_index(i); o.add_index(i)
+        f.add_indices(items[6:])
+        for i in items[6:]:
+            o.add_index(i)
+        assert np.array_equal(f.bit_array, o.bit_array)
+        probe = list(range(0, 3000, 7)) + items
+        assert list(f.check_indices(probe)) == [o.check_index(i) for i in probe]
+        assert f.check_index(4242) is True
+        # assigning the bitmap (decompress does this, :290)
+        f.bit_array = np.zeros(size, dtype=np.uint8)
+        assert not f.bit_array.any() and (k < 1 or not f.check_index(4242))
+
+
+def test_bloom_filter_compressor_class(ctx):
+    meta = load_json("g3_320x180.json")["cases"]
+    z = load_npz("g3_320x180.npz")
+    comp = pkg.BloomFilterCompressor(ctx=ctx)
+    old = pkg.BloomFilterCompressor(seeds=P.SEEDS_BLOOM_COMPRESS, guard_l_ge_n=False, ctx=ctx)
+    assert comp.P_STAR == 0.32453
+    for rec in meta:
+        n = rec["W"] * rec["H"]
+        mask = np.unpackbits(z[rec["case"] + "_mask"])[:n]
+        for c, vname, prefix in ((comp, "video", "video"), (old, "bloom_compress", "bc")):
+            v = rec["variants"][vname]
+            bm, wit, p, nn, ratio = c.compress(mask)
+            assert nn == n and isinstance(wit, list)
+            if v["passthrough"]:
+                assert wit == [] and ratio == 1.0 and np.array_equal(bm, mask)
+                assert np.array_equal(c.decompress(bm, wit, n, 0), mask)
+                continue
+            assert np.array_equal(np.packbits(bm), z["%s_%s_filter" % (rec["case"], prefix)])
+            assert np.array_equal(np.packbits(np.array(wit, dtype=np.uint8)), z["%s_%s_witness" % (rec["case"], prefix)])
+            if vname == "video":
+                assert float(ratio).hex() == v["ratio_hex"] and float(p).hex() == v["p_hex"]
+            k, l = c._calculate_optimal_params(n, p)
+            assert np.array_equal(c.decompress(bm, wit, n, k), mask)
+    with pytest.raises(ValueError):
+        comp.compress(np.zeros(0, dtype=np.uint8))
+    # batch form incl. a passthrough frame
+    masks = [make_mask(s, 5000, p) for s, p in ((1, 0.05), (2, 0.5), (3, 0.2))]
+    recs = comp.compress_batch(np.stack([np.packbits(m) for m in masks]), 5000)
+    assert [r["passthrough"] for r in recs] == [False, True, False]
+    dec = comp.decompress_batch([recs[0], recs[2]], 5000)
+    assert np.array_equal(np.unpackbits(dec[0])[:5000], masks[0]) and np.array_equal(np.unpackbits(dec[1])[:5000], masks[2])
+
+
+def test_video_frame_compressor_matches_reference_fixture(ctx):
+    z, meta = load_npz("g7_g9_frame_codec.npz"), load_json("g7_g9_frame_codec.json")
+    prev, curr = z["prev"], z["curr"]
+    v = pkg.VideoFrameCompressor(use_direct_yuv=True, num_threads=1, wire_format="reference", ctx=ctx)
+    fx = pkg.FixedVideoCompressor(verbose=False)
+    pf, cf = fx.add_yuv_info_to_frame(prev), fx.add_yuv_info_to_frame(curr)
+    mask, values, density = v._calculate_frame_diff(pf, cf, threshold=0.0)
+    assert np.array_equal(mask, z["mask"]) and np.array_equal(values, z["values"])
+    assert float(density).hex() == meta["density_hex"]
+    blob, ratio = v._compress_frame_differences(mask, values)
+    assert blob == z["blob"].tobytes() and float(ratio).hex() == meta["ratio_hex"]      # byte-identical wire record
+    m2, v2 = v._decompress_frame_differences(blob, prev.shape)
+    assert np.array_equal(m2, z["dec_mask"]) and np.array_equal(v2, z["dec_values"])
+    nxt = v._apply_frame_diff(pf, m2, v2)
+    assert np.array_equal(np.asarray(nxt.data), z["applied"]) and np.array_equal(nxt.yuv_info["u_plane"], curr[:, :, 1])
+    # grayscale path, plain ndarray path
+    mg, vg, _ = v._calculate_frame_diff(prev[:, :, 0].copy(), curr[:, :, 0].copy(), threshold=0.0)
+    assert np.array_equal(mg, z["mask_gray"]) and np.array_equal(vg, z["values_gray"])
+    assert np.array_equal(v._apply_frame_diff(prev[:, :, 0].copy(), mg, vg), z["applied_gray"])
+    mp, vp, _ = v._calculate_frame_diff(prev, curr, threshold=0.0)
+    assert np.array_equal(vp, z["values_plain"]) and np.array_equal(v._apply_frame_diff(prev, mp, vp), z["applied_plain"])
+    # the default record (float64 k) round-trips too and differs only in the k field
+    v64 = pkg.VideoFrameCompressor(use_direct_yuv=True, ctx=ctx)
+    blob64, _ = v64._compress_frame_differences(mask, values)
+    assert len(blob64) == len(blob) + 4
+    m3, v3 = v64._decompress_frame_differences(blob64, prev.shape)
+    assert np.array_equal(m3, mask) and np.array_equal(v3, values)
+    with pytest.raises(NotImplementedError):
+        v._calculate_frame_diff(pf, cf)                      # adaptive threshold: OpenCV median blur (next row f3)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_improved_video_compressor_round_trip(ctx, tmp_path, dtype):
+    W, H, F = 96, 64, 7
+    frames = make_gop(555, W, H, F, p=0.08, dtype=dtype)
+    frames[4] = frames[3].copy()                            # identical frame: empty mask (passthrough record)
+    frames[5] = frames[4].copy(); frames[5][10, 10, 2] ^= 1  # chroma-only change: must fall back to a keyframe
+    frames[6] = next_frame(np.random.default_rng(9), frames[5], 0.4)   # dense change: Bloom passthrough (p >= P*)
+    comp = pkg.ImprovedVideoCompressor(keyframe_interval=4, verbose=False, ctx=ctx)
+    path = str(tmp_path / "clip.bfvc")
+    res = comp.compress_video([f.copy() for f in frames], path, input_color_space="YUV")
+    assert res["frame_count"] == F and res["keyframes"] == 3            # t = 0, 4 and the chroma-only frame 5
+    assert [ty for ty, _ in comp.last_compressed_frames] == [1, 2, 2, 2, 1, 1, 2]
+    dec = comp.decompress_video(path)
+    assert len(dec) == F
+    for a, b in zip(frames, dec):
+        assert np.asarray(b).dtype == a.dtype and np.array_equal(a, np.asarray(getattr(b, "data", b)))
+    v = comp.verify_lossless(frames, dec)
+    assert v["lossless"] and v["exact_frame_matches"] == F
+    assert pkg.verify_bit_exact(frames, dec)["success"]
+    assert open(path, "rb").read(4) == b"BFV2"
+    # in-memory records decode as well
+    dec2 = comp.decompress_video(compressed_frames=comp.last_compressed_frames)
+    assert all(np.array_equal(a, np.asarray(getattr(b, "data", b))) for a, b in zip(frames, dec2))

@@ -1,0 +1,175 @@
+"""CPU-only: host-side logic of the product package (no GPU compute calls):
+parameter math vs the reference fixtures, the C ABI's host helpers vs the Python ones, the C-ABI
+surface (every symbol include/rbf.h declares is exported), keyframe codec / container / verifiers."""
+import ctypes
+import math
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_json, load_npz
+from new_bloom_filter_repo_amd import _native as nat
+from new_bloom_filter_repo_amd import params as P
+from new_bloom_filter_repo_amd.synthetic import make_gop, P_KSTAR_2_3
+
+
+def test_abi_header_matches_binding_and_library():
+    hdr = open(os.path.join(REPO, "include", "rbf.h")).read()
+    declared = set(re.findall(r"\b(rbf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(nat.exported_symbols()), declared ^ set(nat.exported_symbols())
+    lib = nat.lib()                       # loads librbf_hip.so (needs no GPU)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rbf_version() == 1
+    assert isinstance(lib.rbf_last_error(), bytes)
+
+
+def test_no_cpu_fallback_message(monkeypatch):
+    monkeypatch.setattr(nat, "LIB_PATH", "/nonexistent/librbf_hip.so")
+    monkeypatch.setattr(nat, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nat.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "new_bloom_filter_repo_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.lower(), f
+
+
+def test_params_match_reference_fixture():
+    for r in load_json("g2_params.json")["rows"]:
+        p = np.uint64(r["ones"]) / r["n"]
+        k, l = P.optimal_params(r["n"], p)
+        assert float(k).hex() == r["k_hex"] and int(l) == r["l"]
+
+
+def test_c_host_math_matches_python():
+    lib = nat.lib()
+    for r in load_json("g2_params.json")["rows"]:
+        k, l = ctypes.c_double(), ctypes.c_uint64()
+        assert lib.rbf_optimal_params(r["n"], r["ones"], ctypes.byref(k), ctypes.byref(l)) == 0
+        assert float(k.value).hex() == r["k_hex"] and l.value == r["l"], r
+        if r["l"]:
+            fk, t = ctypes.c_uint32(), ctypes.c_uint64()
+            assert lib.rbf_activation_threshold(k.value, ctypes.byref(fk), ctypes.byref(t)) == 0
+            assert (fk.value, t.value) == P.activation_threshold(k.value)
+    # plan_batch incl. passthrough decisions
+    n = 57600
+    ones = [0, 3, 62, 1696, 5261, 17894, 18692, 18693, 23048, 57600]
+    arr = (ctypes.c_uint64 * len(ones))(*ones)
+    par = (nat.FilterParams * len(ones))()
+    ks = (ctypes.c_double * len(ones))()
+    assert lib.rbf_plan_batch(n, arr, len(ones), 1, par, ks) == 0
+    for i, c in enumerate(ones):
+        p = np.uint64(c) / n
+        k, l = (0, 0) if p >= P.P_STAR else P.optimal_params(n, p)
+        if l == 0 or l >= n:
+            assert par[i].m == 0
+        else:
+            assert (par[i].m, par[i].floor_k, par[i].threshold) == P.filter_params(k, l) and ks[i] == k
+
+
+def test_activation_threshold_equals_float_predicate(oracle):
+    g = load_json("g2b_activation.json")
+    for row in g["activation"]:
+        k = float.fromhex(row["k_hex"])
+        fk, t = P.activation_threshold(k)
+        assert fk == math.floor(k)
+        for i, want in zip(row["indices"], row["activated"]):
+            assert int(oracle.hash_index(i, row["seed"]) < t) == want
+    for k in (0.1, 0.5, 1.0, 2.0, 2.3, 2.9999999999999996, 12.999999999999998, 5e-17 + 3):
+        fk, t = P.activation_threshold(k)
+        frac = k - math.floor(k)
+        for h in (t - 1, t, t + 1, 0, (1 << 64) - 1):
+            if 0 <= h < (1 << 64):
+                assert (h / (2 ** 64 - 1) < frac) == (h < t), (k, h)
+        fk2, t2 = ctypes.c_uint32(), ctypes.c_uint64()
+        assert nat.lib().rbf_activation_threshold(k, ctypes.byref(fk2), ctypes.byref(t2)) == 0
+        assert (fk2.value, t2.value) == (fk, t)
+
+
+def test_argument_errors_without_gpu():
+    lib = nat.lib()
+    k, l = ctypes.c_double(), ctypes.c_uint64()
+    assert lib.rbf_optimal_params(0, 0, ctypes.byref(k), ctypes.byref(l)) == nat.RBF_EINVAL
+    assert b"n > 0" in lib.rbf_last_error()
+    assert lib.rbf_optimal_params(10, 11, ctypes.byref(k), ctypes.byref(l)) == nat.RBF_EINVAL
+    fk, t = ctypes.c_uint32(), ctypes.c_uint64()
+    assert lib.rbf_activation_threshold(float("nan"), ctypes.byref(fk), ctypes.byref(t)) == nat.RBF_ERANGE
+    assert lib.rbf_ctx_sync(None) == nat.RBF_EINVAL
+
+
+def test_keyframe_codec_matches_reference_bytes():
+    from new_bloom_filter_repo_amd.frame_codec import FixedVideoCompressor
+    z, meta = load_npz("g10_keyframes.npz"), load_json("g10_keyframes.json")
+    fx = FixedVideoCompressor(verbose=False)
+    frames = make_gop(meta["seed"], meta["W"], meta["H"], 3, p=0.2)
+    assert fx.compress_frame(frames[0]) == z["plain"].tobytes()
+    assert fx.compress_frame(fx.add_yuv_info_to_frame(frames[1])) == z["wrapped"].tobytes()
+    assert fx.compress_frame(frames[2][:, :, 0].copy()) == z["gray"].tobytes()
+    u16 = make_gop(10001, 24, 16, 1, dtype=np.uint16)[0]
+    assert fx.compress_frame(u16) == z["u16"].tobytes()
+    for blob, want in ((z["plain"], frames[0]), (z["wrapped"], frames[1]), (z["gray"], frames[2][:, :, 0]), (z["u16"], u16)):
+        got = fx.decompress_frame(blob.tobytes())
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
+def test_all_keyframe_container_is_reference_compatible():
+    from new_bloom_filter_repo_amd.video_compressor import ImprovedVideoCompressor
+    z, meta = load_npz("g10_keyframes.npz"), load_json("g10_keyframes.json")
+    frames = make_gop(meta["seed"], meta["W"], meta["H"], 3, p=0.2)
+    comp = ImprovedVideoCompressor(keyframe_interval=1, verbose=False)      # every frame a keyframe: no GPU involved
+    res = comp.compress_video([f.copy() for f in frames], None, input_color_space="YUV")
+    assert sorted(res) == meta["result_keys"]
+    for key, val in meta["stable"].items():
+        assert res[key] == val, key
+    assert comp._container(comp.last_compressed_frames) == z["container"].tobytes()
+    # and the reference-written container decodes
+    recs = comp._parse_container(z["container"].tobytes())
+    dec = comp.decompress_video(compressed_frames=recs)
+    assert all(np.array_equal(a, b) for a, b in zip(frames, dec))
+    with pytest.raises(ValueError):
+        comp.compress_video([], None)
+    with pytest.raises(ValueError):
+        comp._parse_container(b"XXXX\0\0\0\0")
+    with pytest.raises(ValueError):
+        comp.decompress_video()
+
+
+def test_verifiers_match_reference_dicts():
+    from new_bloom_filter_repo_amd.frame_codec import YUVFrame
+    from new_bloom_filter_repo_amd.verify import verify_bit_exact, verify_lossless
+    g = load_json("g8_verify.json")
+    frames = make_gop(g["seed"], g["W"], g["H"], g["nframes"], p=g["p"])
+    same = [f.copy() for f in frames]
+    off = [f.copy() for f in frames]
+    off[1][3, 4, 1] ^= 1
+    off[2][0, 0, 0] = (int(off[2][0, 0, 0]) + 7) % 256
+    off[2][5, 6, 2] = (int(off[2][5, 6, 2]) + 100) % 256
+    wrap = lambda fs: [YUVFrame(f) for f in fs]
+    for name, (a, b) in {"identical": (frames, same), "pixels_off": (frames, off), "count_mismatch": (frames, same[:2])}.items():
+        for aa, bb in ((a, b), (wrap(a), wrap(b))):          # plain ndarrays and wrappers give the same dicts
+            got = verify_lossless(aa, bb)
+            for key, val in g["results"][name]["verify_lossless"].items():
+                if val == "inf":
+                    assert got[key] == float("inf")
+                else:
+                    assert got[key] == val, (name, key)
+            gb = verify_bit_exact(aa, bb)
+            for key, val in g["results"][name]["verify_bit_exact"].items():
+                if key == "diff_details":
+                    assert [d.get("differences_found") for d in gb[key]] == [d.get("differences_found") for d in val]
+                else:
+                    assert gb[key] == val, (name, key)
+
+
+def test_synthetic_density_gives_kstar_2_3():
+    k, _ = P.optimal_params(10 ** 9, P_KSTAR_2_3)
+    assert abs(k - 2.3) < 1e-12

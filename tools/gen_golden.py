@@ -338,13 +338,38 @@ def g8():
     print("G8", {k: v["verify_lossless"].get("lossless") for k, v in res.items()})
 
 
+# ------------------------------------------------------------------ G10: keyframe records + container
+def g10():
+    fx = fvc.FixedVideoCompressor(verbose=False)
+    frames = make_gop(10000, 24, 16, 3, p=0.2)
+    plain = fx.compress_frame(frames[0])
+    wrapped = fx.compress_frame(fx.add_yuv_info_to_frame(frames[1]))
+    gray = fx.compress_frame(frames[2][:, :, 0].copy())
+    u16 = fx.compress_frame(make_gop(10001, 24, 16, 1, dtype=np.uint16)[0])
+    import tempfile
+    comp = ivc.ImprovedVideoCompressor(verbose=False)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "x.bfvc")
+        res = comp.compress_video([f.copy() for f in frames], path, input_color_space="YUV")
+        blob = open(path, "rb").read()
+        dec = comp.decompress_video(path)
+    np.savez_compressed(os.path.join(OUT, "g10_keyframes.npz"), plain=np.frombuffer(plain, dtype=np.uint8),
+                        wrapped=np.frombuffer(wrapped, dtype=np.uint8), gray=np.frombuffer(gray, dtype=np.uint8),
+                        u16=np.frombuffer(u16, dtype=np.uint8), container=np.frombuffer(blob, dtype=np.uint8))
+    keys = sorted(k for k in res if k not in ("compression_time", "frames_per_second", "output_path"))
+    json.dump({"seed": 10000, "W": 24, "H": 16, "result_keys": sorted(res), "stable": {k: res[k] for k in keys},
+               "decoded_equal": bool(all(np.array_equal(a, b) for a, b in zip(frames, dec)))},
+              open(os.path.join(OUT, "g10_keyframes.json"), "w"), indent=1)
+    print("G10 container bytes", len(blob), "keys", sorted(res))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true", help="skip the 2160p digest (about a minute of reference time)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     steps = {"g1": g1, "g2": g2, "g2b": g2b, "g3": g3, "g4": lambda: g4(a.skip_large), "g5": g5, "g6": g6,
-             "g7": g7_g9, "g8": g8}
+             "g7": g7_g9, "g8": g8, "g10": g10}
     for name, fn in steps.items():
         if a.only and name not in a.only.split(","):
             continue
