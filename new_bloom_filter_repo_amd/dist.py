@@ -1,0 +1,97 @@
+"""Multi-GPU sharding of the residual coder: one process per GPU, torch.distributed (RCCL = backend
+"nccl" on ROCm; "gloo" on CPU for tests).
+
+Frames are independent units on the encoder side (inter-frame t needs only ORIGINAL frames t-1 and
+t), so a video shards by contiguous frame ranges with one halo frame and there is no data-path
+collective: the only exchange is the gather of the variable-length per-frame records to rank 0,
+which writes the container.  RCCL has no gatherv, so lengths are all-gathered first and the padded
+payloads are gathered to the root (xGMI gives every peer its own link into rank 0).
+"""
+import struct
+
+import numpy as np
+
+
+def shard_range(nframes, world, rank):
+    """Contiguous [start, stop) of frame indices coded by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(nframes, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def halo_start(start, keyframe_interval):
+    """First frame a rank must READ: its first coded frame, or the one before when that frame is an
+    inter-frame (it is diffed against the original frame start-1)."""
+    return start if start == 0 or start % keyframe_interval == 0 else start - 1
+
+
+def pack_records(records):
+    """[(frame_index, type, bytes)] -> one uint8 array: count | (index, type, len, payload)*."""
+    parts = [struct.pack("<I", len(records))]
+    for t, ty, rec in records:
+        parts += [struct.pack("<IBI", t, ty, len(rec)), bytes(rec)]
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+
+
+def unpack_records(buf):
+    buf = bytes(buf)
+    (count,) = struct.unpack_from("<I", buf, 0)
+    off, out = 4, []
+    for _ in range(count):
+        t, ty, ln = struct.unpack_from("<IBI", buf, off)
+        off += 9
+        out.append((t, ty, buf[off:off + ln]))
+        off += ln
+    return out
+
+
+def gather_records(records, dst=0, group=None, device=None):
+    """Gather every rank's [(frame_index, type, bytes)] to `dst`; returns the merged list sorted by
+    frame index on dst, None elsewhere.  Works on any backend (tensors live on `device`)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    payload = torch.from_numpy(pack_records(records)).to(device)
+    length = torch.tensor([payload.numel()], dtype=torch.int64, device=device)
+    lengths = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(lengths, length, group=group)
+    maxlen = int(max(int(x.item()) for x in lengths))
+    padded = torch.zeros(maxlen, dtype=torch.uint8, device=device)
+    padded[:payload.numel()] = payload
+    slots = [torch.empty(maxlen, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, slots, dst=dst, group=group)
+    if rank != dst:
+        return None
+    merged = []
+    for r in range(world):
+        merged += unpack_records(slots[r][:int(lengths[r].item())].cpu().numpy().tobytes())
+    merged.sort(key=lambda x: x[0])
+    return merged
+
+
+def encode_video_sharded(frames, first_index, nframes_total, keyframe_interval=30, ctx=None, dst=0, group=None):
+    """Code this rank's shard and gather the container records on rank `dst`.
+
+    frames: the frames this rank READS, i.e. global indices [halo_start(start), stop) where
+    (start, stop) = shard_range(nframes_total, world, rank); first_index = halo_start(start).
+    Returns the container bytes on dst (ImprovedVideoCompressor._container), None elsewhere."""
+    import torch.distributed as dist
+    from .video_compressor import ImprovedVideoCompressor, KEY, INTER
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    start, stop = shard_range(nframes_total, world, rank)
+    comp = ImprovedVideoCompressor(keyframe_interval=keyframe_interval, ctx=ctx)
+    records = []
+    for t in range(start, stop):
+        cur = frames[t - first_index]
+        rec = None
+        if t % keyframe_interval != 0:
+            rec = comp._encode_inter(frames[t - 1 - first_index], cur)
+        records.append((t, INTER, rec) if rec is not None else (t, KEY, comp.compressor.compress_frame(cur)))
+    merged = gather_records(records, dst=dst, group=group)
+    if merged is None:
+        return None
+    assert [t for t, _, _ in merged] == list(range(nframes_total)), "missing frames in the gather"
+    return ImprovedVideoCompressor._container([(ty, rec) for _, ty, rec in merged])

@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the N>1 path -- frame sharding with halo and the variable-length
+record gather to rank 0 (the same code runs over RCCL with backend "nccl")."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from new_bloom_filter_repo_amd import dist as D
+
+
+def test_shard_ranges_cover_everything():
+    for n in (1, 2, 29, 30, 300, 301):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [D.shard_range(n, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            assert max(b - a for a, b in ranges) - min(b - a for a, b in ranges) <= 1
+    assert D.halo_start(0, 30) == 0 and D.halo_start(30, 30) == 30 and D.halo_start(38, 30) == 37
+
+
+def test_record_packing_round_trip():
+    recs = [(5, 1, b""), (6, 2, b"\x00\x01\x02"), (7, 2, bytes(range(256)) * 3)]
+    assert D.unpack_records(D.pack_records(recs)) == recs
+    assert D.unpack_records(D.pack_records([])) == []
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from new_bloom_filter_repo_amd import dist as DD
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 11
+        start, stop = DD.shard_range(n, world, rank)
+        rng = np.random.default_rng(100 + rank)
+        recs = [(t, 1 + (t % 2), bytes(rng.integers(0, 256, 50 + 37 * t, dtype=np.uint8))) for t in range(start, stop)]
+        merged = DD.gather_records(recs, dst=0)
+        if rank == 0:
+            q.put([(t, ty, len(b), b[:4]) for t, ty, b in merged])
+        else:
+            assert merged is None
+            q.put([(t, ty, len(b), b[:4]) for t, ty, b in recs])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_records_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    merged = max(outs, key=len)
+    other = min(outs, key=len)
+    assert [t for t, *_ in merged] == list(range(11))
+    assert all(ln == 50 + 37 * t for t, _, ln, _ in merged)
+    for item in other:                      # rank 1's own records arrived intact on rank 0
+        assert item in merged
