@@ -43,7 +43,6 @@ struct rbf_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     // scratch (grown on demand, never shrunk)
-    uint32_t *seg_bits = nullptr;    size_t seg_bits_cap = 0; // bytes
     uint32_t *seg_cnt = nullptr;     size_t seg_cnt_cap = 0;
     uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
     uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
@@ -166,7 +165,6 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->ones_pinned) (void)hipHostFree(ctx->ones_pinned);
-    if (ctx->seg_bits) (void)hipFree(ctx->seg_bits);
     if (ctx->seg_cnt) (void)hipFree(ctx->seg_cnt);
     if (ctx->seg_off) (void)hipFree(ctx->seg_off);
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
@@ -368,7 +366,7 @@ struct Plan {
     bool fast_insert, fast_query, double_buffer, small_m;
     uint32_t fwords_max, fwords_even, S;
     size_t insert_lds_bytes, query_lds_bytes;
-    uint64_t nseg; uint32_t seg_words;
+    uint64_t nseg; uint32_t words_per_seg;
 };
 
 static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n)
@@ -384,9 +382,9 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     p.fwords_max = (uint32_t)(((uint64_t)mmax + 31) / 32);
     p.fwords_even = (p.fwords_max + 1u) & ~1u;
     p.insert_lds_bytes = (size_t)p.fwords_even * 4 + (size_t)IL_WAVES * IL_QUEUE * 4;
-    const size_t bufbytes = (size_t)((p.fwords_max + 3u) & ~3u) * 4, stagebytes = (size_t)QL_WAVES * QL_SEG_WORDS * 4;
-    p.double_buffer = 2 * bufbytes + stagebytes <= LDS_LIMIT && !ctx->single_buffer;
-    p.query_lds_bytes = (p.double_buffer ? 2 : 1) * bufbytes + stagebytes;
+    const size_t bufbytes = (size_t)((p.fwords_max + 3u) & ~3u) * 4;
+    p.double_buffer = 2 * bufbytes <= LDS_LIMIT && !ctx->single_buffer;
+    p.query_lds_bytes = (p.double_buffer ? 2 : 1) * bufbytes;
     p.fast_insert = !ctx->force_generic && mmax > 0 && p.insert_lds_bytes <= LDS_LIMIT;
     p.fast_query = !ctx->force_generic && mmax > 0 && p.query_lds_bytes <= LDS_LIMIT;
     // slices per frame so that S * frames ~ one workgroup per CU (256 CUs), at most 32
@@ -395,7 +393,7 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     if (S > 32) S = 32;
     p.S = S;
     p.nseg = p.fast_query ? (n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS : nseg_of(n);
-    p.seg_words = p.fast_query ? (uint32_t)QL_SEG_WORDS : (uint32_t)SEG_WORDS;
+    p.words_per_seg = p.fast_query ? (uint32_t)QL_P : (uint32_t)SEG_ITERS;
     return p;
 }
 
@@ -480,6 +478,28 @@ static int check_filter_strides(const rbf_filter_params *params, uint32_t nframe
     return RBF_OK;
 }
 
+// query launch shared by encode and decode
+static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nframes, const FrameTable &tab, const Seeds &sd,
+                        const void *filters_dev, uint64_t filter_stride_bytes)
+{
+    if (pl.fast_query) {
+        auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<true, true> : k_query_lds<true, false>)
+                                     : (pl.small_m ? k_query_lds<false, true> : k_query_lds<false, false>);
+        if (int r = allow_big_lds((const void *)kern)) return r;
+        const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
+                           n, nframes, tab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+                           ctx->seg_cnt, pl.nseg, ctx->pass_words);
+    } else {
+        const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(k_query, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           n, tab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, ctx->seg_cnt, pl.nseg, ctx->pass_words);
+    }
+    return RBF_OK;
+}
+
 // one chunk of at most MAX_BATCH frames (the geometry table rides in the kernel arguments)
 static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
                         uint64_t n, uint32_t nframes, const rbf_filter_params *params,
@@ -491,7 +511,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     const Plan pl = make_plan(ctx, params, nframes, n);
     FrameTable tab;
     if (int r = fill_table(params, nframes, &tab)) return r;
-    if (int r = grow((void **)&ctx->seg_bits, &ctx->seg_bits_cap, (size_t)nframes * pl.nseg * pl.seg_words * 4)) return r;
+    if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * pl.words_per_seg * 8)) return r;
     if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
@@ -538,40 +558,23 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
                                (const uint32_t *)filters_dev, words, 1u, tab, (uint32_t *)filters_dev, words, stats_dev);
         }
     }
-    // ---- query + witness staging
-    if (pl.fast_query) {
-        auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<true, true, true> : k_query_lds<true, true, false>)
-                                     : (pl.small_m ? k_query_lds<true, false, true> : k_query_lds<true, false, false>);
-        if (int r = allow_big_lds((const void *)kern)) return r;
-        const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
-        LaunchTimer t(ctx, RBF_K_QUERY);
-        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, nframes, tab, sd,
-                           (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
-                           ctx->seg_bits, ctx->seg_cnt, pl.nseg, (uint64_t *)nullptr);
-    } else {
-        const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
-        LaunchTimer t(ctx, RBF_K_QUERY);
-        hipLaunchKernelGGL(k_query<true>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           (const uint32_t *)masks_dev, mask_stride_bytes / 4, n, tab, sd,
-                           (const uint32_t *)filters_dev, filter_stride_bytes / 4,
-                           ctx->seg_bits, ctx->seg_cnt, pl.nseg, (uint64_t *)nullptr);
-    }
-    // ---- stitch
+    // ---- query: pass word of every 64 positions + per-segment pass counts
+    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes)) return r;
+    // ---- witness: scan the counts, then pext(mask, pass) of every word lands at its bit offset
     {
         LaunchTimer t(ctx, RBF_K_SCAN);
         hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, pl.nseg,
                            stats_dev, (uint32_t)RBF_STATS_PER_FRAME);
     }
     {
-        const uint64_t pieces = pl.nseg * pl.seg_words;
-        uint64_t bx = (pieces + WG_THREADS * 4 - 1) / (WG_THREADS * 4);
+        const uint64_t words = pl.nseg * pl.words_per_seg;
+        uint64_t bx = (words + WG_THREADS - 1) / WG_THREADS;
         if (bx < 1) bx = 1;
         if (bx > 4096) bx = 4096;
         LaunchTimer t(ctx, RBF_K_STITCH);
-        hipLaunchKernelGGL(k_stitch_pieces, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           ctx->seg_bits, ctx->seg_cnt, ctx->seg_off, pl.nseg, pl.seg_words == 16 ? 4u : 5u,
-                           (uint32_t *)witnesses_dev, witness_stride_bytes / 4);
+        hipLaunchKernelGGL(k_compact_witness, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           ctx->pass_words, ctx->seg_off, pl.nseg, pl.words_per_seg,
+                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4);
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;
@@ -683,31 +686,14 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
                         void *masks_dev, uint64_t mask_stride_bytes)
 {
     const Plan pl = make_plan(ctx, params, nframes, n);
-    const uint32_t wps = pl.fast_query ? (uint32_t)QL_P : (uint32_t)SEG_ITERS;      // pass words per segment
+    const uint32_t wps = pl.words_per_seg;                                            // pass words per segment
     FrameTable tab;
     if (int r = fill_table(params, nframes, &tab)) return r;
     if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * wps * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
-    if (pl.fast_query) {
-        auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<false, true, true> : k_query_lds<false, true, false>)
-                                     : (pl.small_m ? k_query_lds<false, false, true> : k_query_lds<false, false, false>);
-        if (int r = allow_big_lds((const void *)kern)) return r;
-        const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
-        LaunchTimer t(ctx, RBF_K_QUERY);
-        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                           (const uint64_t *)nullptr, (uint64_t)0, n, nframes, tab, sd,
-                           (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
-                           (uint32_t *)nullptr, ctx->seg_cnt, pl.nseg, ctx->pass_words);
-    } else {
-        const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
-        LaunchTimer t(ctx, RBF_K_QUERY);
-        hipLaunchKernelGGL(k_query<false>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           (const uint32_t *)nullptr, (uint64_t)0, n, tab, sd,
-                           (const uint32_t *)filters_dev, filter_stride_bytes / 4,
-                           (uint32_t *)nullptr, ctx->seg_cnt, pl.nseg, ctx->pass_words);
-    }
+    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes)) return r;
     {
         LaunchTimer t(ctx, RBF_K_SCAN);
         hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, pl.nseg,

@@ -1,11 +1,11 @@
 // rbf_kernels.h -- gfx950 kernels of the rational-Bloom residual coder (generic path).
 //
 // Work decomposition: a SEGMENT is 1024 consecutive pixels (16 wave-iterations of 64); a wave
-// owns one segment, so every per-segment quantity (pass count, compacted witness bits) is
-// produced without inter-wave communication.  blockIdx.y is the frame of the batch.
+// owns one segment, so the per-segment pass count is produced without inter-wave communication.
+// blockIdx.y is the frame of the batch.
 //
-// Bit vectors at rest are MSB-first per byte (see rbf_device.h); the per-segment staging
-// streams that only kernels see are natural order.
+// Bit vectors at rest are MSB-first per byte (see rbf_device.h); the 64-bit pass words that only
+// kernels see are natural order (bit l = lane l).
 #pragma once
 #include "rbf_device.h"
 
@@ -13,7 +13,6 @@ namespace rbf {
 
 constexpr int SEG_PIXELS = 1024;                 // pixels per segment (one wave)
 constexpr int SEG_ITERS = SEG_PIXELS / WAVE;     // 16
-constexpr int SEG_WORDS = SEG_PIXELS / 32;       // 32 staging dwords per segment
 constexpr int WG_THREADS = 256;
 constexpr int WG_WAVES = WG_THREADS / WAVE;      // 4
 
@@ -130,73 +129,47 @@ __global__ __launch_bounds__(WG_THREADS) void k_insert(
 }
 
 // ------------------------------------------------------------------------------------------
-// A5 / A6  query: test every position in order (check_index, :116-138)
+// A5 / A6  query: test every position in order (check_index, :116-138) -- generic path, filter
+// probed in global memory.  One wave per segment of 1024 pixels:
+//   pass_words[(f*nseg + seg)*16 + it]  64-bit pass word of wave-iteration it
+//   seg_cnt[f*nseg + seg]               passing positions of the segment
+// k_compact_witness (encode) / k_expand_mask_p (decode) consume them.
 // ------------------------------------------------------------------------------------------
-// ENCODE: the mask bits of passing positions are compacted, per segment, into a natural-order
-//         staging stream (seg_bits) + a pass count (seg_cnt); k_stitch_witness concatenates.
-// DECODE: the 64-bit pass word of every wave-iteration is stored (pass_words) + seg_cnt;
-//         k_expand_mask turns witness bits back into mask bits.
-template <bool ENCODE>
 __global__ __launch_bounds__(WG_THREADS) void k_query(
-    const uint32_t *__restrict__ masks, uint64_t mask_stride_words32, uint64_t n,
-    const FrameTable tab, Seeds seeds,
+    uint64_t n, const FrameTable tab, Seeds seeds,
     const uint32_t *__restrict__ filters, uint64_t filter_stride_words32,
-    uint32_t *__restrict__ seg_bits, uint32_t *__restrict__ seg_cnt, uint64_t nseg,
-    uint64_t *__restrict__ pass_words)
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words)
 {
-    __shared__ uint32_t wbuf[WG_WAVES][SEG_WORDS];
     const uint32_t f = blockIdx.y;
     const FrameDev fd = tab.f[f];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
-    const bool live = seg < nseg;
+    if (seg >= nseg) return;
+    uint64_t *pw_out = pass_words + ((uint64_t)f * nseg + seg) * SEG_ITERS;
     if (fd.m == 0) {                                        // passthrough frame: nothing passes
-        if (live && lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = 0;
-        if (!ENCODE && live && lane < SEG_ITERS) pass_words[(uint64_t)f * (nseg * SEG_ITERS) + seg * SEG_ITERS + lane] = 0;
+        if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = 0;
+        if (lane < SEG_ITERS) pw_out[lane] = 0;
         return;
     }
-    const uint32_t *mask = ENCODE ? masks + (uint64_t)f * mask_stride_words32 : nullptr;
     const uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
-    if (ENCODE && lane < SEG_WORDS) wbuf[wave][lane] = 0;
-    __syncthreads();
-
     uint32_t woff = 0;
-    if (live) {
-        const uint64_t base = seg * SEG_PIXELS;
-        for (int it = 0; it < SEG_ITERS; ++it) {
-            const uint64_t i64 = base + (uint64_t)it * WAVE + lane;
-            const bool valid = i64 < n;
-            const uint32_t i = (uint32_t)i64;
-            bool pass = valid;
-            if (valid) {
-                Probe p = make_probe(i, fd, seeds);
-                for (uint32_t j = 0; j < fd.floor_k; ++j) {
-                    pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
-                    advance(p, fd.m);
-                }
-                if (p.extra) pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
+    const uint64_t base = seg * SEG_PIXELS;
+    for (int it = 0; it < SEG_ITERS; ++it) {
+        const uint64_t i64 = base + (uint64_t)it * WAVE + lane;
+        bool pass = i64 < n;
+        if (pass) {
+            Probe p = make_probe((uint32_t)i64, fd, seeds);
+            for (uint32_t j = 0; j < fd.floor_k; ++j) {
+                pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
+                advance(p, fd.m);
             }
-            const uint64_t pw = __ballot(pass);
-            if (ENCODE) {
-                if (pass) {
-                    const uint32_t mb = (mask[i >> 5] >> msb_pos(i)) & 1u;
-                    if (mb) {
-                        const uint32_t dst = woff + rank_below(pw);
-                        atomicOr(&wbuf[wave][dst >> 5], 1u << (dst & 31u));
-                    }
-                }
-            } else {
-                if (lane == 0) pass_words[(uint64_t)f * (nseg * SEG_ITERS) + seg * SEG_ITERS + it] = pw;
-            }
-            woff += __popcll(pw);
+            if (p.extra) pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
         }
+        const uint64_t pw = __ballot(pass);
+        if (lane == 0) pw_out[it] = pw;
+        woff += __popcll(pw);
     }
-    __syncthreads();
-    if (live) {
-        if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = woff;
-        if (ENCODE && lane < SEG_WORDS)
-            seg_bits[((uint64_t)f * nseg + seg) * SEG_WORDS + lane] = wbuf[wave][lane];
-    }
+    if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = woff;
 }
 
 // Block-wide exclusive scan helper (blockDim.x == 1024): returns exclusive prefix, *total = sum.
@@ -244,39 +217,6 @@ __global__ __launch_bounds__(1024) void k_scan_segments(
         carry += tot;
     }
     if (totals && threadIdx.x == 0) totals[(uint64_t)f * totals_stride] = carry;
-}
-
-// ------------------------------------------------------------------------------------------
-// A6  expand: out[i] = witness[rank(i)] where position i passes, else 0   (:299-304)
-// One wave per segment; lane = pixel within each of the 16 pass words.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS) void k_expand_mask(
-    const uint64_t *__restrict__ pass_words, const uint64_t *__restrict__ seg_off, uint64_t nseg,
-    const uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32,
-    uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n)
-{
-    const uint32_t f = blockIdx.y;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
-    if (seg >= nseg) return;
-    const uint64_t *pw = pass_words + (uint64_t)f * nseg * SEG_ITERS + seg * SEG_ITERS;
-    const uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
-    uint64_t *mask = masks + (uint64_t)f * mask_stride_words64;
-    uint64_t o = seg_off[(uint64_t)f * nseg + seg];
-    const uint64_t nwords = (n + 63) >> 6;
-    for (int it = 0; it < SEG_ITERS; ++it) {
-        const uint64_t w = seg * SEG_ITERS + it;
-        if (w >= nwords) break;
-        const uint64_t p = pw[it];
-        bool bit = false;
-        if ((p >> lane) & 1ull) {
-            const uint64_t src = o + rank_below(p);
-            bit = (wit[src >> 5] >> msb_pos((uint32_t)src)) & 1u;
-        }
-        const uint64_t word = __ballot(bit);
-        if (lane == 0) mask[w] = flip_bytes64(word);
-        o += __popcll(p);
-    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -23,7 +23,6 @@ constexpr int QL_THREADS = 1024;                   // 16 waves, one workgroup pe
 constexpr int QL_WAVES = QL_THREADS / WAVE;
 constexpr int QL_P = 8;                            // pixels per lane
 constexpr int QL_SEG_PIXELS = QL_P * WAVE;         // 512
-constexpr int QL_SEG_WORDS = QL_SEG_PIXELS / 32;   // 16 staging dwords per (segment, frame)
 
 constexpr int IL_THREADS = 1024;                   // insert: one workgroup per CU
 constexpr int IL_WAVES = IL_THREADS / WAVE;
@@ -196,92 +195,86 @@ __device__ __forceinline__ void dma_filter(uint32_t *lds_dst, const uint32_t *sr
     if (wave == 0 && lane < tail) dma4(src + (npieces << 2) + lane, __builtin_amdgcn_readfirstlane(base + (npieces << 4)));
 }
 
-// h mod m for 2 <= m <= 2^30 with three 32x32 multiplies for the quotient estimate:
+// h mod m for 2 <= m <= 2^30 (m2 = 2m), three 32x32 multiplies for the quotient estimate:
 // q' = hh*Mh + hi32(hh*Ml) + hi32(hl*Mh) >= floor(h*M/2^64) - 2 >= floor(h/m) - 3, so
-// r' = h - q'*m < 4m <= 2^32 and everything can be carried modulo 2^32.
-__device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t Mh, uint32_t Ml)
+// r' = h - q'*m < 4m <= 2^32 and everything is carried modulo 2^32; two conditional subtracts
+// (2m, then m) finish the reduction.
+__device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t m2, uint32_t Mh, uint32_t Ml)
 {
     const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
     const uint32_t q = hh * Mh + __umulhi(hh, Ml) + __umulhi(hl, Mh);
     uint32_t r = hl - q * m;
-    r = min(r, r - m);
-    r = min(r, r - m);
+    r = min(r, r - m2);
     r = min(r, r - m);
     return r;
 }
 
-// One frame's pass over a wave's QL_P x 64 pixels: reductions mod m, LDS probes, ballot, witness
-// compaction.  FK >= 0: floor(k*) known at compile time (fully unrolled probes); FK < 0: runtime fk.
+// v_writelane_b32: put a wave-uniform value into ONE lane of a VGPR (no builtin in this hipcc).
+__device__ __forceinline__ void write_lane(uint32_t &dst, uint32_t uniform_value, int lane_index)
+{
+    // s_nop 4: the ballot is a VALU-written SGPR; hipcc pads no hazards inside asm (without the wait
+    // states v_writelane reads the previous value -- caught by the parity tests)
+    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(uniform_value), "n"(lane_index));
+}
+
+// One frame's pass over a wave's QL_P x 64 pixels: reductions mod m, LDS probes, ballot.
+// FK >= 0: floor(k*) known at compile time (fully unrolled probes); FK < 0: runtime fk.
+// Lane `it` (it < QL_P) ends up holding the 64-bit pass word of wave-iteration `it`; returns the
+// number of passing positions.  Branch-free for FK >= 0 so the QL_P dependency chains interleave.
 // AB (ablation mask, tools/bench_query.hip only; 0 in the library): 1 = no reductions, 2 = no LDS
-// probes, 4 = no compaction, 8 = no filter staging, 16 = no hashing.
-template <bool ENCODE, bool SMALL_M, int FK, int AB = 0>
-__device__ __forceinline__ void frame_pass(
+// probes, 4 = no ballot, 8 = no filter staging, 16 = no hashing, 32 = no barrier, 64 = no output.
+template <bool SMALL_M, int FK, int AB = 0>
+__device__ __forceinline__ uint32_t frame_pass(
     const uint64_t (&h1)[QL_P], const uint64_t (&h2)[QL_P], const uint64_t (&ha)[QL_P], uint32_t validmask,
-    const uint32_t *filt, uint32_t m, uint64_t M, uint64_t T, uint32_t fk_rt,
-    uint32_t mw_lo, uint32_t mw_hi, uint32_t lane, uint32_t *stg, uint32_t &woff, uint64_t &mypw)
+    const uint32_t *filt, uint32_t m, uint64_t M, uint64_t T, uint32_t fk_rt, uint32_t &pw_lo, uint32_t &pw_hi)
 {
     const uint32_t Mh = (uint32_t)(M >> 32), Ml = (uint32_t)M;
     const uint32_t fk = FK >= 0 ? (uint32_t)FK : fk_rt;
-    // Phase 1 -- branch-free for FK >= 0, so the scheduler can interleave the QL_P independent
-    // dependency chains (reductions -> LDS probes -> ballot) instead of running them one by one.
-    uint64_t pw[QL_P];
+    const uint32_t m2 = m << 1;
+    uint32_t npass = 0;
 #pragma unroll
     for (int it = 0; it < QL_P; ++it) {
         uint32_t pos, step;
         if (AB & 1) { pos = (uint32_t)h1[it] & 0x7FFFFu; step = (uint32_t)h2[it] & 0x3FFFFu; }
-        else if (SMALL_M) { pos = mod_m_small(h1[it], m, Mh, Ml); step = mod_m_small(h2[it], m, Mh, Ml); }
+        else if (SMALL_M) { pos = mod_m_small(h1[it], m, m2, Mh, Ml); step = mod_m_small(h2[it], m, m2, Mh, Ml); }
         else         { pos = mod_m(h1[it], m, M);            step = mod_m(h2[it], m, M); }
-        const bool extra = ha[it] < T;
-        uint32_t ok = (validmask >> it) & 1u;
+        // Each probe shifts its word LEFT so that the probed bit lands in bit 31: the verdict is the
+        // sign bit of the AND of all probes.  MSB-first bit (pos & 31) ^ 7 -> shift (pos ^ 24) & 31.
+        uint32_t acc = (validmask >> it) << 31;
 #pragma unroll
         for (uint32_t j = 0; j < fk; ++j) {
-            ok &= ((AB & 2) ? (pos * 0x9E3779B1u) : filt[pos >> 5]) >> msb_pos(pos);
+            acc &= ((AB & 2) ? (pos * 0x9E3779B1u) : filt[pos >> 5]) << ((pos ^ 24u) & 31u);
             if (SMALL_M) { const uint32_t s2 = pos + step; pos = min(s2, s2 - m); }
             else { const uint64_t s2 = (uint64_t)pos + step; pos = (uint32_t)(s2 >= m ? s2 - m : s2); }
         }
-        const uint32_t x = ((AB & 2) ? (pos * 0x85EBCA77u) : filt[pos >> 5]) >> msb_pos(pos);
-        ok &= extra ? x : 1u;
-        pw[it] = __ballot((ok & 1u) != 0);
+        const uint32_t x = ((AB & 2) ? (pos * 0x85EBCA77u) : filt[pos >> 5]) << ((pos ^ 24u) & 31u);
+        acc &= (ha[it] < T) ? x : 0x80000000u;
+        if (AB & 4) { npass += acc >> 31; continue; }
+        const uint64_t pw = __ballot((int32_t)acc < 0);
+        write_lane(pw_lo, (uint32_t)pw, it);                   // lane `it` keeps this iteration's pass word
+        write_lane(pw_hi, (uint32_t)(pw >> 32), it);
+        npass += __popcll(pw);
     }
-    // Phase 2 -- order-preserving compaction of the mask bits of the passing positions.
-#pragma unroll
-    for (int it = 0; it < QL_P; ++it) {
-        if (AB & 4) { woff += (uint32_t)pw[it] & 1u; continue; }
-        if (ENCODE) {
-            const uint32_t w_hi = __builtin_amdgcn_readlane(mw_hi, it), w_lo = __builtin_amdgcn_readlane(mw_lo, it);
-            const uint64_t w = ((uint64_t)w_hi << 32) | w_lo;
-            const uint64_t tp = pw[it] & w;                    // passes whose mask bit is 1 (wave-uniform)
-            if ((tp >> lane) & 1ull) {
-                const uint32_t dst = woff + rank_below(pw[it]);
-                atomicOr(&stg[dst >> 5], 1u << (dst & 31u));
-            }
-        } else {
-            if (lane == (uint32_t)it) mypw = pw[it];
-        }
-        woff += __popcll(pw[it]);
-    }
+    return npass;
 }
 
+// Query, frames-inner (A5 for encode, A6 for decode: both need the pass word of every 64 pixels).
+//   pass_words[(f*nseg + seg)*QL_P + it]  bit l = position (seg*QL_P + it)*64 + l passes filter f
+//   seg_cnt[f*nseg + seg]                  passing positions of the segment (= witness bits it owns)
 // SMALL_M: every filter of the batch has 2 <= m <= 2^30 (host-checked) -> cheap reductions.
-template <bool ENCODE, bool DOUBLE_BUFFER, bool SMALL_M, int AB = 0>
+template <bool DOUBLE_BUFFER, bool SMALL_M, int AB = 0>
 __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
-    const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n, uint32_t nframes,
-    const FrameTable tab, Seeds seeds,
+    uint64_t n, uint32_t nframes, const FrameTable tab, Seeds seeds,
     const uint32_t *__restrict__ filters, uint64_t filter_stride_words32, uint32_t fwords_max,
-    uint32_t *__restrict__ seg_bits, uint32_t *__restrict__ seg_cnt, uint64_t nseg,
-    uint64_t *__restrict__ pass_words)
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t bufwords = (fwords_max + 3u) & ~3u;            // 16-byte multiple
-    uint32_t *stage = lds + (DOUBLE_BUFFER ? 2u : 1u) * bufwords; // [QL_WAVES][QL_SEG_WORDS]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t nwaves = blockDim.x >> 6;                      // 16 (one workgroup per CU) or 8 (two per CU)
+    const uint32_t nwaves = blockDim.x >> 6;
     const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
     const bool live = seg < nseg;
     const uint64_t base = seg * QL_SEG_PIXELS;
-    const uint64_t nwords64 = (n + 63) >> 6;
-    uint32_t *stg = stage + wave * QL_SEG_WORDS;
-    if (ENCODE && lane < QL_SEG_WORDS) stg[lane] = 0;
 
     // ---- frame-independent part: the three hashes of my P pixel indices ------------------
     uint64_t h1[QL_P], h2[QL_P], ha[QL_P];
@@ -307,122 +300,134 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     for (uint32_t g = nframes; g-- > 0;) {
         if (tab.f[g].m == 0) {
             if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
-            if (!ENCODE && live && lane < QL_P) pass_words[((uint64_t)g * nseg + seg) * QL_P + lane] = 0;
+            if (live && lane < QL_P) pass_words[((uint64_t)g * nseg + seg) * QL_P + lane] = 0;
         } else {
             f = g;                                                // ends as the FIRST active frame
         }
     }
-    auto load_mw = [&](uint32_t g) -> uint64_t {
-        uint64_t v = 0;
-        if (ENCODE && live && lane < QL_P) {
-            const uint64_t w = seg * QL_P + lane;
-            if (w < nwords64) v = masks[(uint64_t)g * mask_stride_words64 + w];
-        }
-        return v;
-    };
     uint32_t cur = 0;
-    uint64_t mw_next = 0;
-    if (DOUBLE_BUFFER && f < nframes) {
-        mw_next = load_mw(f);
-        if (!(AB & 8)) dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (tab.f[f].m + 31u) >> 5, wave, lane, nwaves);
-    }
+    if (DOUBLE_BUFFER && f < nframes && !(AB & 8))
+        dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (tab.f[f].m + 31u) >> 5, wave, lane, nwaves);
     while (f < nframes) {
         f = __builtin_amdgcn_readfirstlane(f);                    // frame indices are wave-uniform: scalar table loads
         uint32_t fn = f + 1;
         while (fn < nframes && tab.f[fn].m == 0) ++fn;               // next active frame
         fn = __builtin_amdgcn_readfirstlane(fn);
         const FrameDev fd = tab.f[f];
-        uint64_t mw;
         const uint32_t *filt;
         if (DOUBLE_BUFFER) {
             if (!(AB & 32)) {
-            dma_wait_all();           // my share of DMA(f) has landed ...
-            __syncthreads();          // ... and everyone's; buffer cur^1 is free again
+                dma_wait_all();       // my share of DMA(f) has landed ...
+                __syncthreads();      // ... and everyone's; buffer cur^1 is free again
             }
-            mw = mw_next;
             filt = lds + cur * bufwords;
-            if (fn < nframes) {
-                mw_next = load_mw(fn);
-                if (!(AB & 8)) dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
-                                          (tab.f[fn].m + 31u) >> 5, wave, lane, nwaves);
-            }
+            if (fn < nframes && !(AB & 8))
+                dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
+                           (tab.f[fn].m + 31u) >> 5, wave, lane, nwaves);
             cur ^= 1u;
         } else {
             __syncthreads();          // previous frame's probes are done
-            mw = load_mw(f);
             if (!(AB & 8)) dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (fd.m + 31u) >> 5, wave, lane, nwaves);
             dma_wait_all();
             __syncthreads();
             filt = lds;
         }
-        mw = flip_bytes64(mw);                                     // natural order
         // frame geometry is wave-uniform: keep it in SGPRs so every branch below is scalar
+        // (the builtin returns int: go through uint32_t or the low half sign-extends)
         const uint32_t m = __builtin_amdgcn_readfirstlane(fd.m);
         const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
         const uint32_t Mh = __builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32));
         const uint32_t Ml = __builtin_amdgcn_readfirstlane((uint32_t)fd.M);
-        // (the builtin returns int: go through uint32_t or the low half sign-extends)
         const uint32_t Thi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.T >> 32));
         const uint32_t Tlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.T);
         const uint64_t T = ((uint64_t)Thi << 32) | Tlo;
         const uint64_t M = ((uint64_t)Mh << 32) | Ml;
-        const uint32_t mw_lo = (uint32_t)mw, mw_hi = (uint32_t)(mw >> 32);
 
-        uint32_t woff = 0;
-        uint64_t mypw = 0;
+        uint32_t pw_lo = 0, pw_hi = 0, npass;
         // floor(k*) is a small integer: straight-line code for the common values lets the compiler
         // issue every LDS probe of all QL_P pixels back to back instead of one round trip at a time.
         switch (fk) {
-        case 1: frame_pass<ENCODE, SMALL_M, 1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
-        case 2: frame_pass<ENCODE, SMALL_M, 2, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
-        case 3: frame_pass<ENCODE, SMALL_M, 3, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
-        case 4: frame_pass<ENCODE, SMALL_M, 4, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
-        default: frame_pass<ENCODE, SMALL_M, -1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, mw_lo, mw_hi, lane, stg, woff, mypw); break;
+        case 1: npass = frame_pass<SMALL_M, 1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
+        case 2: npass = frame_pass<SMALL_M, 2, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
+        case 3: npass = frame_pass<SMALL_M, 3, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
+        case 4: npass = frame_pass<SMALL_M, 4, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
+        default: npass = frame_pass<SMALL_M, -1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
         }
-        if (AB & 64) { f = fn; continue; }
-        if (ENCODE) {
-            wave_lds_fence();
-            if (lane < QL_SEG_WORDS) {
-                if (live) seg_bits[((uint64_t)f * nseg + seg) * QL_SEG_WORDS + lane] = stg[lane];
-                stg[lane] = 0;
-            }
-            wave_lds_fence();
-        } else if (live && lane < QL_P) {
-            pass_words[((uint64_t)f * nseg + seg) * QL_P + lane] = mypw;
+        if (!(AB & 64) && live) {
+            if (lane < QL_P) pass_words[((uint64_t)f * nseg + seg) * QL_P + lane] = ((uint64_t)pw_hi << 32) | pw_lo;
+            if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
         }
-        if (live && lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = woff;
         f = fn;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// stitch, wide version: seg_off comes from k_scan_segments; every staging dword of every
-// segment is shifted to its final bit offset and OR-ed into the pre-zeroed packed witness.
+// witness compaction (A5): witness = mask bits at the passing positions, in position order.
+// One lane per 64-pixel word: its bits are pext(mask word, pass word) placed at
+// seg_off[segment] + (passes of the segment's earlier words) in the pre-zeroed packed witness.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS) void k_stitch_pieces(
-    const uint32_t *__restrict__ seg_bits, const uint32_t *__restrict__ seg_cnt,
-    const uint64_t *__restrict__ seg_off, uint64_t nseg, uint32_t seg_words_log2,
+__global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
+    const uint64_t *__restrict__ pass_words, const uint64_t *__restrict__ seg_off, uint64_t nseg, uint32_t words_per_seg,
+    const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n,
     uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32)
 {
+    // A workgroup owns WG_THREADS consecutive words (= whole segments): their witness bits form one
+    // contiguous bit range, assembled in LDS with LDS atomics and written out with plain coalesced
+    // stores; only the first and last dword of the range are shared with the neighbours (atomicOr).
+    __shared__ uint32_t buf[WG_THREADS * 2 + 2];
     const uint32_t f = blockIdx.y;
-    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
-    const uint64_t *off = seg_off + (uint64_t)f * nseg;
-    const uint32_t *bits = seg_bits + (((uint64_t)f * nseg) << seg_words_log2);
+    const uint64_t nwords = (n + 63) >> 6;
+    const uint64_t total = nseg * words_per_seg;
+    const uint64_t *pwf = pass_words + (uint64_t)f * total;
     uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
-    const uint64_t pieces = nseg << seg_words_log2;
-    for (uint64_t idx = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x; idx < pieces; idx += (uint64_t)gridDim.x * WG_THREADS) {
-        const uint64_t s = idx >> seg_words_log2;
-        const uint32_t d = (uint32_t)(idx & ((1u << seg_words_log2) - 1u));
-        if (32u * d >= cnt[s]) continue;
-        const uint32_t v = bits[idx];
-        if (!v) continue;
-        const uint64_t o = off[s] + 32u * d;
-        const uint32_t sh = (uint32_t)(o & 31u);
-        atomicOr(&wit[o >> 5], flip_bytes32(v << sh));
-        if (sh) {
-            const uint32_t hi = v >> (32u - sh);
-            if (hi) atomicOr(&wit[(o >> 5) + 1], flip_bytes32(hi));
+    for (uint64_t w0 = (uint64_t)blockIdx.x * WG_THREADS; w0 < total; w0 += (uint64_t)gridDim.x * WG_THREADS) {
+        for (uint32_t i = threadIdx.x; i < WG_THREADS * 2 + 2; i += WG_THREADS) buf[i] = 0;
+        __syncthreads();
+        const uint64_t w = w0 + threadIdx.x;
+        const uint64_t obase = seg_off[(uint64_t)f * nseg + w0 / words_per_seg] & ~31ull;   // dword-aligned start
+        if (w < total && w < nwords) {
+            const uint64_t pw = pwf[w];
+            if (pw) {
+                const uint64_t seg = w / words_per_seg;
+                uint64_t o = seg_off[(uint64_t)f * nseg + seg];
+                for (uint64_t v = seg * words_per_seg; v < w; ++v) o += __popcll(pwf[v]);
+                uint64_t tp = pw & flip_bytes64(masks[(uint64_t)f * mask_stride_words64 + w]);   // passes whose mask bit is 1
+                uint64_t out = 0;                                   // pext(mask, pw), LSB = first passing position
+                while (tp) {
+                    const uint64_t below = (tp & (0 - tp)) - 1;     // bits under the lowest set bit
+                    out |= 1ull << __popcll(pw & below);
+                    tp &= tp - 1;
+                }
+                if (out) {
+                    const uint32_t rel = (uint32_t)(o - obase);
+                    const uint32_t sh = rel & 31u, word = rel >> 5;
+                    const uint32_t lo = (uint32_t)out, hi = (uint32_t)(out >> 32);
+                    const uint32_t d0 = lo << sh;
+                    const uint32_t d1 = sh ? ((lo >> (32u - sh)) | (hi << sh)) : hi;
+                    const uint32_t d2 = sh ? (hi >> (32u - sh)) : 0u;
+                    if (d0) atomicOr(&buf[word], d0);
+                    if (d1) atomicOr(&buf[word + 1], d1);
+                    if (d2) atomicOr(&buf[word + 2], d2);
+                }
+            }
         }
+        __syncthreads();
+        // bit range of this chunk: [obase', oend) with oend = offset after the chunk's last word
+        const uint64_t wl = (w0 + WG_THREADS < total ? w0 + WG_THREADS : total);      // one past the last word
+        uint64_t oend;
+        {
+            const uint64_t lseg = (wl - 1) / words_per_seg;
+            oend = seg_off[(uint64_t)f * nseg + lseg];
+            for (uint64_t v = lseg * words_per_seg; v < wl; ++v) oend += __popcll(pwf[v]);
+        }
+        const uint32_t ndw = (uint32_t)(((oend - obase) + 31) >> 5);
+        for (uint32_t i = threadIdx.x; i < ndw; i += WG_THREADS) {
+            const uint32_t v = buf[i];
+            if (!v) continue;
+            if (i == 0 || i + 1 == ndw) atomicOr(&wit[(obase >> 5) + i], flip_bytes32(v));
+            else wit[(obase >> 5) + i] = flip_bytes32(v);
+        }
+        __syncthreads();
     }
 }
 

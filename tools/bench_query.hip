@@ -11,17 +11,18 @@ template <int AB, bool DB = true, int THREADS = QL_THREADS>
 static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F, const FrameTable &tab, Seeds sd, const uint32_t *filters,
                  uint64_t fstride, uint32_t fwmax, uint32_t *seg_bits, uint32_t *seg_cnt, uint64_t nseg, size_t lds)
 {
-    auto kern = k_query_lds<true, DB, true, AB>;
+    auto kern = k_query_lds<DB, true, AB>;
+    uint64_t *pwords = (uint64_t *)seg_bits;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const uint32_t bx = (uint32_t)((nseg + THREADS / 64 - 1) / (THREADS / 64));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int w = 0; w < 2; ++w)
-        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, masks, mstride, n, F, tab, sd, filters, fstride, fwmax, seg_bits, seg_cnt, nseg, (uint64_t *)nullptr);
+        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, n, F, tab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
     const int R = 10;
     for (int r = 0; r < R; ++r)
-        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, masks, mstride, n, F, tab, sd, filters, fstride, fwmax, seg_bits, seg_cnt, nseg, (uint64_t *)nullptr);
+        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, n, F, tab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return ms / R * 1000.f;
@@ -38,16 +39,16 @@ int main()
     for (auto &x : hf) x = ((uint32_t)rand() << 16) ^ (uint32_t)rand();
     uint64_t *dm; uint32_t *df, *sb, *sc;
     CK(hipMalloc(&dm, hm.size() * 8)); CK(hipMalloc(&df, hf.size() * 4 + 64));
-    CK(hipMalloc(&sb, (size_t)F * nseg * QL_SEG_WORDS * 4)); CK(hipMalloc(&sc, (size_t)F * nseg * 4));
+    CK(hipMalloc(&sb, (size_t)F * nseg * QL_P * 8)); CK(hipMalloc(&sc, (size_t)F * nseg * 4));
     CK(hipMemcpy(dm, hm.data(), hm.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(df, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
     FrameTable tab{};
     for (uint32_t f = 0; f < F; ++f) { tab.f[f].m = m - 37 * f; tab.f[f].floor_k = 2; tab.f[f].T = 0x4D00000000000000ull; tab.f[f].M = (uint64_t)((((unsigned __int128)1) << 64) / tab.f[f].m); }
     Seeds sd{0x12345678, 0x87654321, 999};
     const uint32_t fwmax = (uint32_t)fwords;
-    const size_t lds = 2 * (size_t)((fwmax + 3) & ~3u) * 4 + QL_WAVES * QL_SEG_WORDS * 4;
+    const size_t lds = 2 * (size_t)((fwmax + 3) & ~3u) * 4;
 #define RUN(AB, what) printf("%-44s %8.1f us\n", what, run<AB>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
     RUN(0, "full kernel");
-    { const size_t lds1 = (size_t)((fwmax + 3) & ~3u) * 4 + QL_WAVES * QL_SEG_WORDS * 4;
+    { const size_t lds1 = (size_t)((fwmax + 3) & ~3u) * 4;
       printf("%-44s %8.1f us\n", "single buffer, 1024 thr (1 WG/CU)", run<0, false, 1024>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds1));
       printf("%-44s %8.1f us\n", "single buffer, 512 thr (2 WG/CU)", run<0, false, 512>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds1));
       printf("%-44s %8.1f us\n", "single buffer, 256 thr (2 WG/CU)", run<0, false, 256>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds1));
