@@ -524,10 +524,11 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     if (pl.fast_insert) {
         const uint64_t part_stride = pl.fwords_even;
         if (int r = grow((void **)&ctx->partials, &ctx->partials_cap, (size_t)nframes * pl.S * part_stride * 4)) return r;
-        if (int r = allow_big_lds((const void *)k_insert_lds)) return r;
+        auto ikern = pl.small_m ? k_insert_lds<true> : k_insert_lds<false>;
+        if (int r = allow_big_lds((const void *)ikern)) return r;
         {
             LaunchTimer t(ctx, RBF_K_INSERT);
-            hipLaunchKernelGGL(k_insert_lds, dim3(pl.S, nframes), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+            hipLaunchKernelGGL(ikern, dim3(pl.S, nframes), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
                                (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.fwords_max);
         }
         {

@@ -98,6 +98,73 @@ __device__ __forceinline__ uint64_t xxh64_key(const DecKey &k, uint64_t seed)
     return h;
 }
 
+// ---- the three hashes of one index, tuned -------------------------------------------------------
+// Neighbouring indices have the same number of decimal digits, so a wave almost always agrees on
+// the key length: for the common lengths (5, 6, 7 digits: indices 10^4 .. 10^7-1, i.e. 99.5 % of a
+// 1080p frame and 99.9 % of a 2160p one) the XXH64 short-input path is expanded at compile time --
+// independent digit extractions (one magic multiply each) instead of a serial divide-by-ten loop,
+// no per-byte loops, and the three seeds' dependency chains side by side.
+struct Hash3 { uint64_t h1, h2, ha; };
+
+template <int LEN>
+__device__ __forceinline__ uint64_t xxh64_digits(const uint32_t (&d)[LEN], uint64_t seed)   // d[0] = most significant
+{
+    static_assert(LEN >= 5 && LEN <= 7, "4-byte round + 1..3 byte rounds");
+    uint64_t h = seed + P5 + (uint64_t)LEN;
+    const uint32_t w = 0x30303030u + d[0] + (d[1] << 8) + (d[2] << 16) + (d[3] << 24);
+    h ^= (uint64_t)w * P1;
+    h = rotl64(h, 23) * P2 + P3;
+#pragma unroll
+    for (int t = 4; t < LEN; ++t) {
+        h ^= (uint64_t)(0x30u + d[t]) * P5;
+        h = rotl64(h, 11) * P1;
+    }
+    h ^= h >> 33; h *= P2;
+    h ^= h >> 29; h *= P3;
+    h ^= h >> 32;
+    return h;
+}
+
+template <int LEN>
+__device__ __forceinline__ Hash3 hash3_fixed(uint32_t v, const Seeds &s)
+{
+    constexpr uint32_t P10[8] = {1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u};
+    uint32_t q[LEN + 1];                                     // q[k] = v / 10^k
+#pragma unroll
+    for (int k = 0; k <= LEN; ++k) q[k] = k < LEN ? v / P10[k] : 0u;
+    uint32_t d[LEN];
+#pragma unroll
+    for (int k = 0; k < LEN; ++k) d[LEN - 1 - k] = q[k] - 10u * q[k + 1];
+    Hash3 r;
+    r.h1 = xxh64_digits<LEN>(d, s.h1);
+    r.h2 = xxh64_digits<LEN>(d, s.h2);
+    r.ha = xxh64_digits<LEN>(d, s.act);
+    return r;
+}
+
+__device__ __forceinline__ Hash3 hash3_generic(uint32_t v, const Seeds &s)
+{
+    const DecKey key = make_key(v);
+    Hash3 r;
+    r.h1 = xxh64_key(key, s.h1);
+    r.h2 = xxh64_key(key, s.h2);
+    r.ha = xxh64_key(key, s.act);
+    return r;
+}
+
+// `active`: lanes whose v is meaningful (the others may hold anything; they get a well-defined but
+// unused result).  The fast paths are taken only when every active lane has the same length.
+__device__ __forceinline__ Hash3 hash3_index(uint32_t v, bool active, const Seeds &s)
+{
+    const bool in7 = v >= 1000000u && v < 10000000u;
+    const bool in6 = v >= 100000u && v < 1000000u;
+    const bool in5 = v >= 10000u && v < 100000u;
+    if (__all(!active || in7)) return hash3_fixed<7>(active ? v : 1000000u, s);
+    if (__all(!active || in6)) return hash3_fixed<6>(active ? v : 100000u, s);
+    if (__all(!active || in5)) return hash3_fixed<5>(active ? v : 10000u, s);
+    return hash3_generic(active ? v : 0u, s);
+}
+
 // h mod m, exact, via Barrett with M = floor(2^64/m): q in {floor(h/m)-1, floor(h/m)}.
 __device__ __forceinline__ uint32_t mod_m(uint64_t h, uint32_t m, uint64_t M)
 {

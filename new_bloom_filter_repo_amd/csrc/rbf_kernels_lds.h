@@ -35,9 +35,24 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// h mod m for 2 <= m <= 2^30 (m2 = 2m), three 32x32 multiplies for the quotient estimate:
+// q' = hh*Mh + hi32(hh*Ml) + hi32(hl*Mh) >= floor(h*M/2^64) - 2 >= floor(h/m) - 3, so
+// r' = h - q'*m < 4m <= 2^32 and everything is carried modulo 2^32; two conditional subtracts
+// (2m, then m) finish the reduction.
+__device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t m2, uint32_t Mh, uint32_t Ml)
+{
+    const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
+    const uint32_t q = hh * Mh + __umulhi(hh, Ml) + __umulhi(hl, Mh);
+    uint32_t r = hl - q * m;
+    r = min(r, r - m2);
+    r = min(r, r - m);
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // insert
 // ------------------------------------------------------------------------------------------
+template <bool SMALL_M>
 __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
     const FrameTable tab, Seeds seeds,
@@ -63,14 +78,21 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     uint32_t *q = queues + wave * IL_QUEUE;
     uint32_t qn = 0;                                               // wave-uniform queue length
 
+    const uint32_t m = fd.m, m2 = fd.m << 1, Mh = (uint32_t)(fd.M >> 32), Ml = (uint32_t)fd.M;
     auto drain_at = [&](uint32_t first, uint32_t count) {          // hash `count` (<= 64) queued positions
-        if (lane < count) {
-            Probe p = make_probe(q[first + lane], fd, seeds);
+        const bool act = lane < count;                             // (wave-uniform call: hash3_index votes)
+        const uint32_t idx = act ? q[first + lane] : 0u;
+        const Hash3 h = hash3_index(idx, act, seeds);
+        if (act) {
+            uint32_t pos, step;
+            if (SMALL_M) { pos = mod_m_small(h.h1, m, m2, Mh, Ml); step = mod_m_small(h.h2, m, m2, Mh, Ml); }
+            else         { pos = mod_m(h.h1, m, fd.M);             step = mod_m(h.h2, m, fd.M); }
             for (uint32_t j = 0; j < fd.floor_k; ++j) {
-                atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
-                advance(p, fd.m);
+                atomicOr(&filt[pos >> 5], msb_bit(pos));
+                const uint64_t s2 = (uint64_t)pos + step;
+                pos = (uint32_t)(s2 >= m ? s2 - m : s2);
             }
-            if (p.extra) atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+            if (h.ha < fd.T) atomicOr(&filt[pos >> 5], msb_bit(pos));
         }
     };
 
@@ -195,20 +217,6 @@ __device__ __forceinline__ void dma_filter(uint32_t *lds_dst, const uint32_t *sr
     if (wave == 0 && lane < tail) dma4(src + (npieces << 2) + lane, __builtin_amdgcn_readfirstlane(base + (npieces << 4)));
 }
 
-// h mod m for 2 <= m <= 2^30 (m2 = 2m), three 32x32 multiplies for the quotient estimate:
-// q' = hh*Mh + hi32(hh*Ml) + hi32(hl*Mh) >= floor(h*M/2^64) - 2 >= floor(h/m) - 3, so
-// r' = h - q'*m < 4m <= 2^32 and everything is carried modulo 2^32; two conditional subtracts
-// (2m, then m) finish the reduction.
-__device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t m2, uint32_t Mh, uint32_t Ml)
-{
-    const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
-    const uint32_t q = hh * Mh + __umulhi(hh, Ml) + __umulhi(hl, Mh);
-    uint32_t r = hl - q * m;
-    r = min(r, r - m2);
-    r = min(r, r - m);
-    return r;
-}
-
 // v_writelane_b32: put a wave-uniform value into ONE lane of a VGPR (no builtin in this hipcc).
 __device__ __forceinline__ void write_lane(uint32_t &dst, uint32_t uniform_value, int lane_index)
 {
@@ -285,13 +293,12 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
         h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
         if (live && i < n) {
             if (AB & 16) { h1[it] = i * P1; h2[it] = i * P2 + seeds.h2; ha[it] = i * P3; }
-            else {
-                const DecKey key = make_key((uint32_t)i);
-                h1[it] = xxh64_key(key, seeds.h1);
-                h2[it] = xxh64_key(key, seeds.h2);
-                ha[it] = xxh64_key(key, seeds.act);
-            }
             validmask |= 1u << it;
+        }
+        if (!(AB & 16)) {
+            const bool act = (validmask >> it) & 1u;
+            const Hash3 h = hash3_index((uint32_t)i, act, seeds);
+            if (act) { h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha; }
         }
     }
 
