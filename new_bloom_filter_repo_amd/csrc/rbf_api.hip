@@ -49,6 +49,7 @@ struct rbf_ctx {
     uint32_t *partials = nullptr;    size_t partials_cap = 0;
     int force_generic = 0;           // tests: 1 = never use the LDS fast path
     int single_buffer = 0;           // tests: 1 = fast query path without filter double-buffering
+    uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
     // host staging of encode_gop: device-visible pinned block [flag | ones...] the GPU publishes into
     uint64_t *ones_pinned = nullptr; size_t host_cap = 0;
     uint64_t *ones_mapped_dev = nullptr;     // device address of the same block
@@ -243,6 +244,7 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     if (!ctx) return fail(RBF_EINVAL, "null context");
     ctx->force_generic = (on & 1) ? 1 : 0;
     ctx->single_buffer = (on & 2) ? 1 : 0;
+    ctx->mask_chunks = (uint32_t)(on >> 8) & 0xFF;           // tuning knob, bits 8..15
     return RBF_OK;
 }
 
@@ -436,10 +438,16 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
     if (fast_segs) {
         const uint32_t bx = (uint32_t)((fast_segs + WG_WAVES - 1) / WG_WAVES);
         const size_t lds = (size_t)pairs * 4;
+        // temporal chunks: enough waves to fill the chip (>= ~32 per CU) without re-reading much
+        uint32_t chunks = ctx->mask_chunks ? ctx->mask_chunks : (uint32_t)((6500 + fast_segs - 1) / fast_segs);   // 4 at 1080p (measured best)
+        if (chunks > pairs) chunks = pairs;
+        if (chunks < 1) chunks = 1;
+        const uint32_t ppc = (pairs + chunks - 1) / chunks;
+        chunks = (pairs + ppc - 1) / ppc;
         LaunchTimer t(ctx, RBF_K_MASK);
-#define RBF_MASK_GOP(S, PB) hipLaunchKernelGGL((k_residual_mask_gop<S, PB>), dim3(bx), dim3(WG_THREADS), lds, ctx->stream,          \
+#define RBF_MASK_GOP(S, PB) hipLaunchKernelGGL((k_residual_mask_gop<S, PB>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
                                (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, (uint16_t *)masks_dev, \
-                               mask_stride_bytes / 2, ones_dev)
+                               mask_stride_bytes / 2, ones_dev, ppc)
         if (sample_bytes == 1 && pixel_stride_bytes == 1) RBF_MASK_GOP(uint8_t, 1);
         else if (sample_bytes == 1) RBF_MASK_GOP(uint8_t, 3);
         else if (pixel_stride_bytes == 2) RBF_MASK_GOP(uint16_t, 2);
@@ -522,7 +530,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     }
     // ---- insert
     if (pl.fast_insert) {
-        const uint64_t part_stride = pl.fwords_even;
+        const uint64_t part_stride = (pl.fwords_max + 3u) & ~3ull;      // 16-byte rows for the reduce kernel
         if (int r = grow((void **)&ctx->partials, &ctx->partials_cap, (size_t)nframes * pl.S * part_stride * 4)) return r;
         auto ikern = pl.small_m ? k_insert_lds<true> : k_insert_lds<false>;
         if (int r = allow_big_lds((const void *)ikern)) return r;
@@ -534,10 +542,11 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);
             const uint64_t words = filter_stride_bytes / 4;
+            const uint32_t vec_ok = (words % 4 == 0 && ((uintptr_t)filters_dev % 16) == 0) ? 1u : 0u;
             uint32_t bx = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx < 1) bx = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)ctx->partials, part_stride, pl.S, tab, (uint32_t *)filters_dev, words, stats_dev);
+                               (const uint32_t *)ctx->partials, part_stride, pl.S, tab, (uint32_t *)filters_dev, words, stats_dev, vec_ok);
         }
     } else {
         HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
@@ -556,26 +565,21 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
             uint32_t bx2 = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx2 < 1) bx2 = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx2, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)filters_dev, words, 1u, tab, (uint32_t *)filters_dev, words, stats_dev);
+                               (const uint32_t *)filters_dev, words, 1u, tab, (uint32_t *)filters_dev, words, stats_dev, 0u);
         }
     }
     // ---- query: pass word of every 64 positions + per-segment pass counts
     if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes)) return r;
-    // ---- witness: scan the counts, then pext(mask, pass) of every word lands at its bit offset
-    {
-        LaunchTimer t(ctx, RBF_K_SCAN);
-        hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, pl.nseg,
-                           stats_dev, (uint32_t)RBF_STATS_PER_FRAME);
-    }
+    // ---- witness: pext(mask, pass) of every word lands at its bit offset (scan fused in)
     {
         const uint64_t words = pl.nseg * pl.words_per_seg;
         uint64_t bx = (words + WG_THREADS - 1) / WG_THREADS;
         if (bx < 1) bx = 1;
-        if (bx > 4096) bx = 4096;
+        if (bx > 8192) bx = 8192;
         LaunchTimer t(ctx, RBF_K_STITCH);
         hipLaunchKernelGGL(k_compact_witness, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           ctx->pass_words, ctx->seg_off, pl.nseg, pl.words_per_seg,
-                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4);
+                           ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
+                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4, stats_dev);
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;

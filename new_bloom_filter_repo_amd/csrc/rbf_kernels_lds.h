@@ -135,24 +135,46 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
 }
 
 // OR the S partial filters of every frame into the final packed filter; count its set bits.
+// 16-byte accesses (rows are 8-byte padded and 16-byte aligned bases are not guaranteed, so the
+// vector path is taken only when both strides are multiples of 4 words and the bases are aligned).
 __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
     const uint32_t *partials, uint64_t part_stride_words32, uint32_t S,
     const FrameTable tab,
     uint32_t *filters /* may alias partials when S == 1 */, uint64_t filter_stride_words32,
-    uint64_t *__restrict__ stats)
+    uint64_t *__restrict__ stats, uint32_t vec_ok)
 {
     __shared__ uint32_t red[WG_WAVES];
     const uint32_t f = blockIdx.y;
     const uint32_t m = tab.f[f].m;
     const uint32_t fwords = m ? ((m + 31u) >> 5) : 0u;
     uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
+    const uint32_t *part = partials + (uint64_t)f * S * part_stride_words32;
     uint32_t pc = 0;
-    for (uint64_t w = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x; w < filter_stride_words32; w += (uint64_t)gridDim.x * WG_THREADS) {
-        uint32_t v = 0;
-        if (w < fwords)
-            for (uint32_t s = 0; s < S; ++s) v |= partials[((uint64_t)f * S + s) * part_stride_words32 + w];
-        if (m) filt[w] = v;                                       // passthrough frames: filter untouched
-        pc += __popc(v);
+    if (vec_ok) {
+        const uint64_t quads = filter_stride_words32 >> 2;
+        for (uint64_t q = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * WG_THREADS) {
+            const uint64_t w = q << 2;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (w < fwords) {
+                for (uint32_t s = 0; s < S; ++s) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(part + (uint64_t)s * part_stride_words32 + w);
+                    v.x |= x.x; v.y |= x.y; v.z |= x.z; v.w |= x.w;
+                }
+                if (w + 1 >= fwords) v.y = 0;                    // words past the filter end hold LDS padding
+                if (w + 2 >= fwords) v.z = 0;
+                if (w + 3 >= fwords) v.w = 0;
+            }
+            if (m) *reinterpret_cast<uint4 *>(filt + w) = v;     // passthrough frames: filter untouched
+            pc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        }
+    } else {
+        for (uint64_t w = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x; w < filter_stride_words32; w += (uint64_t)gridDim.x * WG_THREADS) {
+            uint32_t v = 0;
+            if (w < fwords)
+                for (uint32_t s = 0; s < S; ++s) v |= part[(uint64_t)s * part_stride_words32 + w];
+            if (m) filt[w] = v;
+            pc += __popc(v);
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) pc += __shfl_down(pc, d);
@@ -374,59 +396,78 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
 // seg_off[segment] + (passes of the segment's earlier words) in the pre-zeroed packed witness.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
-    const uint64_t *__restrict__ pass_words, const uint64_t *__restrict__ seg_off, uint64_t nseg, uint32_t words_per_seg,
+    const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
     const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n,
-    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32)
+    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32, uint64_t *__restrict__ stats)
 {
-    // A workgroup owns WG_THREADS consecutive words (= whole segments): their witness bits form one
-    // contiguous bit range, assembled in LDS with LDS atomics and written out with plain coalesced
-    // stores; only the first and last dword of the range are shared with the neighbours (atomicOr).
+    // A workgroup owns WG_THREADS consecutive words (= whole segments).  Their witness bits form one
+    // contiguous bit range starting at (passes of all earlier segments): the range is assembled in
+    // LDS with LDS atomics and written with plain coalesced stores; only its first and last dword
+    // are shared with the neighbouring workgroups (atomicOr).  No separate scan kernel: the start
+    // is a block reduction over the earlier segment counts, the offsets inside the chunk a block scan.
     __shared__ uint32_t buf[WG_THREADS * 2 + 2];
+    __shared__ unsigned long long red[WG_WAVES];
+    __shared__ uint32_t wsum[WG_WAVES];
     const uint32_t f = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t nwords = (n + 63) >> 6;
     const uint64_t total = nseg * words_per_seg;
     const uint64_t *pwf = pass_words + (uint64_t)f * total;
+    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
     uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
     for (uint64_t w0 = (uint64_t)blockIdx.x * WG_THREADS; w0 < total; w0 += (uint64_t)gridDim.x * WG_THREADS) {
         for (uint32_t i = threadIdx.x; i < WG_THREADS * 2 + 2; i += WG_THREADS) buf[i] = 0;
-        __syncthreads();
+        // chunk start = passes of every earlier segment
+        const uint64_t seg0 = w0 / words_per_seg;
+        unsigned long long part = 0;
+        for (uint64_t s = threadIdx.x; s < seg0; s += WG_THREADS) part += cnt[s];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_down(part, d);
+        if (lane == 0) red[wave] = part;
+        // my word and the block-exclusive scan of the pass counts
         const uint64_t w = w0 + threadIdx.x;
-        const uint64_t obase = seg_off[(uint64_t)f * nseg + w0 / words_per_seg] & ~31ull;   // dword-aligned start
-        if (w < total && w < nwords) {
-            const uint64_t pw = pwf[w];
-            if (pw) {
-                const uint64_t seg = w / words_per_seg;
-                uint64_t o = seg_off[(uint64_t)f * nseg + seg];
-                for (uint64_t v = seg * words_per_seg; v < w; ++v) o += __popcll(pwf[v]);
-                uint64_t tp = pw & flip_bytes64(masks[(uint64_t)f * mask_stride_words64 + w]);   // passes whose mask bit is 1
-                uint64_t out = 0;                                   // pext(mask, pw), LSB = first passing position
-                while (tp) {
-                    const uint64_t below = (tp & (0 - tp)) - 1;     // bits under the lowest set bit
-                    out |= 1ull << __popcll(pw & below);
-                    tp &= tp - 1;
-                }
-                if (out) {
-                    const uint32_t rel = (uint32_t)(o - obase);
-                    const uint32_t sh = rel & 31u, word = rel >> 5;
-                    const uint32_t lo = (uint32_t)out, hi = (uint32_t)(out >> 32);
-                    const uint32_t d0 = lo << sh;
-                    const uint32_t d1 = sh ? ((lo >> (32u - sh)) | (hi << sh)) : hi;
-                    const uint32_t d2 = sh ? (hi >> (32u - sh)) : 0u;
-                    if (d0) atomicOr(&buf[word], d0);
-                    if (d1) atomicOr(&buf[word + 1], d1);
-                    if (d2) atomicOr(&buf[word + 2], d2);
-                }
+        const uint64_t pw = (w < total && w < nwords) ? pwf[w] : 0ull;
+        const uint32_t c = __popcll(pw);
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += t;
+        }
+        if (lane == WAVE - 1) wsum[wave] = incl;
+        __syncthreads();
+        uint64_t start = 0;
+        uint32_t before = 0, chunk_total = 0;
+#pragma unroll
+        for (int k = 0; k < WG_WAVES; ++k) {
+            start += red[k];
+            if ((uint32_t)k < wave) before += wsum[k];
+            chunk_total += wsum[k];
+        }
+        const uint64_t obase = start & ~31ull;                     // dword-aligned start of my LDS image
+        const uint64_t o = start + before + incl - c;
+        if (pw) {
+            uint64_t tp = pw & flip_bytes64(masks[(uint64_t)f * mask_stride_words64 + w]);   // passes whose mask bit is 1
+            uint64_t out = 0;                                      // pext(mask, pw), LSB = first passing position
+            while (tp) {
+                const uint64_t below = (tp & (0 - tp)) - 1;        // bits under the lowest set bit
+                out |= 1ull << __popcll(pw & below);
+                tp &= tp - 1;
+            }
+            if (out) {
+                const uint32_t rel = (uint32_t)(o - obase);
+                const uint32_t sh = rel & 31u, word = rel >> 5;
+                const uint32_t lo = (uint32_t)out, hi = (uint32_t)(out >> 32);
+                const uint32_t d0 = lo << sh;
+                const uint32_t d1 = sh ? ((lo >> (32u - sh)) | (hi << sh)) : hi;
+                const uint32_t d2 = sh ? (hi >> (32u - sh)) : 0u;
+                if (d0) atomicOr(&buf[word], d0);
+                if (d1) atomicOr(&buf[word + 1], d1);
+                if (d2) atomicOr(&buf[word + 2], d2);
             }
         }
         __syncthreads();
-        // bit range of this chunk: [obase', oend) with oend = offset after the chunk's last word
-        const uint64_t wl = (w0 + WG_THREADS < total ? w0 + WG_THREADS : total);      // one past the last word
-        uint64_t oend;
-        {
-            const uint64_t lseg = (wl - 1) / words_per_seg;
-            oend = seg_off[(uint64_t)f * nseg + lseg];
-            for (uint64_t v = lseg * words_per_seg; v < wl; ++v) oend += __popcll(pwf[v]);
-        }
+        const uint64_t oend = start + chunk_total;
         const uint32_t ndw = (uint32_t)(((oend - obase) + 31) >> 5);
         for (uint32_t i = threadIdx.x; i < ndw; i += WG_THREADS) {
             const uint32_t v = buf[i];
@@ -434,6 +475,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
             if (i == 0 || i + 1 == ndw) atomicOr(&wit[(obase >> 5) + i], flip_bytes32(v));
             else wit[(obase >> 5) + i] = flip_bytes32(v);
         }
+        if (threadIdx.x == 0 && w0 + WG_THREADS >= total) stats[(uint64_t)f * 4 + 0] = oend;   // len(witness)
         __syncthreads();
     }
 }
@@ -484,13 +526,14 @@ template <typename SAMPLE, int PIXEL_BYTES>
 struct LanePixels {
     static constexpr int DW = 16 * PIXEL_BYTES / 4;            // dwords per lane per frame
     uint32_t d[DW];
+    template <bool NT>
     __device__ __forceinline__ void load(const uint8_t *p)
     {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
 #pragma unroll
         for (int i = 0; i < DW / 4; ++i) {
-            const u32x4 v = __builtin_nontemporal_load(q + i);   // streamed once: keep it out of the caches
+            const u32x4 v = NT ? __builtin_nontemporal_load(q + i) : q[i];
             d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
         }
     }
@@ -503,26 +546,31 @@ struct LanePixels {
     }
 };
 
-template <typename SAMPLE, int PIXEL_BYTES>
+template <typename SAMPLE, int PIXEL_BYTES, bool NT = false>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t nframes, uint64_t nsegs /* of 1024 px */,
-    int32_t thr, uint16_t *__restrict__ masks, uint64_t mask_stride_u16, uint64_t *__restrict__ ones)
+    int32_t thr, uint16_t *__restrict__ masks, uint64_t mask_stride_u16, uint64_t *__restrict__ ones,
+    uint32_t pairs_per_chunk)
 {
+    // blockIdx.y = temporal chunk: frames [f0, f1] (f1 - f0 pairs); chunks overlap by one frame, which
+    // buys gridDim.y times more waves in flight for ~gridDim.y/nframes extra reads
     extern __shared__ uint32_t cnt[];                          // [nframes-1] per-workgroup ones
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
+    const uint32_t f0 = blockIdx.y * pairs_per_chunk;
+    const uint32_t f1 = f0 + pairs_per_chunk < nframes - 1 ? f0 + pairs_per_chunk : nframes - 1;
     for (uint32_t i = threadIdx.x; i + 1 < nframes; i += WG_THREADS) cnt[i] = 0;
     __syncthreads();
-    if (seg < nsegs) {
+    if (seg < nsegs && f0 < f1) {
         using LP = LanePixels<SAMPLE, PIXEL_BYTES>;
         const uint64_t lane_off = (seg * 1024 + (uint64_t)lane * 16) * PIXEL_BYTES;
         const uint8_t *p = frames + lane_off;
         uint16_t *out = masks + seg * 64 + lane;
         LP prev, cur, nxt;
-        prev.load(p);
-        if (nframes > 1) cur.load(p + frame_stride);
-        for (uint32_t f = 1; f < nframes; ++f) {
-            if (f + 1 < nframes) nxt.load(p + (uint64_t)(f + 1) * frame_stride);
+        prev.template load<NT>(p + (uint64_t)f0 * frame_stride);
+        cur.template load<NT>(p + (uint64_t)(f0 + 1) * frame_stride);
+        for (uint32_t f = f0 + 1; f <= f1; ++f) {
+            if (f + 1 <= f1) nxt.template load<NT>(p + (uint64_t)(f + 1) * frame_stride);
             uint32_t bits = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -539,7 +587,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i + 1 < nframes; i += WG_THREADS)
+    for (uint32_t i = f0 + threadIdx.x; i < f1; i += WG_THREADS)
         if (cnt[i]) atomicAdd((unsigned long long *)&ones[i], (unsigned long long)cnt[i]);
 }
 

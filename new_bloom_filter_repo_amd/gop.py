@@ -52,7 +52,7 @@ class GopCoder:
         alloc = allocator or owned_allocator(ctx)
         self.frame_bytes = self.n * channels * sample_bytes
         self.mask_stride = nat.packed_stride(self.n)
-        self.filter_stride = nat.packed_stride(int(self.n * 0.32) + 64)   # l <= 0.317 n for every density
+        self.filter_stride = (nat.packed_stride(int(self.n * 0.32) + 64) + 15) // 16 * 16   # l <= 0.317 n for every density
         self.witness_stride = nat.packed_stride(self.n)
         self.frames = alloc(self.frame_bytes * nframes)
         self.masks = alloc(self.mask_stride * self.pairs)
