@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--frames", type=int, default=30, help="frames per GOP (frames-1 inter-frames are coded)")
     ap.add_argument("--bits", type=int, default=8, choices=(8, 16))
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and gather) even with one rank (smoke-tests the N>1 path)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of CPU-oracle work (0 = auto, about 10-30 s)")
@@ -56,12 +57,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from new_bloom_filter_repo_amd import _native as nat
-    from new_bloom_filter_repo_amd.gop import GopCoder, torch_allocator
+    from new_bloom_filter_repo_amd.gop import GopCoder, TorchArena, torch_allocator
     from new_bloom_filter_repo_amd.synthetic import make_gop, P_KSTAR_2_3
 
     W, H, F = args.width, args.height, args.frames
@@ -69,38 +72,59 @@ def main():
     dtype = np.uint8 if args.bits == 8 else np.uint16
     stream = torch.cuda.current_stream(device)
     ctx = nat.Context(local_rank, stream.cuda_stream)
-    coder = GopCoder(ctx, W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device))
+    use_gather = use_dist and not args.no_gather
+    # two coders share the frame buffer and alternate, so that the gather of step s (async, on RCCL's
+    # stream) overlaps the kernels of step s+1; each coder's output record is ONE contiguous tensor
+    ncoders = 2 if use_gather else 1
+    arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
+    coders = [GopCoder(ctx, W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device), out_allocator=arenas[0])]
+    for a in arenas[1:]:
+        coders.append(GopCoder(ctx, W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
+                               out_allocator=a, frames_block=coders[0].frames))
+    coder = coders[0]
     frames = np.stack(make_gop(1000 * 2 + rank, W, H, F, p=P_KSTAR_2_3, dtype=dtype))
     coder.load_frames(frames)
 
-    gather = world > 1 and not args.no_gather
+    gather = use_gather
+    pending = [None] * ncoders
     if gather:
-        # padded per-rank records: [filters | witness | stats] as int64 words, gathered to rank 0
-        parts = [coder.filters.tensor, coder.witness.tensor, coder.stats.tensor]
-        gl = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in parts]
+        gl = [[torch.empty_like(a.tensor) for _ in range(world)] if rank == 0 else None for a in arenas]
+    state = {"s": 0}
 
     def step():
-        coder.encode()
+        k = state["s"] % ncoders
+        state["s"] += 1
+        if pending[k] is not None:
+            pending[k].wait()                 # this coder's previous record has left (stream-side wait)
+            pending[k] = None
+        coders[k].encode()
         if gather:
-            for t, g in zip(parts, gl):
-                dist.gather(t, g, dst=0)
+            pending[k] = dist.gather(arenas[k].tensor, gl[k], dst=0, async_op=True)
+
+    def drain():
+        for k in range(ncoders):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize(device)
     if not args.no_kernel_timing:
         # HIP events around the DOMINANT kernel only (query): two events per step on the launching
         # stream; bracketing every kernel would add ~40 us of event overhead to a ~360 us step
         ctx.timing_reset()
         ctx.timing(1 << nat.K_QUERY)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
@@ -108,7 +132,7 @@ def main():
     if not args.no_kernel_timing:
         ctx.timing(False)
         ktimes = ctx.timing_read()
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -158,7 +182,7 @@ def main():
             verify(res, n)
             out["verified_vs_oracle"] = True
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -38,11 +38,30 @@ def torch_allocator(device):
     return lambda nbytes: _TorchBlock(torch.zeros((int(nbytes) + 7) // 8, dtype=torch.int64, device=device))
 
 
+class TorchArena:
+    """Carves consecutive 256-byte aligned blocks out of ONE torch tensor, so that a GOP's output
+    record (filters | witnesses | stats) is a single contiguous tensor a collective can move."""
+
+    def __init__(self, device, nbytes):
+        import torch
+        self.tensor = torch.zeros((int(nbytes) + 7) // 8, dtype=torch.int64, device=device)
+        self.used = 0
+
+    def __call__(self, nbytes):
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        assert self.used + nbytes <= self.tensor.numel() * 8, "arena exhausted"
+        view = self.tensor[self.used // 8:(self.used + nbytes) // 8]
+        self.used += nbytes
+        return _TorchBlock(view)
+
+
 class GopCoder:
     """Encodes the nframes-1 inter-frame residual masks of one GOP of (H, W, C) frames."""
 
     def __init__(self, ctx, width, height, nframes, channels=3, sample_bytes=1, seeds=P.SEEDS_VIDEO,
-                 allocator=None, threshold=0.0):
+                 allocator=None, threshold=0.0, out_allocator=None, frames_block=None):
+        """allocator: device memory source (default: library-owned); out_allocator: separate source for
+        the output record (filters, witnesses, stats); frames_block: share another coder's frame buffer."""
         from .engine import threshold_floor
         self.ctx, self.W, self.H, self.F, self.C, self.sb = ctx, width, height, nframes, channels, sample_bytes
         self.n = width * height
@@ -51,17 +70,29 @@ class GopCoder:
         self.thr = threshold_floor(threshold)
         alloc = allocator or owned_allocator(ctx)
         self.frame_bytes = self.n * channels * sample_bytes
-        self.mask_stride = nat.packed_stride(self.n)
-        self.filter_stride = (nat.packed_stride(int(self.n * 0.32) + 64) + 15) // 16 * 16   # l <= 0.317 n for every density
-        self.witness_stride = nat.packed_stride(self.n)
-        self.frames = alloc(self.frame_bytes * nframes)
+        self.mask_stride, self.filter_stride, self.witness_stride = self.strides(self.n)
+        oalloc = out_allocator or alloc
+        self.frames = frames_block if frames_block is not None else alloc(self.frame_bytes * nframes)
         self.masks = alloc(self.mask_stride * self.pairs)
         self.ones = alloc(8 * self.pairs)
-        self.filters = alloc(self.filter_stride * self.pairs)
-        self.witness = alloc(self.witness_stride * self.pairs)
-        self.stats = alloc(8 * nat.STATS_PER_FRAME * self.pairs)
+        self.filters = oalloc(self.filter_stride * self.pairs)
+        self.witness = oalloc(self.witness_stride * self.pairs)
+        self.stats = oalloc(8 * nat.STATS_PER_FRAME * self.pairs)
         self.params = (nat.FilterParams * self.pairs)()
         self.k = (ctypes.c_double * self.pairs)()
+
+    @staticmethod
+    def strides(n):
+        """(mask, filter, witness) row strides in bytes for frames of n pixels."""
+        fstride = (nat.packed_stride(int(n * 0.32) + 64) + 15) // 16 * 16     # l <= 0.317 n for every density
+        return nat.packed_stride(n), fstride, nat.packed_stride(n)
+
+    @staticmethod
+    def record_bytes(n, pairs):
+        """Bytes a TorchArena needs for the output record (filters | witnesses | stats) of `pairs` frames."""
+        _, fs, ws = GopCoder.strides(n)
+        r = lambda x: (x + 255) // 256 * 256
+        return r(fs * pairs) + r(ws * pairs) + r(8 * nat.STATS_PER_FRAME * pairs)
 
     def load_frames(self, frames):
         frames = np.ascontiguousarray(frames)
@@ -80,11 +111,13 @@ class GopCoder:
     def results(self):
         """Download: list of per-frame dicts (mask/filter/witness packed uint8, counts, k, l)."""
         self.ctx.sync()
-        masks = self.masks.numpy(self.ctx).reshape(self.pairs, self.mask_stride)
-        filt = self.filters.numpy(self.ctx).reshape(self.pairs, self.filter_stride)
-        wit = self.witness.numpy(self.ctx).reshape(self.pairs, self.witness_stride)
-        stats = self.stats.numpy(self.ctx).view(np.uint64).reshape(self.pairs, nat.STATS_PER_FRAME)
-        ones = self.ones.numpy(self.ctx).view(np.uint64)
+        def rows(block, stride):                       # blocks may be padded (arena alignment)
+            return block.numpy(self.ctx)[:self.pairs * stride].reshape(self.pairs, stride)
+        masks = rows(self.masks, self.mask_stride)
+        filt = rows(self.filters, self.filter_stride)
+        wit = rows(self.witness, self.witness_stride)
+        stats = rows(self.stats, 8 * nat.STATS_PER_FRAME).view(np.uint64)
+        ones = self.ones.numpy(self.ctx)[:8 * self.pairs].view(np.uint64)
         out = []
         for f in range(self.pairs):
             m = int(self.params[f].m)
