@@ -50,6 +50,7 @@ struct rbf_ctx {
     int force_generic = 0;           // tests: 1 = never use the LDS fast path
     int single_buffer = 0;           // tests: 1 = fast query path without filter double-buffering
     uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
+    uint32_t tile_words = 0;         // tests/tuning: cap the LDS filter tile (dwords); forces the tiled kernels
     // host staging of encode_gop: device-visible pinned block [flag | ones...] the GPU publishes into
     uint64_t *ones_pinned = nullptr; size_t host_cap = 0;
     uint64_t *ones_mapped_dev = nullptr;     // device address of the same block
@@ -245,6 +246,7 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->force_generic = (on & 1) ? 1 : 0;
     ctx->single_buffer = (on & 2) ? 1 : 0;
     ctx->mask_chunks = (uint32_t)(on >> 8) & 0xFF;           // tuning knob, bits 8..15
+    ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
     return RBF_OK;
 }
 
@@ -365,8 +367,11 @@ static inline uint64_t nseg_of(uint64_t n) { return (n + SEG_PIXELS - 1) / SEG_P
 // probe / set the filter in global memory.
 constexpr size_t LDS_LIMIT = 160 * 1024;
 struct Plan {
-    bool fast_insert, fast_query, double_buffer, small_m;
-    uint32_t fwords_max, fwords_even, S;
+    bool fast_insert;            // LDS partial-filter insert (any filter size, tiled when needed)
+    int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles
+    bool double_buffer, small_m;
+    uint32_t fwords_max, S;
+    uint32_t insert_tile_words, insert_tiles, query_tile_words;
     size_t insert_lds_bytes, query_lds_bytes;
     uint64_t nseg; uint32_t words_per_seg;
 };
@@ -382,20 +387,40 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
         if (params[f].m == 1 || params[f].m > (1u << 30)) p.small_m = false;
     }
     p.fwords_max = (uint32_t)(((uint64_t)mmax + 31) / 32);
-    p.fwords_even = (p.fwords_max + 1u) & ~1u;
-    p.insert_lds_bytes = (size_t)p.fwords_even * 4 + (size_t)IL_WAVES * IL_QUEUE * 4;
-    const size_t bufbytes = (size_t)((p.fwords_max + 3u) & ~3u) * 4;
-    p.double_buffer = 2 * bufbytes <= LDS_LIMIT && !ctx->single_buffer;
-    p.query_lds_bytes = (p.double_buffer ? 2 : 1) * bufbytes;
-    p.fast_insert = !ctx->force_generic && mmax > 0 && p.insert_lds_bytes <= LDS_LIMIT;
-    p.fast_query = !ctx->force_generic && mmax > 0 && p.query_lds_bytes <= LDS_LIMIT;
-    // slices per frame so that S * frames ~ one workgroup per CU (256 CUs), at most 32
-    uint32_t S = active ? 256u / active : 1u;
+    const size_t fbytes = (size_t)((p.fwords_max + 3u) & ~3u) * 4;
+    // insert: whole partial filter in LDS next to the per-wave queues, else tiles of the largest size that fits
+    const size_t queue_bytes = (size_t)IL_WAVES * IL_QUEUE * 4;
+    const uint32_t max_tile_words = (uint32_t)((LDS_LIMIT - queue_bytes) / 4) & ~3u;
+    p.insert_tile_words = ((p.fwords_max + 3u) & ~3u) <= max_tile_words ? ((p.fwords_max + 3u) & ~3u) : max_tile_words;
+    if (ctx->tile_words && ctx->tile_words < p.insert_tile_words) p.insert_tile_words = ctx->tile_words & ~3u;
+    if (p.insert_tile_words < 4) p.insert_tile_words = 4;
+    p.insert_tiles = (p.fwords_max + p.insert_tile_words - 1) / p.insert_tile_words;
+    if (p.insert_tiles < 1) p.insert_tiles = 1;
+    p.insert_lds_bytes = (size_t)p.insert_tile_words * 4 + queue_bytes;
+    p.fast_insert = !ctx->force_generic && mmax > 0;
+    // query
+    p.double_buffer = 2 * fbytes <= LDS_LIMIT && !ctx->single_buffer;
+    p.query_kind = 0;
+    if (!ctx->force_generic && mmax > 0) {
+        if (fbytes <= LDS_LIMIT && !ctx->tile_words) {
+            p.query_kind = 1;
+            p.query_lds_bytes = (p.double_buffer ? 2 : 1) * fbytes;
+        } else {
+            p.query_kind = 2;
+            p.query_tile_words = (uint32_t)(LDS_LIMIT / 4);
+            if (ctx->tile_words && ctx->tile_words < p.query_tile_words) p.query_tile_words = ctx->tile_words & ~3u;
+            if (p.query_tile_words < 4) p.query_tile_words = 4;
+            p.query_lds_bytes = (size_t)(p.query_tile_words < ((p.fwords_max + 3u) & ~3u) ? p.query_tile_words : ((p.fwords_max + 3u) & ~3u)) * 4;
+        }
+    }
+    // slices per frame so that S * tiles * frames ~ one workgroup per CU (256 CUs), at most 32
+    uint32_t S = active ? 256u / (active * p.insert_tiles) : 1u;
     if (S < 1) S = 1;
     if (S > 32) S = 32;
     p.S = S;
-    p.nseg = p.fast_query ? (n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS : nseg_of(n);
-    p.words_per_seg = p.fast_query ? (uint32_t)QL_P : (uint32_t)SEG_ITERS;
+    const uint32_t segpx = p.query_kind == 1 ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
+    p.nseg = (n + segpx - 1) / segpx;
+    p.words_per_seg = segpx / 64;
     return p;
 }
 
@@ -490,7 +515,7 @@ static int check_filter_strides(const rbf_filter_params *params, uint32_t nframe
 static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nframes, const FrameTable &tab, const Seeds &sd,
                         const void *filters_dev, uint64_t filter_stride_bytes)
 {
-    if (pl.fast_query) {
+    if (pl.query_kind == 1) {
         auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<true, true> : k_query_lds<true, false>)
                                      : (pl.small_m ? k_query_lds<false, true> : k_query_lds<false, false>);
         if (int r = allow_big_lds((const void *)kern)) return r;
@@ -498,6 +523,14 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         LaunchTimer t(ctx, RBF_K_QUERY);
         hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                            n, nframes, tab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+                           ctx->seg_cnt, pl.nseg, ctx->pass_words);
+    } else if (pl.query_kind == 2) {
+        auto kern = pl.small_m ? k_query_tiled<true> : k_query_tiled<false>;
+        if (int r = allow_big_lds((const void *)kern)) return r;
+        const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
+                           n, nframes, tab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
                            ctx->seg_cnt, pl.nseg, ctx->pass_words);
     } else {
         const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
@@ -536,8 +569,8 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         if (int r = allow_big_lds((const void *)ikern)) return r;
         {
             LaunchTimer t(ctx, RBF_K_INSERT);
-            hipLaunchKernelGGL(ikern, dim3(pl.S, nframes), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
-                               (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.fwords_max);
+            hipLaunchKernelGGL(ikern, dim3(pl.S, nframes, pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                               (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.insert_tile_words);
         }
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);

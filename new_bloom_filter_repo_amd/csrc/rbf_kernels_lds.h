@@ -56,17 +56,23 @@ template <bool SMALL_M>
 __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
     const FrameTable tab, Seeds seeds,
-    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t fwords_max)
+    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t tile_words /* even */)
 {
+    // blockIdx.z = filter tile: this workgroup keeps words [tile0, tile0 + tile_words) of the partial
+    // filter in LDS and sets only the positions that fall into them.  Filters that fit LDS whole
+    // (1080p: 76 KB) have one tile; a 4K filter (306 KB) is built in 3 tiles (keys re-hashed per tile).
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *filt = lds;                                         // [fwords_max (even)]
-    uint32_t *queues = lds + ((fwords_max + 1u) & ~1u);           // [IL_WAVES][IL_QUEUE]
+    uint32_t *filt = lds;                                         // [tile_words]
+    uint32_t *queues = lds + tile_words;                          // [IL_WAVES][IL_QUEUE]
     const uint32_t f = blockIdx.y, s = blockIdx.x, S = gridDim.x;
     const FrameDev fd = tab.f[f];
     if (fd.m == 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t fwords = (fd.m + 31u) >> 5;
-    for (uint32_t i = threadIdx.x; i < fwords_max; i += IL_THREADS) filt[i] = 0;
+    const uint32_t tile0 = blockIdx.z * tile_words;               // first word of my tile
+    if (tile0 >= fwords) return;
+    const uint32_t tile_bit0 = tile0 << 5, tile_bits = tile_words << 5;
+    for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
     __syncthreads();
 
     const uint8_t *mask = masks + (uint64_t)f * mask_stride_bytes;
@@ -88,11 +94,13 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
             if (SMALL_M) { pos = mod_m_small(h.h1, m, m2, Mh, Ml); step = mod_m_small(h.h2, m, m2, Mh, Ml); }
             else         { pos = mod_m(h.h1, m, fd.M);             step = mod_m(h.h2, m, fd.M); }
             for (uint32_t j = 0; j < fd.floor_k; ++j) {
-                atomicOr(&filt[pos >> 5], msb_bit(pos));
+                const uint32_t rel = pos - tile_bit0;              // unsigned: out-of-tile positions wrap high
+                if (rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
                 const uint64_t s2 = (uint64_t)pos + step;
                 pos = (uint32_t)(s2 >= m ? s2 - m : s2);
             }
-            if (h.ha < fd.T) atomicOr(&filt[pos >> 5], msb_bit(pos));
+            const uint32_t rel = pos - tile_bit0;
+            if (h.ha < fd.T && rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
         }
     };
 
@@ -128,8 +136,9 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     }
     drain_at(0, qn);
     __syncthreads();
-    uint32_t *part = partials + ((uint64_t)f * S + s) * part_stride_words32;
-    const uint32_t pairs = (fwords + 1) >> 1;
+    uint32_t *part = partials + ((uint64_t)f * S + s) * part_stride_words32 + tile0;
+    const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
+    const uint32_t pairs = (mine + 1) >> 1;                        // tile0 is even: 8-byte aligned
     for (uint32_t i = threadIdx.x; i < pairs; i += IL_THREADS)
         reinterpret_cast<uint2 *>(part)[i] = reinterpret_cast<const uint2 *>(filt)[i];
 }
@@ -387,6 +396,92 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
             if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
         }
         f = fn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// query for filters larger than LDS (4K frames: 306 KB): the filter is staged tile by tile; every
+// (pixel, frame) computes its probe positions once and tests, per tile, the probes that land in it.
+// Same outputs as k_query_lds with TQ_P pass words per segment.
+// ------------------------------------------------------------------------------------------
+constexpr int TQ_P = 4;                            // fewer pixels per lane: positions stay in registers too
+constexpr int TQ_SEG_PIXELS = TQ_P * WAVE;         // 256
+
+template <bool SMALL_M>
+__global__ __launch_bounds__(QL_THREADS) void k_query_tiled(
+    uint64_t n, uint32_t nframes, const FrameTable tab, Seeds seeds,
+    const uint32_t *__restrict__ filters, uint64_t filter_stride_words32, uint32_t tile_words /* multiple of 4 */,
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    const bool live = seg < nseg;
+    const uint64_t base = seg * TQ_SEG_PIXELS;
+    uint64_t h1[TQ_P], h2[TQ_P], ha[TQ_P];
+    uint32_t validmask = 0;
+#pragma unroll
+    for (int it = 0; it < TQ_P; ++it) {
+        const uint64_t i = base + (uint64_t)it * WAVE + lane;
+        const bool act = live && i < n;
+        const Hash3 h = hash3_index((uint32_t)i, act, seeds);
+        h1[it] = act ? h.h1 : 0; h2[it] = act ? h.h2 : 0; ha[it] = act ? h.ha : ~0ull;
+        validmask |= act ? 1u << it : 0u;
+    }
+    for (uint32_t f = 0; f < nframes; ++f) {
+        const FrameDev fd = tab.f[f];
+        if (fd.m == 0) {                                          // passthrough frame (block-uniform)
+            if (live && lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = 0;
+            if (live && lane < TQ_P) pass_words[((uint64_t)f * nseg + seg) * TQ_P + lane] = 0;
+            continue;
+        }
+        const uint32_t m = __builtin_amdgcn_readfirstlane(fd.m);
+        const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
+        const uint32_t Mh = __builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32));
+        const uint32_t Ml = __builtin_amdgcn_readfirstlane((uint32_t)fd.M);
+        const uint32_t Thi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.T >> 32));
+        const uint32_t Tlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.T);
+        const uint64_t T = ((uint64_t)Thi << 32) | Tlo, M = ((uint64_t)Mh << 32) | Ml;
+        const uint32_t fwords = (m + 31u) >> 5;
+        uint32_t pos0[TQ_P], step[TQ_P], acc[TQ_P];
+#pragma unroll
+        for (int it = 0; it < TQ_P; ++it) {
+            if (SMALL_M) { pos0[it] = mod_m_small(h1[it], m, m << 1, Mh, Ml); step[it] = mod_m_small(h2[it], m, m << 1, Mh, Ml); }
+            else         { pos0[it] = mod_m(h1[it], m, M);                     step[it] = mod_m(h2[it], m, M); }
+            acc[it] = (validmask >> it) << 31;
+        }
+        for (uint32_t tile0 = 0; tile0 < fwords; tile0 += tile_words) {
+            const uint32_t words = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
+            __syncthreads();                                      // previous tile's probes are done
+            dma_filter(lds, filters + (uint64_t)f * filter_stride_words32 + tile0, words, wave, lane, nwaves);
+            dma_wait_all();
+            __syncthreads();
+            const uint32_t bit0 = tile0 << 5, nbits = words << 5;
+#pragma unroll
+            for (int it = 0; it < TQ_P; ++it) {
+                uint32_t pos = pos0[it];
+                for (uint32_t j = 0; j <= fk; ++j) {               // j == fk: the activated extra probe
+                    const uint32_t rel = pos - bit0;
+                    const bool in = rel < nbits && (j < fk || ha[it] < T);
+                    const uint32_t w = lds[in ? rel >> 5 : 0u];
+                    acc[it] &= in ? w << ((pos ^ 24u) & 31u) : 0x80000000u;
+                    const uint64_t s2 = (uint64_t)pos + step[it];
+                    pos = (uint32_t)(s2 >= m ? s2 - m : s2);
+                }
+            }
+        }
+        uint32_t npass = 0, pw_lo = 0, pw_hi = 0;
+#pragma unroll
+        for (int it = 0; it < TQ_P; ++it) {
+            const uint64_t pw = __ballot((int32_t)acc[it] < 0);
+            if (lane == (uint32_t)it) { pw_lo = (uint32_t)pw; pw_hi = (uint32_t)(pw >> 32); }
+            npass += __popcll(pw);
+        }
+        if (live) {
+            if (lane < TQ_P) pass_words[((uint64_t)f * nseg + seg) * TQ_P + lane] = ((uint64_t)pw_hi << 32) | pw_lo;
+            if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
+        }
     }
 }
 
