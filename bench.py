@@ -169,8 +169,8 @@ def main():
         if ktimes and ktimes["query"][1]:
             q_ms = ktimes["query"][0] / ktimes["query"][1]
             achieved = alg_bytes / (q_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_query", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+            out["roofline"] = {"bound": "hbm", "kernel": "k_query_lds", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(W, H, F, args.bits),
                                "avg_launch_ms": round(q_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                                "bytes_per_pixel": round(alg_bytes / (pairs * n), 4)}
             out["kernels_ms_per_step"] = breakdown
@@ -185,6 +185,17 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(W, H, F, bits):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_query_traffic.json; FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs and
+    corrected as MI355X_MICROARCH.md prescribes).  Only valid for the workload it was measured on."""
+    path = os.path.join(REPO, "profiles", "r01_query_traffic.json")
+    if (W, H, F, bits) != (1920, 1080, 30, 8) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return int(json.load(f)["hbm_bytes_per_launch"])
 
 
 def cpu_baseline(res, n, nframes):
