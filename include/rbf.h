@@ -185,6 +185,19 @@ int rbf_filter_query_indices(rbf_ctx *ctx, const void *filter_dev, const rbf_fil
                              const rbf_seeds *seeds, const uint32_t *indices_dev, uint64_t count,
                              uint8_t *out_dev);
 
+/* ---- string-keyed twins  (rational_bloom_filter.py) ----------------------------------------- */
+/* Keys are arbitrary byte strings: key i = keys_dev[offsets_dev[i] .. offsets_dev[i+1]) (count+1
+ * uint32 offsets).  standard_k == 0: RationalBloomFilter.add / contains (rational_bloom_filter.py:
+ * 139-182; seeds (0, 1, ceil(k*))); standard_k > 0: StandardBloomFilter.add / contains (:29-41), k
+ * independent hashes XXH64(key, seed=j) % m (params->m; floor_k / threshold / seeds unused). */
+int rbf_filter_insert_keys(rbf_ctx *ctx, void *filter_dev, const rbf_filter_params *params,
+                           const rbf_seeds *seeds, uint32_t standard_k,
+                           const uint8_t *keys_dev, const uint32_t *offsets_dev, uint64_t count);
+int rbf_filter_query_keys(rbf_ctx *ctx, const void *filter_dev, const rbf_filter_params *params,
+                          const rbf_seeds *seeds, uint32_t standard_k,
+                          const uint8_t *keys_dev, const uint32_t *offsets_dev, uint64_t count,
+                          uint8_t *out_dev);
+
 /* ---- A2 / A8: changed-value gather / scatter  (:811-842, :886-903) ------------------------ */
 /* Gather, in raster order, the `channels` samples of every pixel whose mask bit is 1 out of
  * an interleaved frame (sample c of pixel (x,y) at base + y*row_pitch + x*pixel_stride + c*sample_bytes)

@@ -7,6 +7,8 @@ __version__ = "0.1.0"
 
 _LAZY = {
     "RationalBloomFilter": "rational_bloom_filter",
+    "StringRationalBloomFilter": "rational_bloom_filter",
+    "StandardBloomFilter": "rational_bloom_filter",
     "BloomFilterCompressor": "bloom_compressor",
     "VideoFrameCompressor": "frame_codec",
     "FixedVideoCompressor": "frame_codec",

@@ -62,6 +62,8 @@ _PROTOS = {
                                       ctypes.POINTER(Seeds), _vp, _u64]),
     "rbf_filter_insert_indices": (_int, [_vp, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(Seeds), _vp, _u64]),
     "rbf_filter_query_indices": (_int, [_vp, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(Seeds), _vp, _u64, _vp]),
+    "rbf_filter_insert_keys": (_int, [_vp, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(Seeds), _u32, _vp, _vp, _u64]),
+    "rbf_filter_query_keys": (_int, [_vp, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(Seeds), _u32, _vp, _vp, _u64, _vp]),
     "rbf_gather_values": (_int, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rbf_scatter_values": (_int, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _vp, _vp]),
 }

@@ -827,6 +827,47 @@ int rbf_filter_query_indices(rbf_ctx *ctx, const void *filter_dev, const rbf_fil
     return RBF_OK;
 }
 
+int rbf_filter_insert_keys(rbf_ctx *ctx, void *filter_dev, const rbf_filter_params *params,
+                           const rbf_seeds *seeds, uint32_t standard_k,
+                           const uint8_t *keys_dev, const uint32_t *offsets_dev, uint64_t count)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!filter_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
+    FrameDev fd;
+    if (int r = one_frame(params, &fd)) return r;
+    if (standard_k > 64) return fail(RBF_ERANGE, "standard_k %u > 64", standard_k);
+    if (count == 0) return RBF_OK;
+    if (!keys_dev || !offsets_dev) return fail(RBF_EINVAL, "null key arrays");
+    {
+        LaunchTimer t(ctx, RBF_K_INDEX);
+        hipLaunchKernelGGL(k_keys<true>, dim3(index_grid(count)), dim3(WG_THREADS), 0, ctx->stream,
+                           (uint32_t *)filter_dev, fd, Seeds{seeds->h1, seeds->h2, seeds->act}, standard_k, keys_dev, offsets_dev, count, (uint8_t *)nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
+int rbf_filter_query_keys(rbf_ctx *ctx, const void *filter_dev, const rbf_filter_params *params,
+                          const rbf_seeds *seeds, uint32_t standard_k,
+                          const uint8_t *keys_dev, const uint32_t *offsets_dev, uint64_t count,
+                          uint8_t *out_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!filter_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
+    FrameDev fd;
+    if (int r = one_frame(params, &fd)) return r;
+    if (standard_k > 64) return fail(RBF_ERANGE, "standard_k %u > 64", standard_k);
+    if (count == 0) return RBF_OK;
+    if (!keys_dev || !offsets_dev || !out_dev) return fail(RBF_EINVAL, "null pointer");
+    {
+        LaunchTimer t(ctx, RBF_K_INDEX);
+        hipLaunchKernelGGL(k_keys<false>, dim3(index_grid(count)), dim3(WG_THREADS), 0, ctx->stream,
+                           (uint32_t *)filter_dev, fd, Seeds{seeds->h1, seeds->h2, seeds->act}, standard_k, keys_dev, offsets_dev, count, out_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // A2 / A8
 // ------------------------------------------------------------------------------------------

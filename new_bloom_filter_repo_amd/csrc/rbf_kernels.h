@@ -252,6 +252,89 @@ __global__ __launch_bounds__(WG_THREADS) void k_index_query(
 }
 
 // ------------------------------------------------------------------------------------------
+// string-keyed twins (rational_bloom_filter.py): keys are arbitrary byte strings, so the whole XXH64
+// algorithm is needed (stripe loop for >= 32 bytes).  One thread per key; byte loads (keys are short).
+//   standard_k == 0 : RationalBloomFilter.add / contains  (:139-182), double hashing + activation
+//   standard_k  > 0 : StandardBloomFilter.add / contains  (:29-41), k hashes with seed = j, `% m`
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t load_le(const uint8_t *p, int nbytes)
+{
+    uint64_t v = 0;
+    for (int b = 0; b < nbytes; ++b) v |= (uint64_t)p[b] << (8 * b);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t xxh_round(uint64_t acc, uint64_t input)
+{
+    acc += input * P2;
+    return rotl64(acc, 31) * P1;
+}
+
+__device__ inline uint64_t xxh64_bytes(const uint8_t *p, uint32_t len, uint64_t seed)
+{
+    const uint8_t *end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 = xxh_round(v1, load_le(p, 8)); p += 8;
+            v2 = xxh_round(v2, load_le(p, 8)); p += 8;
+            v3 = xxh_round(v3, load_le(p, 8)); p += 8;
+            v4 = xxh_round(v4, load_le(p, 8)); p += 8;
+        } while (p + 32 <= end);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = (h ^ xxh_round(0, v1)) * P1 + P4;
+        h = (h ^ xxh_round(0, v2)) * P1 + P4;
+        h = (h ^ xxh_round(0, v3)) * P1 + P4;
+        h = (h ^ xxh_round(0, v4)) * P1 + P4;
+    } else {
+        h = seed + P5;
+    }
+    h += (uint64_t)len;
+    while (p + 8 <= end) { h ^= xxh_round(0, load_le(p, 8)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= load_le(p, 4) * P1; h = rotl64(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (uint64_t)(*p) * P5; h = rotl64(h, 11) * P1; ++p; }
+    h ^= h >> 33; h *= P2;
+    h ^= h >> 29; h *= P3;
+    h ^= h >> 32;
+    return h;
+}
+
+template <bool INSERT>
+__global__ __launch_bounds__(WG_THREADS) void k_keys(
+    uint32_t *__restrict__ filt, FrameDev fd, Seeds seeds, uint32_t standard_k,
+    const uint8_t *__restrict__ bytes, const uint32_t *__restrict__ offsets, uint64_t count, uint8_t *__restrict__ out)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *key = bytes + offsets[t];
+        const uint32_t len = offsets[t + 1] - offsets[t];
+        bool pass = true;
+        if (standard_k) {
+            for (uint32_t j = 0; j < standard_k; ++j) {
+                const uint32_t pos = mod_m(xxh64_bytes(key, len, (uint64_t)j), fd.m, fd.M);
+                if (INSERT) atomicOr(&filt[pos >> 5], msb_bit(pos));
+                else pass = pass && ((filt[pos >> 5] >> msb_pos(pos)) & 1u);
+            }
+        } else {
+            Probe p;
+            p.pos = mod_m(xxh64_bytes(key, len, seeds.h1), fd.m, fd.M);
+            p.step = mod_m(xxh64_bytes(key, len, seeds.h2), fd.m, fd.M);
+            p.extra = xxh64_bytes(key, len, seeds.act) < fd.T;
+            for (uint32_t j = 0; j < fd.floor_k; ++j) {
+                if (INSERT) atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+                else pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
+                advance(p, fd.m);
+            }
+            if (p.extra) {
+                if (INSERT) atomicOr(&filt[p.pos >> 5], msb_bit(p.pos));
+                else pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
+            }
+        }
+        if (!INSERT) out[t] = pass ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // A2 / A8  changed-value gather / scatter in raster order (:811-842, :886-903)
 // ------------------------------------------------------------------------------------------
 // segment popcounts of a packed mask (one wave per segment)

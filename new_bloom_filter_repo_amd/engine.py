@@ -170,6 +170,33 @@ class DeviceFilter:
         ib.free(); ob.free()
         return out
 
+    def _keys(self, items):
+        keys = [str(x).encode("utf-8") for x in items]
+        offs = np.zeros(len(keys) + 1, dtype=np.uint32)
+        offs[1:] = np.cumsum([len(k) for k in keys])
+        blob = np.frombuffer(b"".join(keys) + b"\0" * 8, dtype=np.uint8)
+        return self.ctx.alloc(blob.nbytes).upload(blob), self.ctx.alloc(offs.nbytes).upload(offs), len(keys)
+
+    def insert_keys(self, items, floor_k, threshold, seeds, standard_k=0):
+        """String keys str(item) (rational_bloom_filter.py add); standard_k > 0 = StandardBloomFilter."""
+        if len(items) == 0:
+            return
+        kb, ob, cnt = self._keys(items)
+        p, sd = self._params(floor_k, threshold), nat.Seeds(*[int(s) for s in seeds])
+        nat.check(nat.lib().rbf_filter_insert_keys(self.ctx.handle, self.buf.ptr, ctypes.byref(p), ctypes.byref(sd), int(standard_k), kb.ptr, ob.ptr, cnt))
+        kb.free(); ob.free()
+
+    def query_keys(self, items, floor_k, threshold, seeds, standard_k=0):
+        if len(items) == 0:
+            return np.zeros(0, dtype=bool)
+        kb, ob, cnt = self._keys(items)
+        out = self.ctx.alloc(cnt)
+        p, sd = self._params(floor_k, threshold), nat.Seeds(*[int(s) for s in seeds])
+        nat.check(nat.lib().rbf_filter_query_keys(self.ctx.handle, self.buf.ptr, ctypes.byref(p), ctypes.byref(sd), int(standard_k), kb.ptr, ob.ptr, cnt, out.ptr))
+        res = out.download(cnt).astype(bool)
+        kb.free(); ob.free(); out.free()
+        return res
+
     def bits(self):
         """np.uint8[m], one byte per bit (the reference's `bit_array`)."""
         return np.unpackbits(self.buf.download(self.nbytes))[:self.m]

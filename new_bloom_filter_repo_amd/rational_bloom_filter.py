@@ -62,3 +62,84 @@ def _as_indices(indices):
     if a.size and (a.min() < 0 or a.max() > 0xFFFFFFFF):
         raise ValueError("indices must fit in uint32")
     return a.astype(np.uint32)
+
+
+class StringRationalBloomFilter:
+    """rational_bloom_filter.RationalBloomFilter (rational_bloom_filter.py:74-214): string keys,
+    seeds (0, 1) and activation seed ceil(k*); add / contains (+ list forms add_many / contains_many)."""
+
+    def __init__(self, m, k_star, ctx=None):
+        self.size = int(m)
+        self.k_star = k_star
+        self.floor_k = math.floor(k_star)
+        self.ceil_k = math.ceil(k_star)
+        self.p_activation = k_star - self.floor_k
+        self.h1_seed, self.h2_seed = 0, 1
+        _fk, self._threshold = P.activation_threshold(k_star)
+        self._dev = DeviceFilter(ctx or nat.default_context(), self.size)
+
+    @property
+    def _seeds(self):
+        return (self.h1_seed, self.h2_seed, self.ceil_k)
+
+    def add(self, item):
+        self.add_many([item])
+
+    def contains(self, item):
+        return bool(self.contains_many([item])[0])
+
+    def add_many(self, items):
+        self._dev.insert_keys(list(items), self.floor_k, self._threshold, self._seeds)
+
+    def contains_many(self, items):
+        return self._dev.query_keys(list(items), self.floor_k, self._threshold, self._seeds)
+
+    @property
+    def bit_array(self):
+        return self._dev.bits().tolist()
+
+    @staticmethod
+    def get_optimal_size(n, p):
+        return int(math.ceil(-(n * math.log(p)) / (math.log(2) ** 2)))
+
+    @staticmethod
+    def get_optimal_hash_count(m, n):
+        return max(0.1, (m / n) * math.log(2))
+
+
+class StandardBloomFilter:
+    """rational_bloom_filter.StandardBloomFilter (rational_bloom_filter.py:9-71): k independent
+    hashes XXH64(str(item), seed=j) % m."""
+
+    def __init__(self, m, k, ctx=None):
+        self.size = int(m)
+        self.hash_count = int(k)
+        self._dev = DeviceFilter(ctx or nat.default_context(), self.size)
+
+    def add(self, item):
+        self.add_many([item])
+
+    def contains(self, item):
+        return bool(self.contains_many([item])[0])
+
+    def add_many(self, items):
+        if self.hash_count > 0:
+            self._dev.insert_keys(list(items), 0, 0, (0, 0, 0), standard_k=self.hash_count)
+
+    def contains_many(self, items):
+        items = list(items)
+        if self.hash_count <= 0:
+            return np.ones(len(items), dtype=bool)          # no hash functions: `all([])` is True
+        return self._dev.query_keys(items, 0, 0, (0, 0, 0), standard_k=self.hash_count)
+
+    @property
+    def bit_array(self):
+        return self._dev.bits().tolist()
+
+    @staticmethod
+    def get_optimal_size(n, p):
+        return int(math.ceil(-(n * math.log(p)) / (math.log(2) ** 2)))
+
+    @staticmethod
+    def get_optimal_hash_count(m, n):
+        return max(1, int(round((m / n) * math.log(2))))

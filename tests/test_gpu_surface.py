@@ -149,3 +149,49 @@ def test_sharded_encode_single_rank_container(ctx):
         assert all(np.array_equal(a, np.asarray(getattr(b, "data", b))) for a, b in zip(frames, dec))
     finally:
         dist.destroy_process_group()
+
+
+def test_string_keyed_filters_match_reference_fixture(ctx):
+    """rational_bloom_filter.py twins (arbitrary string keys, full XXH64 on the device) vs fixture G6,
+    incl. the reference's own `test_small_example` arrays under random.seed(42)."""
+    import math
+    g = load_json("g6_string_filters.json")
+    s = g["small"]
+    k = float.fromhex(s["k_star_hex"])
+    f1 = pkg.StandardBloomFilter(s["m"], math.floor(k), ctx=ctx)
+    f2 = pkg.StandardBloomFilter(s["m"], math.ceil(k), ctx=ctx)
+    f3 = pkg.StringRationalBloomFilter(s["m"], k, ctx=ctx)
+    for e in s["elements"]:
+        f1.add(e); f2.add(e); f3.add(e)
+    assert f1.bit_array == s["std_floor"] == [0, 1, 1, 0, 0, 0, 1, 0, 0, 0]
+    assert f2.bit_array == s["std_ceil"] == [0, 1, 1, 1, 1, 0, 1, 1, 0, 1]
+    assert f3.bit_array == s["rational"] == [0, 1, 1, 0, 0, 1, 1, 1, 0, 0]
+    assert [int(x) for x in f1.contains_many(s["tests"])] == s["std_floor_contains"]
+    assert [int(x) for x in f2.contains_many(s["tests"])] == s["std_ceil_contains"]
+    assert [int(x) for x in f3.contains_many(s["tests"])] == s["rational_contains"]
+    assert f3.contains(s["elements"][0]) is True
+    b = g["big"]
+    k = float.fromhex(b["k_star_hex"])
+    assert pkg.StringRationalBloomFilter.get_optimal_hash_count(b["m"], b["n"]) == k
+    f = pkg.StringRationalBloomFilter(b["m"], k, ctx=ctx)
+    sf = pkg.StandardBloomFilter(b["m"], b["std_k"], ctx=ctx)
+    f.add_many(b["elements"]); sf.add_many(b["elements"])
+    assert np.packbits(np.array(f.bit_array, dtype=np.uint8)).tobytes().hex() == b["rational_packed_hex"]
+    assert np.packbits(np.array(sf.bit_array, dtype=np.uint8)).tobytes().hex() == b["std_packed_hex"]
+    assert [int(x) for x in f.contains_many(b["tests"])] == b["rational_contains"]
+    assert [int(x) for x in sf.contains_many(b["tests"])] == b["std_contains"]
+
+
+def test_device_xxh64_all_lengths(ctx):
+    """Device XXH64 over byte strings of every length class (0..100 bytes, the >= 32-byte stripe loop
+    included), checked through a 2^31-bit-free trick: a 1-hash standard filter of prime size."""
+    rows = [r for r in load_json("g1_xxh64.json")["rows"] if r[1] == 0]
+    m = 1000003
+    sf = pkg.StandardBloomFilter(m, 1, ctx=ctx)
+    keys = [r[0] for r in rows]
+    sf.add_many(keys)
+    bits = np.array(sf.bit_array, dtype=np.uint8)
+    want = np.zeros(m, dtype=np.uint8)
+    for r in rows:
+        want[r[2] % m] = 1
+    assert np.array_equal(bits, want)
