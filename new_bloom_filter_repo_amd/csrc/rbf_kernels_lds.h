@@ -104,14 +104,18 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
         }
     };
 
-    for (uint64_t g = g0 + wave; g < g1; g += IL_WAVES) {
+    auto load_bits = [&](uint64_t g) -> uint32_t {                 // my byte of wave step g in natural bit order
         const uint64_t byte = g * 64 + lane;
-        uint32_t bits = 0;
-        if (byte < nbytes) {
-            bits = __builtin_bitreverse32((uint32_t)mask[byte]) >> 24;       // natural order
-            const uint64_t rem = n - byte * 8;
-            if (rem < 8) bits &= (1u << rem) - 1u;
-        }
+        if (g >= g1 || byte >= nbytes) return 0u;
+        uint32_t b = __builtin_bitreverse32((uint32_t)mask[byte]) >> 24;
+        const uint64_t rem = n - byte * 8;
+        if (rem < 8) b &= (1u << rem) - 1u;                        // ignore pad bits
+        return b;
+    };
+    uint32_t nxt = load_bits(g0 + wave);
+    for (uint64_t g = g0 + wave; g < g1; g += IL_WAVES) {
+        uint32_t bits = nxt;
+        nxt = load_bits(g + IL_WAVES);                             // prefetch: the load flies while we hash
         const uint32_t c = __popc(bits);
         uint32_t incl = c;
 #pragma unroll
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
         }
         const uint32_t total = __shfl(incl, WAVE - 1);
         uint32_t off = qn + incl - c;
-        const uint32_t base = (uint32_t)(byte << 3);
+        const uint32_t base = (uint32_t)((g * 64 + lane) << 3);
         while (bits) {
             q[off++] = base + __builtin_ctz(bits);
             bits &= bits - 1u;

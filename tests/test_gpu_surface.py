@@ -195,3 +195,42 @@ def test_device_xxh64_all_lengths(ctx):
     for r in rows:
         want[r[2] % m] = 1
     assert np.array_equal(bits, want)
+
+
+def test_gop_coder_edge_cases(ctx, oracle):
+    """rbf_encode_gop: identical frames (all passthrough), mixed densities incl. p >= P*, a 2-frame GOP,
+    and a batch of more than 128 inter-frames (split into kernel-argument-sized chunks on the host)."""
+    from new_bloom_filter_repo_amd.gop import GopCoder
+
+    def check(frames, expect_pass=None):
+        F, H, W = frames.shape[:3]
+        n = H * W
+        coder = GopCoder(ctx, W, H, F)
+        coder.load_frames(frames)
+        coder.encode()
+        res = coder.results()
+        assert len(res) == F - 1
+        for f, r in enumerate(res):
+            want_mask = oracle.residual_mask(frames[f][:, :, 0], frames[f + 1][:, :, 0], 0.0).reshape(-1)
+            assert np.array_equal(np.unpackbits(r["mask"])[:n], want_mask) and r["ones"] == int(want_mask.sum())
+            bm, wit, p, _, _ = oracle.compress(want_mask)
+            if len(wit) == 0:                                   # the reference would not Bloom-code this frame
+                assert r["l"] == 0 and r["witness_bits"] == 0
+                continue
+            k, l = oracle.optimal_params(n, p)
+            assert (r["k"], r["l"]) == (k, l)
+            assert np.array_equal(np.unpackbits(r["filter"])[:l], bm)
+            assert r["witness_bits"] == len(wit) and r["filter_ones"] == int(bm.sum())
+            assert np.array_equal(np.unpackbits(r["witness"])[:len(wit)], np.array(wit, dtype=np.uint8))
+        if expect_pass is not None:
+            assert [r["l"] == 0 for r in res] == expect_pass
+
+    base = make_gop(31, 64, 48, 1)[0]
+    check(np.stack([base, base, base]), [True, True])                                   # nothing changes
+    rng = np.random.default_rng(5)
+    frames = [base]
+    for p in (0.05, 0.5, 0.0, 0.2, 0.9, 0.001):
+        frames.append(next_frame(rng, frames[-1], p) if p else frames[-1].copy())
+    check(np.stack(frames), [False, True, True, False, True, False])
+    check(np.stack(make_gop(32, 40, 24, 2, p=0.1)))                                       # a single pair
+    check(np.stack(make_gop(33, 32, 16, 140, p=0.08)))                                    # 139 inter-frames > 128
