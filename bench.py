@@ -29,8 +29,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=30, help="frames per GOP (frames-1 inter-frames are coded)")
@@ -199,25 +199,27 @@ def measured_traffic(W, H, F, bits):
 
 
 def cpu_baseline(res, n, nframes):
-    """CPU oracle (scalar C port, oracle/rbf_oracle.c) on the same masks: insert + query/witness."""
+    """CPU oracle (scalar C port of the reference loops, oracle/rbf_oracle.c) on the step's own masks:
+    residual mask is not included (numpy-trivial); insert + query/witness, one core, >= ~10 s of work."""
     import ctypes
     from oracle import oracle as orc
     L = orc.lib()
     seeds = (ctypes.c_uint64 * 3)(*orc.SEEDS_VIDEO)
-    nframes = nframes or min(len(res), 29)
-    t_total, px = 0.0, 0
-    for r in res[:nframes]:
-        mask = np.unpackbits(r["mask"])[:n]
-        if r["l"] == 0:
-            continue
-        bit_array = np.zeros(r["l"], dtype=np.uint8)
-        witness = np.zeros(n, dtype=np.uint8)
-        t0 = time.perf_counter()
-        L.orc_compress(mask.ctypes.data, n, r["l"], ctypes.c_double(r["k"]), seeds, bit_array.ctypes.data, witness.ctypes.data)
-        t_total += time.perf_counter() - t0
-        px += n
+    frames = [r for r in res[:nframes or len(res)] if r["l"]]
+    masks = [np.unpackbits(r["mask"])[:n] for r in frames]
+    t_total, px, passes = 0.0, 0, 0
+    while t_total < 10.0 and passes < 6:
+        for r, mask in zip(frames, masks):
+            bit_array = np.zeros(r["l"], dtype=np.uint8)
+            witness = np.zeros(n, dtype=np.uint8)
+            t0 = time.perf_counter()
+            L.orc_compress(mask.ctypes.data, n, r["l"], ctypes.c_double(r["k"]), seeds, bit_array.ctypes.data, witness.ctypes.data)
+            t_total += time.perf_counter() - t0
+            px += n
+        passes += 1
     return {"value": round(px / t_total / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
-            "sample": "%d of the step's 1080p masks, insert+query/witness in the scalar C oracle, %.1f s" % (nframes, t_total),
+            "sample": "%d passes over the step's %d masks (%d pixels each), insert+query/witness in the scalar C oracle, %.1f s"
+                      % (passes, len(frames), n, t_total),
             "reference_python_mpixels_per_s": 0.38}
 
 

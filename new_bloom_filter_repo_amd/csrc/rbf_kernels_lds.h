@@ -365,7 +365,8 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
             filt = lds + cur * bufwords;
             if (fn < nframes && !(AB & 8))
                 dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
-                           (tab.f[fn].m + 31u) >> 5, wave, lane, nwaves);
+                           ((tab.f[fn].m + 31u) >> 5) >> ((AB & 128) ? 1 : 0), wave, (AB & 256) ? (wave < 4 ? lane : 64u) : lane,
+                           (AB & 256) ? 4u : nwaves);
             cur ^= 1u;
         } else {
             __syncthreads();          // previous frame's probes are done

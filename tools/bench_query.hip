@@ -57,6 +57,8 @@ int main()
     RUN(64, "no staging flush");
     RUN(32 | 64, "no barrier, no flush");
     RUN(32 | 64 | 8, "no barrier, no flush, no DMA");
+    RUN(128, "DMA of half the filter (WRONG RESULTS)");
+    RUN(256, "DMA issued by 4 waves only");
     RUN(16, "no hashing");
     RUN(1, "no reductions (mod m)");
     RUN(2, "no LDS probes");
