@@ -338,23 +338,29 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     }
 
     // passthrough frames (m == 0): nothing passes
-    uint32_t f = nframes;
-    for (uint32_t g = nframes; g-- > 0;) {
+    for (uint32_t g = 0; g < nframes; ++g) {
         if (tab.f[g].m == 0) {
             if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
             if (live && lane < QL_P) pass_words[((uint64_t)g * nseg + seg) * QL_P + lane] = 0;
-        } else {
-            f = g;                                                // ends as the FIRST active frame
         }
     }
+    // Every workgroup walks the frames in the same order: all CUs then pull the same 76 KB filter at
+    // about the same time, which the L2 serves best (measured: rotating the start frame per workgroup,
+    // AB & 512, so that ~29 different filters are in flight costs +11 us per launch).
+    const uint32_t rot = (AB & 512) ? blockIdx.x % nframes : 0u;
+    auto frame_at = [&](uint32_t k) -> uint32_t { const uint32_t g = k + rot; return g >= nframes ? g - nframes : g; };
+    auto next_active = [&](uint32_t k) -> uint32_t { while (k < nframes && tab.f[frame_at(k)].m == 0) ++k; return k; };
+    uint32_t k = next_active(0);
     uint32_t cur = 0;
-    if (DOUBLE_BUFFER && f < nframes && !(AB & 8))
-        dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (tab.f[f].m + 31u) >> 5, wave, lane, nwaves);
-    while (f < nframes) {
-        f = __builtin_amdgcn_readfirstlane(f);                    // frame indices are wave-uniform: scalar table loads
-        uint32_t fn = f + 1;
-        while (fn < nframes && tab.f[fn].m == 0) ++fn;               // next active frame
-        fn = __builtin_amdgcn_readfirstlane(fn);
+    if (DOUBLE_BUFFER && k < nframes && !(AB & 8)) {
+        const uint32_t f0 = frame_at(k);
+        dma_filter(lds, filters + (uint64_t)f0 * filter_stride_words32, (tab.f[f0].m + 31u) >> 5, wave, lane, nwaves);
+    }
+    while (k < nframes) {
+        k = __builtin_amdgcn_readfirstlane(k);                    // frame indices are wave-uniform: scalar table loads
+        const uint32_t kn = __builtin_amdgcn_readfirstlane(next_active(k + 1));
+        const uint32_t f = __builtin_amdgcn_readfirstlane(frame_at(k));
+        const uint32_t fn = __builtin_amdgcn_readfirstlane(kn < nframes ? frame_at(kn) : 0u);
         const FrameDev fd = tab.f[f];
         const uint32_t *filt;
         if (DOUBLE_BUFFER) {
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
                 __syncthreads();      // ... and everyone's; buffer cur^1 is free again
             }
             filt = lds + cur * bufwords;
-            if (fn < nframes && !(AB & 8))
+            if (kn < nframes && !(AB & 8))
                 dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
                            ((tab.f[fn].m + 31u) >> 5) >> ((AB & 128) ? 1 : 0), wave, (AB & 256) ? (wave < 4 ? lane : 64u) : lane,
                            (AB & 256) ? 4u : nwaves);
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
             if (lane < QL_P) pass_words[((uint64_t)f * nseg + seg) * QL_P + lane] = ((uint64_t)pw_hi << 32) | pw_lo;
             if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
         }
-        f = fn;
+        k = kn;
     }
 }
 

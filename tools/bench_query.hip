@@ -57,6 +57,7 @@ int main()
     RUN(64, "no staging flush");
     RUN(32 | 64, "no barrier, no flush");
     RUN(32 | 64 | 8, "no barrier, no flush, no DMA");
+    RUN(512, "frame order rotated per workgroup");
     RUN(128, "DMA of half the filter (WRONG RESULTS)");
     RUN(256, "DMA issued by 4 waves only");
     RUN(16, "no hashing");
