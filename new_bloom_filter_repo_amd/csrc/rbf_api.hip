@@ -606,9 +606,8 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     // ---- witness: pext(mask, pass) of every word lands at its bit offset (scan fused in)
     {
         const uint64_t words = pl.nseg * pl.words_per_seg;
-        uint64_t bx = (words + WG_THREADS - 1) / WG_THREADS;
+        uint64_t bx = (words + WG_THREADS * CW_CHUNKS - 1) / (WG_THREADS * CW_CHUNKS);
         if (bx < 1) bx = 1;
-        if (bx > 8192) bx = 8192;
         LaunchTimer t(ctx, RBF_K_STITCH);
         hipLaunchKernelGGL(k_compact_witness, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                            ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
