@@ -253,11 +253,27 @@ __device__ __forceinline__ void dma_filter(uint32_t *lds_dst, const uint32_t *sr
 }
 
 // v_writelane_b32: put a wave-uniform value into ONE lane of a VGPR (no builtin in this hipcc).
+// The value must not be an SGPR a VALU instruction wrote in the last 5 wait states (the ballot!):
+// hipcc pads no hazards inside asm, and without the wait v_writelane reads the PREVIOUS value --
+// caught by the parity tests.  Callers batch their writelanes behind one valu_sgpr_hazard_gap().
+// The gap takes the SGPR values as in/out operands: "memory" alone would not stop hipcc from sinking
+// a register-only ballot below the s_nop (guide rule 18), so the values are threaded THROUGH the asm.
+__device__ __forceinline__ void valu_sgpr_hazard_gap(uint32_t (&a)[8], uint32_t (&b)[8])
+{
+    asm volatile("" : "+s"(a[0]), "+s"(a[1]), "+s"(a[2]), "+s"(a[3]), "+s"(a[4]), "+s"(a[5]), "+s"(a[6]), "+s"(a[7]));
+    asm volatile("s_nop 4" : "+s"(b[0]), "+s"(b[1]), "+s"(b[2]), "+s"(b[3]), "+s"(b[4]), "+s"(b[5]), "+s"(b[6]), "+s"(b[7]));
+}
 __device__ __forceinline__ void write_lane(uint32_t &dst, uint32_t uniform_value, int lane_index)
 {
-    // s_nop 4: the ballot is a VALU-written SGPR; hipcc pads no hazards inside asm (without the wait
-    // states v_writelane reads the previous value -- caught by the parity tests)
-    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(uniform_value), "n"(lane_index));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(uniform_value), "n"(lane_index));
+}
+
+// LDS dword holding filter bit `pos`: (pos >> 5) * 4 + base in two instructions (v_bfe_u32 +
+// v_lshl_add_u32); written plainly the compiler folds it to shift / and / add.
+__device__ __forceinline__ uint32_t probe_word(const uint32_t *filt, uint32_t pos)
+{
+    const uint32_t w = __builtin_amdgcn_ubfe(pos, 5, 27);
+    return filt[w];
 }
 
 // One frame's pass over a wave's QL_P x 64 pixels: reductions mod m, LDS probes, ballot.
@@ -275,6 +291,7 @@ __device__ __forceinline__ uint32_t frame_pass(
     const uint32_t fk = FK >= 0 ? (uint32_t)FK : fk_rt;
     const uint32_t m2 = m << 1;
     uint32_t npass = 0;
+    uint64_t pw[QL_P];
 #pragma unroll
     for (int it = 0; it < QL_P; ++it) {
         uint32_t pos, step;
@@ -286,17 +303,26 @@ __device__ __forceinline__ uint32_t frame_pass(
         uint32_t acc = (validmask >> it) << 31;
 #pragma unroll
         for (uint32_t j = 0; j < fk; ++j) {
-            acc &= ((AB & 2) ? (pos * 0x9E3779B1u) : filt[pos >> 5]) << ((pos ^ 24u) & 31u);
+            acc &= ((AB & 2) ? (pos * 0x9E3779B1u) : probe_word(filt, pos)) << ((pos ^ 24u) & 31u);
             if (SMALL_M) { const uint32_t s2 = pos + step; pos = min(s2, s2 - m); }
             else { const uint64_t s2 = (uint64_t)pos + step; pos = (uint32_t)(s2 >= m ? s2 - m : s2); }
         }
-        const uint32_t x = ((AB & 2) ? (pos * 0x85EBCA77u) : filt[pos >> 5]) << ((pos ^ 24u) & 31u);
+        const uint32_t x = ((AB & 2) ? (pos * 0x85EBCA77u) : probe_word(filt, pos)) << ((pos ^ 24u) & 31u);
         acc &= (ha[it] < T) ? x : 0x80000000u;
-        if (AB & 4) { npass += acc >> 31; continue; }
-        const uint64_t pw = __ballot((int32_t)acc < 0);
-        write_lane(pw_lo, (uint32_t)pw, it);                   // lane `it` keeps this iteration's pass word
-        write_lane(pw_hi, (uint32_t)(pw >> 32), it);
-        npass += __popcll(pw);
+        if (AB & 4) { npass += acc >> 31; pw[it] = 0; continue; }
+        pw[it] = __ballot((int32_t)acc < 0);
+        npass += __popcll(pw[it]);
+    }
+    // lane `it` keeps iteration it's pass word (one hazard gap for all the ballots above)
+    static_assert(QL_P == 8, "the hazard gap threads 8 + 8 SGPR values");
+    uint32_t lo[8], hi[8];
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) { lo[it] = (uint32_t)pw[it]; hi[it] = (uint32_t)(pw[it] >> 32); }
+    valu_sgpr_hazard_gap(lo, hi);
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) {
+        write_lane(pw_lo, lo[it], it);
+        write_lane(pw_hi, hi[it], it);
     }
     return npass;
 }
