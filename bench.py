@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=30, help="frames per GOP (frames-1 inter-frames are coded)")
     ap.add_argument("--bits", type=int, default=8, choices=(8, 16))
+    ap.add_argument("--streams", type=int, default=2, help="GOP pipelines in flight per GPU (each its own HIP stream)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and gather) even with one rank (smoke-tests the N>1 path)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-kernel HIP events in the timed region")
@@ -70,20 +71,26 @@ def main():
     W, H, F = args.width, args.height, args.frames
     n, pairs = W * H, F - 1
     dtype = np.uint8 if args.bits == 8 else np.uint16
-    stream = torch.cuda.current_stream(device)
-    ctx = nat.Context(local_rank, stream.cuda_stream)
     use_gather = use_dist and not args.no_gather
-    # two coders share the frame buffer and alternate, so that the gather of step s (async, on RCCL's
-    # stream) overlaps the kernels of step s+1; each coder's output record is ONE contiguous tensor
-    ncoders = 2 if use_gather else 1
+    # `--streams` GOP pipelines (default 2): consecutive steps alternate between them, each with its own
+    # HIP stream, library context (scratch) and output record, sharing the resident frames.  The
+    # HBM-bound mask kernel and the latency-bound compaction / reduce kernels of one step then overlap
+    # the integer-issue-bound insert / query kernels of its neighbour, and (N > 1) the async RCCL gather
+    # of step s overlaps the kernels of step s+1.  Every step still does all of its work inside the
+    # timed region.
+    ncoders = max(1, args.streams)
+    streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(ncoders - 1)]
+    ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
+    ctx = ctxs[0]
     arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
-    coders = [GopCoder(ctx, W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device), out_allocator=arenas[0])]
-    for a in arenas[1:]:
-        coders.append(GopCoder(ctx, W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
-                               out_allocator=a, frames_block=coders[0].frames))
+    coders = []
+    for k in range(ncoders):
+        coders.append(GopCoder(ctxs[k], W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
+                               out_allocator=arenas[k], frames_block=coders[0].frames if k else None))
     coder = coders[0]
     frames = np.stack(make_gop(1000 * 2 + rank, W, H, F, p=P_KSTAR_2_3, dtype=dtype))
     coder.load_frames(frames)
+    torch.cuda.synchronize(device)
 
     gather = use_gather
     pending = [None] * ncoders
@@ -94,17 +101,19 @@ def main():
     def step():
         k = state["s"] % ncoders
         state["s"] += 1
-        if pending[k] is not None:
-            pending[k].wait()                 # this coder's previous record has left (stream-side wait)
-            pending[k] = None
-        coders[k].encode()
-        if gather:
-            pending[k] = dist.gather(arenas[k].tensor, gl[k], dst=0, async_op=True)
+        with torch.cuda.stream(streams[k]):
+            if pending[k] is not None:
+                pending[k].wait()             # this pipeline's previous record has left (stream-side wait)
+                pending[k] = None
+            coders[k].encode()
+            if gather:
+                pending[k] = dist.gather(arenas[k].tensor, gl[k], dst=0, async_op=True)
 
     def drain():
         for k in range(ncoders):
             if pending[k] is not None:
-                pending[k].wait()
+                with torch.cuda.stream(streams[k]):
+                    pending[k].wait()
                 pending[k] = None
 
     for _ in range(args.warmup):
@@ -114,8 +123,9 @@ def main():
     if not args.no_kernel_timing:
         # HIP events around the DOMINANT kernel only (query): two events per step on the launching
         # stream; bracketing every kernel would add ~40 us of event overhead to a ~360 us step
-        ctx.timing_reset()
-        ctx.timing(1 << nat.K_QUERY)
+        for c in ctxs:
+            c.timing_reset()
+            c.timing(1 << nat.K_QUERY)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -130,8 +140,12 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = None
     if not args.no_kernel_timing:
-        ctx.timing(False)
-        ktimes = ctx.timing_read()
+        ktimes = {}
+        for c in ctxs:
+            c.timing(False)
+            for name, (ms, cnt) in c.timing_read().items():
+                a = ktimes.get(name, (0.0, 0))
+                ktimes[name] = (a[0] + ms, a[1] + cnt)
     if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -140,12 +154,13 @@ def main():
     breakdown = None
     if not args.no_kernel_timing:
         # per-kernel breakdown from a few extra, untimed steps with every kernel bracketed
+        torch.cuda.synchronize(device)
         ctx.timing_reset()
         ctx.timing(True)
         for _ in range(5):
             coder.encode()
         ctx.timing(False)
-        breakdown = {k: round(v[0] / 5, 4) for k, v in ctx.timing_read().items() if v[1]}
+        breakdown = {k: round(v[0] / 5, 4) for k, v in ctx.timing_read().items() if v[1]}    # one pipeline alone
 
     res = coder.results()
     pixels_per_step = pairs * n * world
@@ -158,7 +173,7 @@ def main():
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), k*=2.3, threshold 0"
                                % (W, H, args.bits, F, pairs),
-                   "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather),
+                   "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
                    "stages": "residual mask -> host params -> insert -> query+witness"},
     }
     if rank == 0:
