@@ -186,7 +186,9 @@ def main():
             achieved = alg_bytes / (q_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_query_lds", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(W, H, F, args.bits),
-                               "avg_launch_ms": round(q_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                               "avg_launch_ms": round(q_ms, 4),
+                               "avg_launch_ms_alone": (breakdown or {}).get("query"),   # same kernel, one pipeline, nothing co-running
+                               "algorithmic_bytes_per_launch": int(alg_bytes),
                                "bytes_per_pixel": round(alg_bytes / (pairs * n), 4)}
             out["kernels_ms_per_step"] = breakdown
         else:
