@@ -234,3 +234,22 @@ def test_gop_coder_edge_cases(ctx, oracle):
     check(np.stack(frames), [False, True, True, False, True, False])
     check(np.stack(make_gop(32, 40, 24, 2, p=0.1)))                                       # a single pair
     check(np.stack(make_gop(33, 32, 16, 140, p=0.08)))                                    # 139 inter-frames > 128
+
+
+def test_bloom_compress_front_ends_match_reference_bytes(ctx):
+    """bloom_compress.py image / text containers (seeds 0/1/999, '!' headers): byte-identical blobs,
+    round trips, passthrough text (density >= P*)."""
+    from new_bloom_filter_repo_amd.bloom_compress import BloomFilterCompressor as BC
+    z, meta = load_npz("g11_bloom_compress.npz"), load_json("g11_bloom_compress.json")
+    comp = BC(ctx=ctx)
+    for name in ("img", "gray"):
+        blob, ratio = comp.compress_image(z[name], 127)
+        assert blob == z[name + "_blob"].tobytes() and float(ratio).hex() == meta[name]["ratio_hex"]
+        dec = comp.decompress_image(blob)
+        want = comp._binarize_image(z[name], 127).reshape(z[name].shape[:2]) * 255
+        assert np.array_equal(dec, want) == meta[name]["roundtrip"] is True
+    for name in ("text", "sparse_text"):
+        txt = meta[name]["text"]
+        blob, ratio = comp.compress_text(txt, 8)
+        assert blob == z[name + "_blob"].tobytes() and float(ratio).hex() == meta[name]["ratio_hex"]
+        assert comp.decompress_text(blob) == txt

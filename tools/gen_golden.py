@@ -363,13 +363,42 @@ def g10():
     print("G10 container bytes", len(blob), "keys", sorted(res))
 
 
+# ------------------------------------------------------------------ G11: bloom_compress.py front-ends
+def g11():
+    comp = bc.BloomFilterCompressor()
+    rng = np.random.default_rng(11)
+    img = (rng.random((40, 56, 3)) * 90 + 60 * (rng.random((40, 56, 1)) < 0.2) * 2).astype(np.uint8)   # ~20 % above 127
+    gray = (rng.random((33, 47)) < 0.07).astype(np.uint8) * 200
+    text = "bloom filters compress sparse bit vectors; " * 7 + "\x00\x01\x02 low-density tail \x00\x00\x04\x00\x10"
+    sparse_text = "".join(chr(c) for c in rng.choice([0, 0, 0, 0, 1, 2, 4, 8, 16, 32, 64], size=600))
+    out, meta = {}, {}
+    for name, arr in (("img", img), ("gray", gray)):
+        binary = comp._binarize_image(arr, 127)
+        bm, wit, p, n, ratio = quiet(comp.compress, binary)
+        k, _ = comp._calculate_optimal_params(n, p)
+        blob = comp._pack_compressed_data(bm, wit, p, n, k, arr.shape)
+        dec = quiet(comp.decompress_image, blob)
+        out[name] = arr
+        out[name + "_blob"] = np.frombuffer(blob, dtype=np.uint8)
+        meta[name] = {"ratio_hex": float(ratio).hex(), "roundtrip": bool(np.array_equal(dec, binary.reshape(arr.shape[:2]) * 255)),
+                      "ones": int(binary.sum()), "n": int(n)}
+    for name, txt in (("text", text), ("sparse_text", sparse_text)):
+        blob, ratio = quiet(comp.compress_text, txt, 8)
+        back = quiet(comp.decompress_text, blob)
+        out[name + "_blob"] = np.frombuffer(blob, dtype=np.uint8)
+        meta[name] = {"text": txt, "ratio_hex": float(ratio).hex(), "roundtrip": back == txt}
+    np.savez_compressed(os.path.join(OUT, "g11_bloom_compress.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "g11_bloom_compress.json"), "w"), indent=1)
+    print("G11", {k: (v.get("ratio_hex"), v["roundtrip"]) for k, v in meta.items()})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true", help="skip the 2160p digest (about a minute of reference time)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     steps = {"g1": g1, "g2": g2, "g2b": g2b, "g3": g3, "g4": lambda: g4(a.skip_large), "g5": g5, "g6": g6,
-             "g7": g7_g9, "g8": g8, "g10": g10}
+             "g7": g7_g9, "g8": g8, "g10": g10, "g11": g11}
     for name, fn in steps.items():
         if a.only and name not in a.only.split(","):
             continue
