@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--frames", type=int, default=30, help="frames per GOP (frames-1 inter-frames are coded)")
     ap.add_argument("--bits", type=int, default=8, choices=(8, 16))
     ap.add_argument("--streams", type=int, default=2, help="GOP pipelines in flight per GPU (each its own HIP stream)")
+    ap.add_argument("--lds-tile-kib", type=int, default=0, help="cap the LDS filter tile (KiB) -> tiled kernels; 0 = auto (BASELINE config 4 sweep)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and gather) even with one rank (smoke-tests the N>1 path)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-kernel HIP events in the timed region")
@@ -81,6 +82,9 @@ def main():
     ncoders = max(1, args.streams)
     streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(ncoders - 1)]
     ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
+    if args.lds_tile_kib:
+        for c in ctxs:
+            c.force_generic((args.lds_tile_kib * 1024 // 256) << 16)      # knob unit: 64 dwords
     ctx = ctxs[0]
     arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
     coders = []
@@ -174,6 +178,7 @@ def main():
         "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), k*=2.3, threshold 0"
                                % (W, H, args.bits, F, pairs),
                    "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
+                   "lds_tile_kib": args.lds_tile_kib or "auto",
                    "stages": "residual mask -> host params -> insert -> query+witness"},
     }
     if rank == 0:
