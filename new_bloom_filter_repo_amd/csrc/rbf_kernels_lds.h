@@ -441,7 +441,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
 // (pixel, frame) computes its probe positions once and tests, per tile, the probes that land in it.
 // Same outputs as k_query_lds with TQ_P pass words per segment.
 // ------------------------------------------------------------------------------------------
-constexpr int TQ_P = 4;                            // fewer pixels per lane: positions stay in registers too
+constexpr int TQ_P = 8;                            // pixels per lane (more pixels per filter staging)
 constexpr int TQ_SEG_PIXELS = TQ_P * WAVE;         // 256
 
 template <bool SMALL_M>
