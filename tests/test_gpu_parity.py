@@ -190,3 +190,27 @@ def test_edge_geometries(eng, oracle):
             if len(wit):
                 dec = eng.decode(n, pl, [r["filter"]], [r["witness"]])
                 assert np.array_equal(unpack(dec[0], n), m)
+
+
+def test_adversarial_filter_lengths(eng, oracle):
+    """Reductions mod m for awkward m (tiny, powers of two +-1, primes, > 2^20 so that the tiled kernels
+    are used even by default) and k* values with extreme fractions."""
+    n = 3000
+    mask = make_mask(321, n, 0.12)
+    ones = np.flatnonzero(mask)
+    for m, k in ((2, 1.5), (3, 2.0), (4, 0.999999), (5, 3.7), (7, 1.0000001), (8, 2.5), (255, 4.25), (256, 2.3), (257, 2.3),
+                 (65535, 2.9), (65536, 2.1), (65537, 5.5), (1048575, 2.3), (1048576, 2.3), (1048577, 2.3), (1398101, 3.3),
+                 (4194303, 2.3)):
+        pl = [P.filter_params(k, m)]
+        eng.upload_masks(np.packbits(mask)[None, :], n)
+        r = eng.encode(n, pl)[0]
+        f = oracle.RationalFilter(m, k)
+        for i in ones:
+            f.add_index(int(i))
+        assert np.array_equal(unpack(r["filter"], m), f.bit_array), (m, k)
+        assert r["filter_ones"] == int(f.bit_array.sum())
+        wit = [int(mask[i]) for i in range(n) if f.check_index(i)]
+        assert r["witness_bits"] == len(wit), (m, k)
+        assert np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8)), (m, k)
+        dec = eng.decode(n, pl, [r["filter"]], [r["witness"]])
+        assert np.array_equal(unpack(dec[0], n), mask), (m, k)
