@@ -52,7 +52,9 @@ __device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t
 // ------------------------------------------------------------------------------------------
 // insert
 // ------------------------------------------------------------------------------------------
-template <bool SMALL_M>
+// IAB (ablation mask, tools/bench_insert.hip only; 0 in the library): 1 = no hashing, 2 = no LDS
+// atomics, 4 = no LDS zeroing / partial store, 8 = no queueing (mask bytes read, nothing queued).
+template <bool SMALL_M, int IAB = 0>
 __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
     const FrameTable tab, Seeds seeds,
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const uint32_t tile0 = blockIdx.z * tile_words;               // first word of my tile
     if (tile0 >= fwords) return;
     const uint32_t tile_bit0 = tile0 << 5, tile_bits = tile_words << 5;
-    for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
+    if (!(IAB & 4)) for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
     __syncthreads();
 
     const uint8_t *mask = masks + (uint64_t)f * mask_stride_bytes;
@@ -88,19 +90,21 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     auto drain_at = [&](uint32_t first, uint32_t count) {          // hash `count` (<= 64) queued positions
         const bool act = lane < count;                             // (wave-uniform call: hash3_index votes)
         const uint32_t idx = act ? q[first + lane] : 0u;
-        const Hash3 h = hash3_index(idx, act, seeds);
+        Hash3 h;
+        if (IAB & 1) { h.h1 = idx * P1; h.h2 = idx * P2 + 7; h.ha = idx * P3; }
+        else h = hash3_index(idx, act, seeds);
         if (act) {
             uint32_t pos, step;
             if (SMALL_M) { pos = mod_m_small(h.h1, m, m2, Mh, Ml); step = mod_m_small(h.h2, m, m2, Mh, Ml); }
             else         { pos = mod_m(h.h1, m, fd.M);             step = mod_m(h.h2, m, fd.M); }
             for (uint32_t j = 0; j < fd.floor_k; ++j) {
                 const uint32_t rel = pos - tile_bit0;              // unsigned: out-of-tile positions wrap high
-                if (rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
+                if (rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
                 const uint64_t s2 = (uint64_t)pos + step;
                 pos = (uint32_t)(s2 >= m ? s2 - m : s2);
             }
             const uint32_t rel = pos - tile_bit0;
-            if (h.ha < fd.T && rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
+            if (h.ha < fd.T && rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
         }
     };
 
@@ -114,17 +118,16 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     };
     uint32_t nxt = load_bits(g0 + wave);
     for (uint64_t g = g0 + wave; g < g1; g += IL_WAVES) {
-        uint32_t bits = nxt;
+        uint32_t bits = (IAB & 8) ? (nxt & 0u) : nxt;
         nxt = load_bits(g + IL_WAVES);                             // prefetch: the load flies while we hash
+        // exclusive prefix of the per-lane counts (0..8) without a cross-lane scan: one ballot per bit
+        // of the count, rank of the ballot below my lane (mbcnt), weighted sum -- no LDS round trips
         const uint32_t c = __popc(bits);
-        uint32_t incl = c;
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if (lane >= (uint32_t)d) incl += t;
-        }
-        const uint32_t total = __shfl(incl, WAVE - 1);
-        uint32_t off = qn + incl - c;
+        const uint64_t b0 = __ballot((c & 1u) != 0), b1 = __ballot((c & 2u) != 0);
+        const uint64_t b2 = __ballot((c & 4u) != 0), b3 = __ballot((c & 8u) != 0);
+        const uint32_t excl = rank_below(b0) + 2u * rank_below(b1) + 4u * rank_below(b2) + 8u * rank_below(b3);
+        const uint32_t total = __popcll(b0) + 2u * __popcll(b1) + 4u * __popcll(b2) + 8u * __popcll(b3);
+        uint32_t off = qn + excl;
         const uint32_t base = (uint32_t)((g * 64 + lane) << 3);
         while (bits) {
             q[off++] = base + __builtin_ctz(bits);
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     __syncthreads();
     uint32_t *part = partials + ((uint64_t)f * S + s) * part_stride_words32 + tile0;
     const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
-    const uint32_t pairs = (mine + 1) >> 1;                        // tile0 is even: 8-byte aligned
+    const uint32_t pairs = (IAB & 4) ? 1u : (mine + 1) >> 1;      // tile0 is even: 8-byte aligned
     for (uint32_t i = threadIdx.x; i < pairs; i += IL_THREADS)
         reinterpret_cast<uint2 *>(part)[i] = reinterpret_cast<const uint2 *>(filt)[i];
 }
