@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=30, help="frames per GOP (frames-1 inter-frames are coded)")
     ap.add_argument("--bits", type=int, default=8, choices=(8, 16))
+    ap.add_argument("--density", type=float, default=0.0, help="fraction of changed pixels per inter-frame (0 = 0.08889, i.e. k*=2.3; SURVEY 8d density sweep)")
     ap.add_argument("--streams", type=int, default=2, help="GOP pipelines in flight per GPU (each its own HIP stream)")
     ap.add_argument("--lds-tile-kib", type=int, default=0, help="cap the LDS filter tile (KiB) -> tiled kernels; 0 = auto (BASELINE config 4 sweep)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
@@ -92,7 +93,8 @@ def main():
         coders.append(GopCoder(ctxs[k], W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
                                out_allocator=arenas[k], frames_block=coders[0].frames if k else None))
     coder = coders[0]
-    frames = np.stack(make_gop(1000 * 2 + rank, W, H, F, p=P_KSTAR_2_3, dtype=dtype))
+    density = args.density or P_KSTAR_2_3
+    frames = np.stack(make_gop(1000 * 2 + rank, W, H, F, p=density, dtype=dtype))
     coder.load_frames(frames)
     torch.cuda.synchronize(device)
 
@@ -175,8 +177,8 @@ def main():
         "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), k*=2.3, threshold 0"
-                               % (W, H, args.bits, F, pairs),
+        "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), %s, threshold 0"
+                               % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3"),
                    "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
                    "lds_tile_kib": args.lds_tile_kib or "auto",
                    "stages": "residual mask -> host params -> insert -> query+witness"},
@@ -190,7 +192,7 @@ def main():
             q_ms = ktimes["query"][0] / ktimes["query"][1]
             achieved = alg_bytes / (q_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_query_lds", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(W, H, F, args.bits),
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None if args.density else measured_traffic(W, H, F, args.bits),
                                "avg_launch_ms": round(q_ms, 4),
                                "avg_launch_ms_alone": (breakdown or {}).get("query"),   # same kernel, one pipeline, nothing co-running
                                "algorithmic_bytes_per_launch": int(alg_bytes),

@@ -100,7 +100,8 @@ int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes); 
 #define RBF_K_INDEX   7
 #define RBF_K_REDUCE  8
 #define RBF_K_SCAN    9
-#define RBF_K_COUNT   10
+#define RBF_K_NOISE   10
+#define RBF_K_COUNT   11
 int rbf_timing_enable(rbf_ctx *ctx, int on);
 /* Testing knob (bit mask): bit 0 = always use the generic (global-memory filter) kernels;
  * bit 1 = LDS fast path without double-buffering the filter.  0 (default) = pick the fastest
@@ -125,7 +126,9 @@ int rbf_plan_batch(uint64_t n, const uint64_t *ones, uint32_t nframes, int guard
                    rbf_filter_params *params, double *k);
 
 /* ---- A1: residual mask  (VideoFrameCompressor._calculate_frame_diff, :784-808,845) ------- */
-/* mask bit = abs_int16(prev - curr) > thr_floor, with numpy's int16 wrap for 16-bit samples.
+/* mask bit = abs_int16(prev - curr) > thr, with numpy's int16 wrap for 16-bit samples; thr is
+ * thr_floors[f] for pair f when thr_floors (HOST array of nframes-1 entries) is not NULL -- the
+ * adaptive per-frame thresholds of :804-805 -- else thr_floor for every pair.
  * Sample (x, y) of a frame is at base + y*row_pitch_bytes + x*pixel_stride_bytes (so the luma
  * of interleaved YUV444 or a planar plane are both addressable); sample_bytes is 1 or 2.
  * Frame f of the batch is at frames_dev + f*frame_stride_bytes; mask f (f = 0..nframes-2) is the
@@ -134,8 +137,22 @@ int rbf_plan_batch(uint64_t n, const uint64_t *ones, uint32_t nframes, int guard
 int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
                             uint32_t nframes, uint32_t width, uint32_t height,
                             uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
-                            uint32_t sample_bytes, int32_t thr_floor,
+                            uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
                             void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev);
+
+/* ---- A1, adaptive threshold  (VideoFrameCompressor._estimate_noise_level, :727-744) -------- */
+/* For each of nframes luma planes (addressed as above): smoothed = 5x5 median with replicated
+ * borders (cv2.medianBlur(frame, 5), :738), noise = frame - smoothed (:741).
+ *   moments_dev  out: nframes x 2 int64 -- exact sum(noise) and sum(noise^2)
+ *   noise_dev    out, nullable: nframes planes of height*width float32, the array whose float32
+ *                np.std the reference takes (:744); every value is an exact integer.
+ * The standard deviation, the clamp to [min, max] and the floor that turns it into thr_floors
+ * (:756-760) are host float work: engine.py does them from the moments, and falls back to the
+ * noise plane when rounding could matter. */
+int rbf_noise_moments_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                            uint32_t nframes, uint32_t width, uint32_t height,
+                            uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                            uint32_t sample_bytes, int64_t *moments_dev, float *noise_dev);
 
 /* ---- A4 + A5: insert + query/witness  (BloomFilterCompressor.compress loops, :232-253) --- */
 /* For each frame f: zero filter f, insert every '1' position of mask f
@@ -162,7 +179,8 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
 int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
                    uint32_t nframes, uint32_t width, uint32_t height,
                    uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
-                   uint32_t sample_bytes, int32_t thr_floor, const rbf_seeds *seeds,
+                   uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                   const rbf_seeds *seeds,
                    void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
                    void *filters_dev, uint64_t filter_stride_bytes,
                    void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,

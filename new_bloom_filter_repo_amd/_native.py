@@ -14,8 +14,8 @@ RBF_ENOMEM = -12
 RBF_EIO = -5
 RBF_ERANGE = -34
 
-K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN = range(10)
-KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan"]
+K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE = range(11)
+KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise"]
 STATS_PER_FRAME = 4
 
 
@@ -34,6 +34,7 @@ class RbfError(RuntimeError):
 
 
 _vp, _u64, _u32, _i32, _int = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int
+_i32p = ctypes.POINTER(ctypes.c_int32)
 _PROTOS = {
     "rbf_version": (_int, []),
     "rbf_last_error": (ctypes.c_char_p, []),
@@ -53,9 +54,10 @@ _PROTOS = {
     "rbf_optimal_params": (_int, [_u64, _u64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
     "rbf_activation_threshold": (_int, [ctypes.c_double, ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),
     "rbf_plan_batch": (_int, [_u64, ctypes.POINTER(_u64), _u32, _int, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
-    "rbf_encode_gop": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, ctypes.POINTER(Seeds),
+    "rbf_encode_gop": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, ctypes.POINTER(Seeds),
                               _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
-    "rbf_residual_mask_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _vp, _u64, _vp]),
+    "rbf_residual_mask_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, _vp, _u64, _vp]),
+    "rbf_noise_moments_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _vp, _vp]),
     "rbf_bloom_encode_batch": (_int, [_vp, _vp, _u64, _u64, _u32, ctypes.POINTER(FilterParams), ctypes.POINTER(Seeds),
                                       _vp, _u64, _vp, _u64, _vp]),
     "rbf_bloom_decode_batch": (_int, [_vp, _vp, _u64, _vp, _u64, _u64, _u32, ctypes.POINTER(FilterParams),

@@ -2,6 +2,7 @@
 // scratch management, launches on the context's single HIP stream, optional per-kernel timing.
 #include "../../include/rbf.h"
 #include "rbf_kernels_lds.h"
+#include "rbf_kernels_noise.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -47,6 +48,7 @@ struct rbf_ctx {
     uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
     uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
     uint32_t *partials = nullptr;    size_t partials_cap = 0;
+    int32_t *thr_tab = nullptr;      size_t thr_tab_cap = 0;      // per-pair thresholds of the mask kernels
     int force_generic = 0;           // tests: 1 = never use the LDS fast path
     int single_buffer = 0;           // tests: 1 = fast query path without filter double-buffering
     uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
@@ -171,6 +173,7 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (ctx->seg_off) (void)hipFree(ctx->seg_off);
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->thr_tab) (void)hipFree(ctx->thr_tab);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RBF_OK;
@@ -433,10 +436,20 @@ static int allow_big_lds(const void *fn)
 // ------------------------------------------------------------------------------------------
 // A1
 // ------------------------------------------------------------------------------------------
+// per-pair thresholds travel as kernel arguments (captured at launch) into a device table
+struct ThrChunk {
+    static constexpr uint32_t N = 256;
+    int32_t v[N];
+};
+__global__ void k_store_thresholds(const ThrChunk c, int32_t *__restrict__ dst, uint32_t count)
+{
+    if (threadIdx.x < count) dst[threadIdx.x] = c.v[threadIdx.x];
+}
+
 int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
                             uint32_t nframes, uint32_t width, uint32_t height,
                             uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
-                            uint32_t sample_bytes, int32_t thr_floor,
+                            uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
                             void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev)
 {
     if (int r = set_device(ctx)) return r;
@@ -451,6 +464,22 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
     if (int r = check_frame_geometry(n, nframes - 1, mask_stride_bytes)) return r;
     const uint32_t pairs = nframes - 1;
     HIP_TRY(hipMemsetAsync(ones_dev, 0, (size_t)pairs * sizeof(uint64_t), ctx->stream));
+    const int32_t *thr_tab = nullptr;
+    if (thr_floors) {
+        // Kernel arguments are captured at launch, so the caller's array is free as soon as we return.
+        if (int r = grow((void **)&ctx->thr_tab, &ctx->thr_tab_cap, (size_t)pairs * 4)) return r;
+        for (uint32_t base = 0; base < pairs; base += ThrChunk::N) {
+            ThrChunk c{};
+            const uint32_t cnt = pairs - base < ThrChunk::N ? pairs - base : ThrChunk::N;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                if (thr_floors[base + i] < 0) return fail(RBF_EINVAL, "negative threshold %d for pair %u", thr_floors[base + i], base + i);
+                c.v[i] = thr_floors[base + i];
+            }
+            hipLaunchKernelGGL(k_store_thresholds, dim3(1), dim3(ThrChunk::N), 0, ctx->stream, c, ctx->thr_tab + base, cnt);
+        }
+        HIP_TRY(hipGetLastError());
+        thr_tab = ctx->thr_tab;
+    }
     const uint64_t nwords = (n + 63) / 64;
     // Fast path: flat frames, 16-byte aligned, whole 1024-pixel segments; the generic kernel does the rest.
     uint64_t fast_segs = 0;
@@ -471,7 +500,7 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
         chunks = (pairs + ppc - 1) / ppc;
         LaunchTimer t(ctx, RBF_K_MASK);
 #define RBF_MASK_GOP(S, PB) hipLaunchKernelGGL((k_residual_mask_gop<S, PB>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
-                               (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, (uint16_t *)masks_dev, \
+                               (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, thr_tab, (uint16_t *)masks_dev, \
                                mask_stride_bytes / 2, ones_dev, ppc)
         if (sample_bytes == 1 && pixel_stride_bytes == 1) RBF_MASK_GOP(uint8_t, 1);
         else if (sample_bytes == 1) RBF_MASK_GOP(uint8_t, 3);
@@ -489,10 +518,10 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
         LaunchTimer t(ctx, RBF_K_MASK);
         if (sample_bytes == 1)
             hipLaunchKernelGGL(k_residual_mask<uint8_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
-                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev, first_word);
+                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, thr_tab, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev, first_word);
         else
             hipLaunchKernelGGL(k_residual_mask<uint16_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
-                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev, first_word);
+                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, thr_tab, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev, first_word);
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;
@@ -651,6 +680,38 @@ int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_st
                              witnesses_dev, witness_stride_bytes, stats_dev, false);
 }
 
+// ------------------------------------------------------------------------------------------
+// A1, adaptive threshold: 5x5 median residual and its exact moments
+// ------------------------------------------------------------------------------------------
+int rbf_noise_moments_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                            uint32_t nframes, uint32_t width, uint32_t height,
+                            uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                            uint32_t sample_bytes, int64_t *moments_dev, float *noise_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!frames_dev || !moments_dev) return fail(RBF_EINVAL, "null device pointer");
+    if (nframes == 0 || nframes > 65535) return fail(RBF_EINVAL, "frame count %u out of range 1..65535", nframes);
+    if (width == 0 || height == 0) return fail(RBF_EINVAL, "empty frame %ux%u", width, height);
+    if (sample_bytes != 1 && sample_bytes != 2) return fail(RBF_EINVAL, "sample_bytes must be 1 or 2, got %u", sample_bytes);
+    if (pixel_stride_bytes < sample_bytes || pixel_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "pixel stride %u incompatible with %u-byte samples", pixel_stride_bytes, sample_bytes);
+    if (row_pitch_bytes < (uint64_t)width * pixel_stride_bytes || row_pitch_bytes % sample_bytes) return fail(RBF_EINVAL, "row pitch %llu too small or misaligned", (unsigned long long)row_pitch_bytes);
+    if (frame_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "frame stride misaligned");
+    if ((uint64_t)width * height >= (1ull << 32)) return fail(RBF_ERANGE, "frame of %llu pixels is too large", (unsigned long long)width * height);
+    const uint32_t by = (height + NZ_TILE_H - 1) / NZ_TILE_H;
+    if (by > 65535) return fail(RBF_ERANGE, "frame height %u too large", height);
+    HIP_TRY(hipMemsetAsync(moments_dev, 0, (size_t)nframes * 2 * sizeof(int64_t), ctx->stream));
+    dim3 grid((width + NZ_TILE_W - 1) / NZ_TILE_W, by, nframes), block(NZ_THREADS);
+    LaunchTimer t(ctx, RBF_K_NOISE);
+    if (sample_bytes == 1)
+        hipLaunchKernelGGL(k_noise_moments<uint8_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
+                           width, height, row_pitch_bytes, pixel_stride_bytes, (unsigned long long *)moments_dev, noise_dev);
+    else
+        hipLaunchKernelGGL(k_noise_moments<uint16_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
+                           width, height, row_pitch_bytes, pixel_stride_bytes, (unsigned long long *)moments_dev, noise_dev);
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
 // copies the ones counts into the device-visible pinned block and raises its flag word
 __global__ void k_publish_ones(const uint64_t *__restrict__ ones, uint64_t *host_block, uint32_t count, uint64_t token)
 {
@@ -664,7 +725,8 @@ __global__ void k_publish_ones(const uint64_t *__restrict__ ones, uint64_t *host
 int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
                    uint32_t nframes, uint32_t width, uint32_t height,
                    uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
-                   uint32_t sample_bytes, int32_t thr_floor, const rbf_seeds *seeds,
+                   uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                   const rbf_seeds *seeds,
                    void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
                    void *filters_dev, uint64_t filter_stride_bytes,
                    void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
@@ -672,7 +734,7 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
 {
     if (!filters_dev || !witnesses_dev || !stats_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
     if (int r = rbf_residual_mask_batch(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
-                                        pixel_stride_bytes, sample_bytes, thr_floor, masks_dev, mask_stride_bytes, ones_dev))
+                                        pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev))
         return r;
     const uint32_t pairs = nframes - 1;
     const uint64_t n = (uint64_t)width * height;

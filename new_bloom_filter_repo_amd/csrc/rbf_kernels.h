@@ -31,11 +31,12 @@ __device__ __forceinline__ bool residual_bit(SAMPLE a, SAMPLE b, int32_t thr)
 template <typename SAMPLE>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t width, uint64_t n,
-    uint64_t row_pitch, uint32_t pixel_stride, int32_t thr,
+    uint64_t row_pitch, uint32_t pixel_stride, int32_t thr_all, const int32_t *__restrict__ thr_tab /* nullable: per pair */,
     uint64_t *__restrict__ masks, uint64_t mask_stride_words, uint64_t *__restrict__ ones, uint64_t first_word)
 {
     __shared__ uint32_t wave_ones[WG_WAVES];
     const uint32_t f = blockIdx.y;
+    const int32_t thr = thr_tab ? thr_tab[f] : thr_all;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint8_t *prev = frames + (uint64_t)f * frame_stride;
     const uint8_t *curr = prev + frame_stride;

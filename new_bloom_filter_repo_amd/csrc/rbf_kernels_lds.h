@@ -694,7 +694,8 @@ struct LanePixels {
 template <typename SAMPLE, int PIXEL_BYTES, bool NT = false>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t nframes, uint64_t nsegs /* of 1024 px */,
-    int32_t thr, uint16_t *__restrict__ masks, uint64_t mask_stride_u16, uint64_t *__restrict__ ones,
+    int32_t thr_all, const int32_t *__restrict__ thr_tab /* nullable: per pair */,
+    uint16_t *__restrict__ masks, uint64_t mask_stride_u16, uint64_t *__restrict__ ones,
     uint32_t pairs_per_chunk)
 {
     // blockIdx.y = temporal chunk: frames [f0, f1] (f1 - f0 pairs); chunks overlap by one frame, which
@@ -716,6 +717,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         cur.template load<NT>(p + (uint64_t)(f0 + 1) * frame_stride);
         for (uint32_t f = f0 + 1; f <= f1; ++f) {
             if (f + 1 <= f1) nxt.template load<NT>(p + (uint64_t)(f + 1) * frame_stride);
+            const int32_t thr = thr_tab ? thr_tab[f - 1] : thr_all;
             uint32_t bits = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {

@@ -33,31 +33,99 @@ class BloomEngine:
         self._bufs = {}
 
     # ------------------------------------------------------------------ A1
-    def residual_masks(self, frames, threshold, luma_only=True):
-        """frames: array (F, H, W[, C]) uint8/uint16 (channel 0 = luma).  Returns
-        (masks_packed uint8 [F-1, stride], ones uint64 [F-1]); masks stay on the device as well
-        (self.masks_dev) for the following encode."""
+    def _upload_frames(self, frames, min_frames):
         frames = np.ascontiguousarray(frames)
         if frames.ndim not in (3, 4):
             raise ValueError("frames must be (F, H, W) or (F, H, W, C)")
+        if frames.dtype not in (np.uint8, np.uint16):
+            raise ValueError("8- or 16-bit unsigned samples expected")
+        if frames.shape[0] < min_frames:
+            raise ValueError("need at least %d frame%s" % (min_frames, "s" if min_frames > 1 else ""))
         F, H, W = frames.shape[:3]
         C = frames.shape[3] if frames.ndim == 4 else 1
-        sb = frames.dtype.itemsize
-        if F < 2:
-            raise ValueError("need at least two frames")
+        fb = self._buf("frames", frames.nbytes).upload(frames)
+        return fb, F, H, W, C, frames.dtype.itemsize
+
+    def residual_masks(self, frames, threshold, luma_only=True, adaptive=None):
+        """frames: array (F, H, W[, C]) uint8/uint16 (channel 0 = luma).  threshold: one number for
+        every pair, a sequence of F-1 numbers, or None with adaptive=(noise_tolerance, min_thr,
+        max_thr) for the reference's per-frame noise-adaptive threshold (:746-766).  Returns
+        (masks_packed uint8 [F-1, stride], ones uint64 [F-1]); masks stay on the device as well
+        for the following encode."""
+        fb, F, H, W, C, sb = self._upload_frames(frames, 2)
         n = H * W
         stride = nat.packed_stride(n)
-        fb = self._buf("frames", frames.nbytes).upload(frames)
         mb = self._buf("masks", (F - 1) * stride)
         ob = self._buf("ones", (F - 1) * 8)
-        thr = threshold_floor(threshold)
+        if threshold is None:
+            if adaptive is None:
+                raise ValueError("threshold=None needs adaptive=(noise_tolerance, min_thr, max_thr)")
+            threshold = self._adaptive_floors(fb, F, H, W, C, sb, *adaptive)
+        thr, thr_tab = 0, None
+        if np.ndim(threshold) == 0:
+            thr = threshold_floor(threshold)
+        else:
+            if len(threshold) != F - 1:
+                raise ValueError("need one threshold per frame pair")
+            thr_tab = (ctypes.c_int32 * (F - 1))(*[threshold_floor(t) for t in threshold])
+        self.thresholds = [thr] * (F - 1) if thr_tab is None else list(thr_tab)
         nat.check(nat.lib().rbf_residual_mask_batch(
-            self.ctx.handle, fb.ptr, H * W * C * sb, F, W, H, W * C * sb, C * sb, sb, thr,
+            self.ctx.handle, fb.ptr, H * W * C * sb, F, W, H, W * C * sb, C * sb, sb, thr, thr_tab,
             mb.ptr, stride, ob.ptr))
         masks = mb.download((F - 1) * stride).reshape(F - 1, stride)
         ones = ob.download((F - 1) * 8, dtype=np.uint64).copy()
         self.n, self.mask_stride = n, stride
         return masks, ones
+
+    # ------------------------------------------------------------------ A1, adaptive threshold
+    def _noise(self, fb, first, count, H, W, C, sb, want_planes):
+        """Launch the 5x5-median residual kernel on frames [first, first+count) of the uploaded block."""
+        mo = self._buf("moments", count * 16)
+        nz = self._buf("noise", count * H * W * 4) if want_planes else None
+        fs = H * W * C * sb
+        nat.check(nat.lib().rbf_noise_moments_batch(
+            self.ctx.handle, fb.ptr + first * fs, fs, count, W, H, W * C * sb, C * sb, sb,
+            mo.ptr, nz.ptr if nz else None))
+        moments = mo.download(count * 16, dtype=np.int64).reshape(count, 2).copy()
+        planes = nz.download(count * H * W * 4, dtype=np.float32).reshape(count, H, W) if nz else None
+        return moments, planes
+
+    def noise_moments(self, frames):
+        """Exact (sum, sum of squares) of luma - medianBlur5(luma) per frame: int64 [F, 2]."""
+        fb, F, H, W, C, sb = self._upload_frames(frames, 1)
+        return self._noise(fb, 0, F, H, W, C, sb, False)[0]
+
+    def noise_levels(self, frames):
+        """VideoFrameCompressor._estimate_noise_level for every frame (:727-744): np.float32 [F].
+        The median residual comes from the GPU; the float32 np.std is taken here, with numpy, on
+        the same (H, W) float32 array the reference would hold, so the result has the same bits."""
+        fb, F, H, W, C, sb = self._upload_frames(frames, 1)
+        planes = self._noise(fb, 0, F, H, W, C, sb, True)[1]
+        return np.array([np.std(planes[f]) for f in range(F)], dtype=np.float32)
+
+    def _adaptive_floors(self, fb, F, H, W, C, sb, noise_tolerance, min_thr, max_thr):
+        """floor() of the reference's adaptive threshold of frames 1..F-1 (the `curr` frame of each
+        pair, :805).  Fast path: the exact integer moments give the standard deviation to ~1e-16;
+        numpy's float32 pairwise np.std differs from that by < 1e-5 relative, so unless an integer
+        lies inside that band around the clamped threshold the floor is already decided.  Otherwise
+        (rare) the frame's noise plane is downloaded and the reference's float32 math is replayed."""
+        n = H * W
+        moments = self._noise(fb, 1, F - 1, H, W, C, sb, False)[0]
+        floors = []
+        for i in range(F - 1):
+            s1, s2 = int(moments[i, 0]), int(moments[i, 1])
+            lo, hi = adaptive_threshold_band(n, s1, s2, noise_tolerance, min_thr, max_thr)
+            if lo != hi:
+                plane = self._noise(fb, 1 + i, 1, H, W, C, sb, True)[1][0]
+                lo = threshold_floor(adaptive_threshold(np.std(plane), noise_tolerance, min_thr, max_thr))
+                self.adaptive_exact_fallbacks = getattr(self, "adaptive_exact_fallbacks", 0) + 1
+            floors.append(lo)
+        return floors
+
+    def adaptive_thresholds(self, frames, noise_tolerance=10.0, min_thr=3.0, max_thr=30.0):
+        """Integer thresholds (floors) the reference's adaptive rule gives frames 1..F-1."""
+        fb, F, H, W, C, sb = self._upload_frames(frames, 2)
+        return self._adaptive_floors(fb, F, H, W, C, sb, noise_tolerance, min_thr, max_thr)
 
     # ------------------------------------------------------------------ A4 + A5
     def upload_masks(self, masks_packed, n):
@@ -136,6 +204,26 @@ def threshold_floor(threshold):
     import math
     t = math.floor(threshold)
     return int(max(-2 ** 31, min(2 ** 31 - 1, t)))
+
+
+def adaptive_threshold(noise_level, noise_tolerance, min_thr, max_thr):
+    """VideoFrameCompressor._adaptive_diff_threshold's clamp (:756-760); with a np.float32 noise
+    level the product stays float32, as it does in the reference."""
+    return max(min_thr, min(max_thr, noise_level * noise_tolerance))
+
+
+ADAPTIVE_GUARD = 1e-4      # >> the float32 pairwise-summation error of np.std (measured < 2e-6)
+
+
+def adaptive_threshold_band(n, s1, s2, noise_tolerance, min_thr, max_thr):
+    """(floor_lo, floor_hi) of the adaptive threshold from the exact moments of the noise plane:
+    equal when numpy's float32 rounding cannot change the integer threshold."""
+    import math
+    var_num = n * s2 - s1 * s1                       # n^2 * variance, exact
+    std = math.sqrt(var_num) / n if var_num > 0 else 0.0
+    lo = adaptive_threshold(std * (1.0 - ADAPTIVE_GUARD), noise_tolerance, min_thr, max_thr)
+    hi = adaptive_threshold(std * (1.0 + ADAPTIVE_GUARD), noise_tolerance, min_thr, max_thr)
+    return threshold_floor(min(lo, hi)), threshold_floor(max(lo, hi))
 
 
 class DeviceFilter:

@@ -22,7 +22,7 @@ import numpy as np
 from . import _native as nat
 from . import params as P
 from .bloom_compressor import BloomFilterCompressor
-from .engine import BloomEngine, gather_values, scatter_values
+from .engine import BloomEngine, adaptive_threshold, gather_values, scatter_values
 
 
 # ----------------------------------------------------------------------------- YUV wrapper
@@ -166,12 +166,26 @@ class VideoFrameCompressor:
                                       "pass YUV frames with use_direct_yuv=True or 2-D luma frames")
         return a, b, is_color
 
+    # ---- A1, adaptive threshold
+    def _estimate_noise_level(self, frame):
+        """np.std of luma - medianBlur5(luma) as np.float32 -- improved_video_compressor.py:727-744.
+        `frame` is a 2-D luma plane (what _calculate_frame_diff passes, :805)."""
+        luma = frame_data(frame)
+        if luma.ndim != 2:
+            raise ValueError("a 2-D luma plane is expected")
+        return self._engine.noise_levels(luma[None])[0]
+
+    def _adaptive_diff_threshold(self, frame):
+        """max(min, min(max, noise_level * noise_tolerance)) -- improved_video_compressor.py:746-766."""
+        return adaptive_threshold(self._estimate_noise_level(frame), self.noise_tolerance,
+                                  self.min_diff_threshold, self.max_diff_threshold)
+
     def _calculate_frame_diff(self, prev_frame, curr_frame, threshold=None):
-        """(binary_diff HxW uint8, changed_values, density) -- improved_video_compressor.py:768-847."""
-        if threshold is None:
-            raise NotImplementedError("the noise-adaptive threshold needs a 5x5 median blur (cv2.medianBlur, :738); "
-                                      "pass an explicit threshold (0.0 for lossless coding)")
+        """(binary_diff HxW uint8, changed_values, density) -- improved_video_compressor.py:768-847.
+        threshold=None: noise-adaptive threshold of the current luma plane (:804-805)."""
         a, b, is_color = self._luma_pair(prev_frame, curr_frame)
+        if threshold is None:
+            threshold = self._adaptive_diff_threshold(b[:, :, 0] if is_color else b)
         masks, ones = self._engine.residual_masks(np.stack([a, b]), threshold)
         h, w = a.shape[:2]
         n = h * w

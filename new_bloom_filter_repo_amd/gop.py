@@ -59,15 +59,21 @@ class GopCoder:
     """Encodes the nframes-1 inter-frame residual masks of one GOP of (H, W, C) frames."""
 
     def __init__(self, ctx, width, height, nframes, channels=3, sample_bytes=1, seeds=P.SEEDS_VIDEO,
-                 allocator=None, threshold=0.0, out_allocator=None, frames_block=None):
+                 allocator=None, threshold=0.0, out_allocator=None, frames_block=None, adaptive=None):
         """allocator: device memory source (default: library-owned); out_allocator: separate source for
-        the output record (filters, witnesses, stats); frames_block: share another coder's frame buffer."""
+        the output record (filters, witnesses, stats); frames_block: share another coder's frame buffer.
+        threshold=None with adaptive=(noise_tolerance, min_thr, max_thr): per-frame noise-adaptive
+        thresholds (improved_video_compressor.py:746-766) -- lossy, like the reference's default."""
         from .engine import threshold_floor
         self.ctx, self.W, self.H, self.F, self.C, self.sb = ctx, width, height, nframes, channels, sample_bytes
         self.n = width * height
         self.pairs = nframes - 1
         self.seeds = nat.Seeds(*[int(s) for s in seeds])
-        self.thr = threshold_floor(threshold)
+        if threshold is None and adaptive is None:
+            raise ValueError("threshold=None needs adaptive=(noise_tolerance, min_thr, max_thr)")
+        self.thr = 0 if threshold is None else threshold_floor(threshold)
+        self.adaptive = adaptive if threshold is None else None
+        self.thr_tab = None
         alloc = allocator or owned_allocator(ctx)
         self.frame_bytes = self.n * channels * sample_bytes
         self.mask_stride, self.filter_stride, self.witness_stride = self.strides(self.n)
@@ -78,6 +84,10 @@ class GopCoder:
         self.filters = oalloc(self.filter_stride * self.pairs)
         self.witness = oalloc(self.witness_stride * self.pairs)
         self.stats = oalloc(8 * nat.STATS_PER_FRAME * self.pairs)
+        if self.adaptive is not None:
+            self.moments = alloc(16 * self.pairs)
+            self.noise_plane = None                       # allocated on the first exact fallback
+            self._alloc = alloc
         self.params = (nat.FilterParams * self.pairs)()
         self.k = (ctypes.c_double * self.pairs)()
 
@@ -99,11 +109,40 @@ class GopCoder:
         assert frames.nbytes == self.frame_bytes * self.F, (frames.shape, frames.dtype)
         nat.check(nat.lib().rbf_memcpy_h2d(self.ctx.handle, self.frames.ptr, frames.ctypes.data, frames.nbytes))
 
+    def _noise(self, first, count, moments_ptr, planes_ptr):
+        nat.check(nat.lib().rbf_noise_moments_batch(
+            self.ctx.handle, self.frames.ptr + first * self.frame_bytes, self.frame_bytes, count, self.W, self.H,
+            self.W * self.C * self.sb, self.C * self.sb, self.sb, moments_ptr, planes_ptr))
+
+    def adaptive_floors(self):
+        """Integer thresholds of the reference's adaptive rule for frames 1..F-1 (engine.py has the
+        reasoning: exact integer moments decide the floor; the float32 replay is the rare fallback)."""
+        from .engine import adaptive_threshold, adaptive_threshold_band, threshold_floor
+        self._noise(1, self.pairs, self.moments.ptr, None)
+        self.ctx.sync()
+        moments = self.moments.numpy(self.ctx)[:16 * self.pairs].view(np.int64).reshape(self.pairs, 2)
+        floors = []
+        for i in range(self.pairs):
+            lo, hi = adaptive_threshold_band(self.n, int(moments[i, 0]), int(moments[i, 1]), *self.adaptive)
+            if lo != hi:
+                if self.noise_plane is None:
+                    self.noise_plane = self._alloc(4 * self.n)
+                    self.moments1 = self._alloc(16)
+                self._noise(1 + i, 1, self.moments1.ptr, self.noise_plane.ptr)
+                self.ctx.sync()
+                plane = self.noise_plane.numpy(self.ctx)[:4 * self.n].view(np.float32).reshape(self.H, self.W)
+                lo = threshold_floor(adaptive_threshold(np.std(plane), *self.adaptive))
+            floors.append(lo)
+        return floors
+
     def encode(self):
         """Enqueue one full pass; returns after the Bloom kernels are enqueued."""
+        if self.adaptive is not None:
+            self.thresholds = self.adaptive_floors()
+            self.thr_tab = (ctypes.c_int32 * self.pairs)(*self.thresholds)
         nat.check(nat.lib().rbf_encode_gop(
             self.ctx.handle, self.frames.ptr, self.frame_bytes, self.F, self.W, self.H,
-            self.W * self.C * self.sb, self.C * self.sb, self.sb, self.thr, ctypes.byref(self.seeds),
+            self.W * self.C * self.sb, self.C * self.sb, self.sb, self.thr, self.thr_tab, ctypes.byref(self.seeds),
             self.masks.ptr, self.mask_stride, self.ones.ptr,
             self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr,
             self.params, self.k))

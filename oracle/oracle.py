@@ -13,6 +13,13 @@ Reference anchors (/root/reference):
   improved_video_compressor.py:198-266  compress                    -> compress
   improved_video_compressor.py:268-307  decompress                  -> decompress
   improved_video_compressor.py:768-847  _calculate_frame_diff       -> frame_diff
+  improved_video_compressor.py:727-766  _estimate_noise_level / _adaptive_diff_threshold
+                                        -> median_blur5, estimate_noise_level, adaptive_diff_threshold
+      PARITY UNPINNED for this one row: cv2 (opencv-python, requirements.txt, unpinned) is absent
+      here, so cv2.medianBlur(frame, 5) is restated from OpenCV's documented behaviour (median of
+      the 5x5 neighbourhood, border pixels replicated) and no golden vector exists; everything
+      around it (float32 subtraction, np.std, clamp) is the reference's numpy code verbatim in
+      behaviour and runs on the same numpy.
   improved_video_compressor.py:849-909  _apply_frame_diff           -> apply_frame_diff
   improved_video_compressor.py:911-967  _compress_frame_differences -> pack_frame_differences
   improved_video_compressor.py:969-1027 _decompress_frame_differences -> unpack_frame_differences
@@ -219,8 +226,33 @@ def residual_mask(prev_y, curr_y, threshold):
     return mask.reshape(prev_y.shape)
 
 
-def frame_diff(prev_frame, curr_frame, threshold, yuv_planes=True):
-    """_calculate_frame_diff (:768-847) for direct-YUV H x W x 3 or 2-D frames.
+def median_blur5(plane):
+    """cv2.medianBlur(plane, 5) for a 2-D uint8/uint16 plane (improved_video_compressor.py:738):
+    the 13th smallest of the 5x5 window, with BORDER_REPLICATE (OpenCV's documented border mode
+    for medianBlur).  Parity unpinned -- see the module header."""
+    plane = np.asarray(plane)
+    assert plane.ndim == 2
+    padded = np.pad(plane, 2, mode="edge")
+    win = np.lib.stride_tricks.sliding_window_view(padded, (5, 5)).reshape(plane.shape + (25,))
+    return np.partition(win, 12, axis=-1)[..., 12].astype(plane.dtype)
+
+
+def estimate_noise_level(plane):
+    """improved_video_compressor.py:727-744."""
+    smoothed = median_blur5(plane)
+    noise = plane.astype(np.float32) - smoothed.astype(np.float32)
+    return np.std(noise)
+
+
+def adaptive_diff_threshold(plane, noise_tolerance=10.0, min_thr=3.0, max_thr=30.0):
+    """improved_video_compressor.py:746-766."""
+    noise_level = estimate_noise_level(plane)
+    return max(min_thr, min(max_thr, noise_level * noise_tolerance))
+
+
+def frame_diff(prev_frame, curr_frame, threshold, yuv_planes=True, adaptive=(10.0, 3.0, 30.0)):
+    """_calculate_frame_diff (:768-847) for direct-YUV H x W x 3 or 2-D frames; threshold None ->
+    adaptive threshold of the current luma (:804-805) with adaptive = (tolerance, min, max).
 
     Returns (mask HxW uint8, changed_values, density).  With yuv_planes the values are
     uint8 Y,U,V interleaved (:825-829 -- dtype hard-coded uint8 in the reference);
@@ -232,6 +264,8 @@ def frame_diff(prev_frame, curr_frame, threshold, yuv_planes=True):
         prev_gray, curr_gray = prev_frame[:, :, 0], curr_frame[:, :, 0]
     else:
         prev_gray, curr_gray = prev_frame, curr_frame
+    if threshold is None:
+        threshold = adaptive_diff_threshold(curr_gray.copy(), *adaptive)
     mask = residual_mask(prev_gray, curr_gray, threshold)
     rows, cols = np.where(mask == 1)
     if is_color:

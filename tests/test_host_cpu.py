@@ -25,6 +25,11 @@ def test_abi_header_matches_binding_and_library():
         assert hasattr(lib, name), name
     assert lib.rbf_version() == 1
     assert isinstance(lib.rbf_last_error(), bytes)
+    # same number of parameters in the header and in the ctypes prototypes
+    clean = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for name, args in re.findall(r"\b(rbf_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", clean):
+        count = 0 if args.strip() == "void" else args.count(",") + 1
+        assert count == len(nat._PROTOS[name][1]), (name, count, len(nat._PROTOS[name][1]))
 
 
 def test_no_cpu_fallback_message(monkeypatch):
