@@ -5,7 +5,8 @@ A step = one pass of the hot path over one GOP resident in HBM: residual masks o
 inter-frames of a 1920x1080 YUV444 30-frame GOP -> ones counts to the host -> filter geometry
 (float64, host) -> Bloom insert -> query + witness compaction (BASELINE.json configs[1], k* = 2.3).
 With N > 1 every rank encodes its own GOP (independent frames shard; weak scaling) and the
-per-frame (filter, witness, stats) records are gathered to rank 0 over RCCL inside the step.
+step compacts its per-frame (filter, witness, stats) rows into one exact-size record on the device and
+gathers it to rank 0 over RCCL inside the step (asynchronously, overlapping the next step's kernels).
 
 Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel (query) priced at its
 ALGORITHMIC bytes (packed mask in + filter in + witness out) against the 8 TB/s HBM peak, from HIP
@@ -38,6 +39,7 @@ def main():
     ap.add_argument("--density", type=float, default=0.0, help="fraction of changed pixels per inter-frame (0 = 0.08889, i.e. k*=2.3; SURVEY 8d density sweep)")
     ap.add_argument("--streams", type=int, default=2, help="GOP pipelines in flight per GPU (each its own HIP stream)")
     ap.add_argument("--lds-tile-kib", type=int, default=0, help="cap the LDS filter tile (KiB) -> tiled kernels; 0 = auto (BASELINE config 4 sweep)")
+    ap.add_argument("--gather-every", type=int, default=4, help="N>1: steps whose records travel in one RCCL gather")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and gather) even with one rank (smoke-tests the N>1 path)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-kernel HIP events in the timed region")
@@ -65,6 +67,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # Finish RCCL's own setup (its streams, channels, proxy threads) with one collective BEFORE the
+        # GOP pipelines' streams exist.  Measured (tools/dist_overhead.py): streams created between an
+        # eager communicator init and its first collective end up serialised with each other
+        # (260 instead of 222 us/step); created after it, or before a lazy init, they overlap.
+        dist.barrier()
+        torch.cuda.synchronize(device)
+    ncoders = max(1, args.streams)
+    streams = [torch.cuda.Stream(device) for _ in range(ncoders)]      # none of them is the null stream
 
     from new_bloom_filter_repo_amd import _native as nat
     from new_bloom_filter_repo_amd.gop import GopCoder, TorchArena, torch_allocator
@@ -80,8 +90,6 @@ def main():
     # the integer-issue-bound insert / query kernels of its neighbour, and (N > 1) the async RCCL gather
     # of step s overlaps the kernels of step s+1.  Every step still does all of its work inside the
     # timed region.
-    ncoders = max(1, args.streams)
-    streams = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(ncoders - 1)]
     ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
     if args.lds_tile_kib:
         for c in ctxs:
@@ -99,32 +107,89 @@ def main():
     torch.cuda.synchronize(device)
 
     gather = use_gather
-    pending = [None] * ncoders
-    if gather:
-        gl = [[torch.empty_like(a.tensor) for _ in range(world)] if rank == 0 else None for a in arenas]
+    # N > 1: every step compacts its output rows into an exact-size record on the device
+    # (rbf_pack_records) inside an outbox of `--gather-every` slots; a full outbox goes to rank 0 in ONE
+    # asynchronous RCCL gather (fewer, larger collectives; two outboxes alternate so packing never waits
+    # for a transfer).  RCCL's gather needs one size on all ranks, so the slot size is agreed once, after
+    # the warm-up steps (max of the ranks' record sizes + 2 %); a record that outgrew its slot would be
+    # flagged in its header (checked on rank 0 after the timed region).
+    G = max(1, args.gather_every)
+    record_max = (int(nat.lib().rbf_record_max_bytes(pairs, n)) + 255) // 256 * 256
+
+    class Slot:                                   # what GopCoder.pack needs of a block
+        def __init__(self, tensor):
+            self.ptr, self.nbytes = tensor.data_ptr(), tensor.numel() * 8
+
+    box = {"slot_words": 0, "out": None, "slots": None, "gl": None, "pend": [None, None], "sent": 0,
+           "probe": [Slot(torch.zeros(record_max // 8, dtype=torch.int64, device=device)) for _ in range(ncoders)] if gather else None}
+    packed_ev = [torch.cuda.Event() for _ in range(ncoders)]
     state = {"s": 0}
 
+    def send(ob, k):
+        """Gather outbox `ob` from stream k once the other pipelines' packs into it are done."""
+        for k2 in range(ncoders):
+            if k2 != k:
+                streams[k].wait_event(packed_ev[k2])
+        box["pend"][ob] = dist.gather(box["out"][ob].view(-1), box["gl"][ob], dst=0, async_op=True)
+        box["sent"] += 1
+
     def step():
-        k = state["s"] % ncoders
+        s = state["s"]
         state["s"] += 1
+        k = s % ncoders
         with torch.cuda.stream(streams[k]):
-            if pending[k] is not None:
-                pending[k].wait()             # this pipeline's previous record has left (stream-side wait)
-                pending[k] = None
+            if not gather:
+                coders[k].encode()
+                return
+            if not box["slot_words"]:             # warm-up: pack only, to learn the record size
+                coders[k].encode()
+                coders[k].pack(box["probe"][k])
+                return
+            j, ob = s % G, (s // G) % 2
+            if j < ncoders and box["pend"][ob] is not None:
+                box["pend"][ob].wait()            # stream-side: this outbox's previous transfer has left
             coders[k].encode()
-            if gather:
-                pending[k] = dist.gather(arenas[k].tensor, gl[k], dst=0, async_op=True)
+            coders[k].pack(box["slots"][ob][j])
+            packed_ev[k].record(streams[k])
+            if j == G - 1:
+                send(ob, k)
 
     def drain():
-        for k in range(ncoders):
-            if pending[k] is not None:
-                with torch.cuda.stream(streams[k]):
-                    pending[k].wait()
-                pending[k] = None
+        if gather and box["slot_words"] and state["s"] % G:       # a partly filled outbox
+            k = (state["s"] - 1) % ncoders
+            with torch.cuda.stream(streams[k]):
+                send((state["s"] // G) % 2, k)
+            state["s"] += G - state["s"] % G
+        for ob in range(2):
+            if gather and box["pend"][ob] is not None:
+                box["pend"][ob].wait()
+                box["pend"][ob] = None
 
     for _ in range(args.warmup):
         step()
     drain()
+    if gather:
+        torch.cuda.synchronize(device)
+        done = min(ncoders, args.warmup)
+        heads = []
+        for k in range(done):
+            buf = np.zeros(4, dtype=np.uint64)
+            nat.check(nat.lib().rbf_memcpy_d2h(ctxs[k].handle, buf.ctypes.data, box["probe"][k].ptr, 32))
+            heads.append(int(buf[2]))
+        used = max(heads) if heads else record_max
+        agreed = torch.tensor([used], dtype=torch.int64, device=device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
+        slot_bytes = min(record_max, (int(agreed.item()) * 102 // 100 + 4096 + 255) // 256 * 256)
+        box["slot_words"] = slot_bytes // 8
+        box["out"] = [torch.zeros(G, box["slot_words"], dtype=torch.int64, device=device) for _ in range(2)]
+        box["slots"] = [[Slot(o[j]) for j in range(G)] for o in box["out"]]
+        box["gl"] = [[torch.empty(G * box["slot_words"], dtype=torch.int64, device=device) for _ in range(world)] if rank == 0 else None
+                     for _ in range(2)]
+        box["probe"] = None
+        state["s"] = 0
+        for _ in range(2 * G):                    # untimed: the first RCCL transfer of both outboxes
+            step()
+        drain()
     torch.cuda.synchronize(device)
     if not args.no_kernel_timing:
         # HIP events around the DOMINANT kernel only (query): two events per step on the launching
@@ -180,9 +245,25 @@ def main():
         "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), %s, threshold 0"
                                % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3"),
                    "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
+                   "gather_bytes_per_rank_per_step": box["slot_words"] * 8 if gather else 0, "steps_per_gather": G if gather else 0,
                    "lds_tile_kib": args.lds_tile_kib or "auto",
                    "stages": "residual mask -> host params -> insert -> query+witness"},
     }
+    if rank == 0 and gather:
+        # what arrived on rank 0 is complete: every slot of every rank has the right magic and frame
+        # count, no overflow flag, a size that fits the slot; rank 0's own record matches its rows
+        from new_bloom_filter_repo_amd.dist import RECORD_MAGIC, unpack_device_record
+        sw = box["slot_words"]
+        for ob in range(2):
+            for r in range(world):
+                heads = box["gl"][ob][r].view(G, sw)[:, :4].cpu().numpy().view(np.uint64)
+                for j in range(G):
+                    h = heads[j]
+                    if int(h[0]) != RECORD_MAGIC or int(h[1]) != pairs or int(h[3]) != 0 or int(h[2]) > sw * 8:
+                        raise SystemExit("gathered record of rank %d (outbox %d slot %d) is damaged: %s" % (r, ob, j, h.tolist()))
+        mine = box["gl"][0][0].view(G, sw)[0].cpu().numpy().view(np.uint8)
+        for got, want in zip(unpack_device_record(mine, n), res):
+            assert got["witness_bits"] == want["witness_bits"] and np.array_equal(got["witness"], want["witness"]), "gathered record differs"
     if rank == 0:
         l_sum = sum(r["l"] for r in res)
         w_sum = sum(r["witness_bits"] for r in res)

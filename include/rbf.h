@@ -101,7 +101,8 @@ int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes); 
 #define RBF_K_REDUCE  8
 #define RBF_K_SCAN    9
 #define RBF_K_NOISE   10
-#define RBF_K_COUNT   11
+#define RBF_K_PACK    11
+#define RBF_K_COUNT   12
 int rbf_timing_enable(rbf_ctx *ctx, int on);
 /* Testing knob (bit mask): bit 0 = always use the generic (global-memory filter) kernels;
  * bit 1 = LDS fast path without double-buffering the filter.  0 (default) = pick the fastest
@@ -185,6 +186,24 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
                    void *filters_dev, uint64_t filter_stride_bytes,
                    void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
                    rbf_filter_params *params_out, double *k_out);
+
+/* ---- exact-size record of a batch (what the gather to rank 0 moves) ------------- */
+/* Compacts the padded output rows of an encode into ONE contiguous self-describing block on the
+ * device, without the host learning the witness lengths.  Little-endian uint64 words:
+ *   [0] "RBFREC01"  [1] nframes  [2] used bytes  [3] 1 if capacity_bytes was too small (payload incomplete)
+ *   per frame 8 words: m, floor_k, threshold, k (float64 bits), witness_bits, filter_ones,
+ *                      filter_offset, witness_offset (bytes from the start of the block)
+ *   payload, 8-byte aligned rows: filter ceil(m/64)*8 bytes -- or, for a frame the reference does
+ *   not Bloom-code (m == 0; :215-225 returns the input itself), its packed mask ceil(n/64)*8 bytes --
+ *   and witness ceil(witness_bits/64)*8 bytes.
+ * params / k: the host arrays rbf_encode_gop or rbf_plan_batch filled (k nullable -> 0.0).
+ * rbf_record_max_bytes: a capacity that can never overflow. */
+uint64_t rbf_record_max_bytes(uint32_t nframes, uint64_t n);
+int rbf_pack_records(rbf_ctx *ctx, uint32_t nframes, uint64_t n, const rbf_filter_params *params, const double *k,
+                     const void *masks_dev, uint64_t mask_stride_bytes,
+                     const void *filters_dev, uint64_t filter_stride_bytes,
+                     const void *witnesses_dev, uint64_t witness_stride_bytes,
+                     const uint64_t *stats_dev, void *record_dev, uint64_t capacity_bytes);
 
 /* ---- A6: decode  (BloomFilterCompressor.decompress loop, :286-307) ------------------------ */
 /* out mask bit i = witness[w++] if position i passes the filter, else 0. */

@@ -14,8 +14,8 @@ RBF_ENOMEM = -12
 RBF_EIO = -5
 RBF_ERANGE = -34
 
-K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE = range(11)
-KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise"]
+K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE, K_PACK = range(12)
+KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack"]
 STATS_PER_FRAME = 4
 
 
@@ -57,6 +57,9 @@ _PROTOS = {
     "rbf_encode_gop": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, ctypes.POINTER(Seeds),
                               _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
     "rbf_residual_mask_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, _vp, _u64, _vp]),
+    "rbf_record_max_bytes": (_u64, [_u32, _u64]),
+    "rbf_pack_records": (_int, [_vp, _u32, _u64, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double),
+                                _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64]),
     "rbf_noise_moments_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _vp, _vp]),
     "rbf_bloom_encode_batch": (_int, [_vp, _vp, _u64, _u64, _u32, ctypes.POINTER(FilterParams), ctypes.POINTER(Seeds),
                                       _vp, _u64, _vp, _u64, _vp]),

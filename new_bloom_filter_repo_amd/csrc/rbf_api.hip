@@ -3,6 +3,7 @@
 #include "../../include/rbf.h"
 #include "rbf_kernels_lds.h"
 #include "rbf_kernels_noise.h"
+#include "rbf_kernels_pack.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -49,6 +50,7 @@ struct rbf_ctx {
     uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
     uint32_t *partials = nullptr;    size_t partials_cap = 0;
     int32_t *thr_tab = nullptr;      size_t thr_tab_cap = 0;      // per-pair thresholds of the mask kernels
+    uint64_t *pack_base = nullptr;   size_t pack_base_cap = 0;    // running record size between pack chunks
     int force_generic = 0;           // tests: 1 = never use the LDS fast path
     int single_buffer = 0;           // tests: 1 = fast query path without filter double-buffering
     uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
@@ -174,6 +176,7 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->thr_tab) (void)hipFree(ctx->thr_tab);
+    if (ctx->pack_base) (void)hipFree(ctx->pack_base);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RBF_OK;
@@ -773,6 +776,49 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
     if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)pairs * sizeof(double));
     return encode_batch_impl(ctx, masks_dev, mask_stride_bytes, n, pairs, ctx->plan.data(), seeds,
                              filters_dev, filter_stride_bytes, witnesses_dev, witness_stride_bytes, stats_dev, true);
+}
+
+// ------------------------------------------------------------------------------------------
+// exact-size record of a batch (what the multi-GPU gather moves)
+// ------------------------------------------------------------------------------------------
+uint64_t rbf_record_max_bytes(uint32_t nframes, uint64_t n)
+{
+    // header + per frame: a filter (or the passthrough mask) and a witness of at most n bits each
+    return (uint64_t)(RECORD_HEADER_WORDS + RECORD_ROW_WORDS * (uint64_t)nframes) * 8 + (uint64_t)nframes * 2 * (((n + 63) / 64) * 8);
+}
+
+int rbf_pack_records(rbf_ctx *ctx, uint32_t nframes, uint64_t n, const rbf_filter_params *params, const double *k,
+                     const void *masks_dev, uint64_t mask_stride_bytes,
+                     const void *filters_dev, uint64_t filter_stride_bytes,
+                     const void *witnesses_dev, uint64_t witness_stride_bytes,
+                     const uint64_t *stats_dev, void *record_dev, uint64_t capacity_bytes)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!params || !masks_dev || !filters_dev || !witnesses_dev || !stats_dev || !record_dev) return fail(RBF_EINVAL, "null pointer");
+    if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
+    if (filter_stride_bytes % 8 || witness_stride_bytes % 8 || ((uintptr_t)record_dev % 8)) return fail(RBF_EINVAL, "strides and the record must be 8-byte aligned");
+    const uint64_t header = (uint64_t)(RECORD_HEADER_WORDS + RECORD_ROW_WORDS * (uint64_t)nframes) * 8;
+    if (capacity_bytes < header || capacity_bytes % 8) return fail(RBF_EINVAL, "record capacity %llu is smaller than the %llu-byte header or misaligned",
+                                                                  (unsigned long long)capacity_bytes, (unsigned long long)header);
+    for (uint32_t f = 0; f < nframes; ++f)
+        if (params[f].m && ((uint64_t)params[f].m + 63) / 64 * 8 > filter_stride_bytes) return fail(RBF_EINVAL, "frame %u: filter of %u bits exceeds the filter stride", f, params[f].m);
+    if (int r = grow((void **)&ctx->pack_base, &ctx->pack_base_cap, ((size_t)nframes / PACK_BATCH + 2) * 8)) return r;
+    for (uint32_t first = 0; first < nframes; first += PACK_BATCH) {
+        const uint32_t cnt = nframes - first < (uint32_t)PACK_BATCH ? nframes - first : (uint32_t)PACK_BATCH;
+        PackTable tab{};
+        for (uint32_t i = 0; i < cnt; ++i) {
+            PackRow &r = tab.r[i];
+            r.m = params[first + i].m; r.floor_k = params[first + i].floor_k; r.threshold = params[first + i].threshold;
+            const double kv = k ? k[first + i] : 0.0;
+            memcpy(&r.k_bits, &kv, 8);
+        }
+        LaunchTimer t(ctx, RBF_K_PACK);
+        hipLaunchKernelGGL(k_pack_records, dim3(8, 2 * cnt), dim3(256), 0, ctx->stream, tab, first, cnt, nframes, n, stats_dev,
+                           (const uint8_t *)masks_dev, mask_stride_bytes, (const uint8_t *)filters_dev, filter_stride_bytes,
+                           (const uint8_t *)witnesses_dev, witness_stride_bytes, (uint64_t *)record_dev, capacity_bytes, ctx->pack_base);
+    }
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
 }
 
 // ------------------------------------------------------------------------------------------

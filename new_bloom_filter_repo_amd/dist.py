@@ -45,6 +45,42 @@ def unpack_records(buf):
     return out
 
 
+RECORD_MAGIC = 0x3130434552464252          # "RBFREC01", csrc/rbf_kernels_pack.h
+
+
+def record_used_bytes(buf):
+    """Used bytes of a device-packed record (its header is enough: pass at least the first 32 bytes)."""
+    head = np.frombuffer(bytes(buf[:32]), dtype="<u8")
+    if int(head[0]) != RECORD_MAGIC:
+        raise ValueError("not a packed record")
+    return int(head[2])
+
+
+def unpack_device_record(buf, n):
+    """Parse the block rbf_pack_records wrote (GopCoder.pack): list of per-frame dicts with the
+    packed filter / witness bytes (numpy.packbits order), or the packed mask for frames the
+    reference does not Bloom-code (l == 0)."""
+    raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+    head = raw[:32].view("<u8")
+    if int(head[0]) != RECORD_MAGIC:
+        raise ValueError("not a packed record")
+    nframes, used, overflow = int(head[1]), int(head[2]), int(head[3])
+    if overflow or used > raw.size:
+        raise ValueError("packed record is truncated: %d bytes used, %d present%s" % (used, raw.size, " (overflow flagged)" if overflow else ""))
+    rows = raw[32:32 + 64 * nframes].view("<u8").reshape(nframes, 8)
+    out = []
+    for m, floor_k, thr, kbits, wbits, fones, foff, woff in rows.tolist():
+        k = struct.unpack("<d", struct.pack("<Q", kbits))[0]
+        rec = {"l": m, "floor_k": floor_k, "threshold": thr, "k": k, "witness_bits": wbits, "filter_ones": fones}
+        if m:
+            rec["filter"] = raw[foff:foff + (m + 7) // 8].copy()
+        else:
+            rec["mask"] = raw[foff:foff + (n + 7) // 8].copy()
+        rec["witness"] = raw[woff:woff + (wbits + 7) // 8].copy()
+        out.append(rec)
+    return out
+
+
 def gather_records(records, dst=0, group=None, device=None):
     """Gather every rank's [(frame_index, type, bytes)] to `dst`; returns the merged list sorted by
     frame index on dst, None elsewhere.  Works on any backend (tensors live on `device`)."""

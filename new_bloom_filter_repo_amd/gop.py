@@ -77,7 +77,7 @@ class GopCoder:
         alloc = allocator or owned_allocator(ctx)
         self.frame_bytes = self.n * channels * sample_bytes
         self.mask_stride, self.filter_stride, self.witness_stride = self.strides(self.n)
-        oalloc = out_allocator or alloc
+        oalloc = self._out_alloc = out_allocator or alloc
         self.frames = frames_block if frames_block is not None else alloc(self.frame_bytes * nframes)
         self.masks = alloc(self.mask_stride * self.pairs)
         self.ones = alloc(8 * self.pairs)
@@ -146,6 +146,19 @@ class GopCoder:
             self.masks.ptr, self.mask_stride, self.ones.ptr,
             self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr,
             self.params, self.k))
+
+    def pack(self, block=None):
+        """Compact this GOP's output rows into one exact-size record on the device (rbf_pack_records);
+        returns the block holding it.  `block`: where to put it (default: a block of the worst-case size)."""
+        if block is None:
+            if getattr(self, "record", None) is None:
+                self.record = self._out_alloc(int(nat.lib().rbf_record_max_bytes(self.pairs, self.n)))
+            block = self.record
+        nat.check(nat.lib().rbf_pack_records(
+            self.ctx.handle, self.pairs, self.n, self.params, self.k, self.masks.ptr, self.mask_stride,
+            self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr,
+            block.ptr, block.nbytes // 8 * 8))
+        return block
 
     def results(self):
         """Download: list of per-frame dicts (mask/filter/witness packed uint8, counts, k, l)."""

@@ -67,3 +67,31 @@ def test_gather_records_gloo_world2():
     assert all(ln == 50 + 37 * t for t, _, ln, _ in merged)
     for item in other:                      # rank 1's own records arrived intact on rank 0
         assert item in merged
+
+
+def test_unpack_device_record_parser():
+    """The parser of the device-packed record (layout of csrc/rbf_kernels_pack.h) on a hand-built block."""
+    import struct
+    from new_bloom_filter_repo_amd.dist import RECORD_MAGIC, record_used_bytes, unpack_device_record
+    n = 100
+    filt = np.arange(16, dtype=np.uint8)            # m = 120 bits -> 15 bytes used, 16-byte row
+    wit = np.array([0xAB, 0xC0] + [0] * 6, np.uint8)
+    mask = np.arange(16, dtype=np.uint8) + 100      # n = 100 bits -> 13 bytes used, 16-byte row
+    header = 32 + 2 * 64
+    rows = [(120, 2, 12345, struct.unpack("<Q", struct.pack("<d", 2.5))[0], 10, 55, header, header + 16),
+            (0, 0, 0, 0, 0, 0, header + 24, header + 40)]
+    words = [RECORD_MAGIC, 2, header + 40, 0] + [v for r in rows for v in r]
+    blob = np.concatenate([np.array(words, dtype="<u8").view(np.uint8), filt, wit, mask])
+    assert record_used_bytes(blob) == len(blob)
+    a, b = unpack_device_record(blob, n)
+    assert (a["l"], a["floor_k"], a["threshold"], a["k"], a["witness_bits"], a["filter_ones"]) == (120, 2, 12345, 2.5, 10, 55)
+    assert a["filter"].tolist() == list(range(15)) and a["witness"].tolist() == [0xAB, 0xC0]
+    assert b["l"] == 0 and b["mask"].tolist() == list(range(100, 113)) and len(b["witness"]) == 0
+    import pytest
+    with pytest.raises(ValueError):
+        unpack_device_record(blob[:-8], n)
+    bad = blob.copy(); bad[24] = 1
+    with pytest.raises(ValueError, match="overflow"):
+        unpack_device_record(bad, n)
+    with pytest.raises(ValueError, match="not a packed record"):
+        unpack_device_record(np.zeros(64, np.uint8), n)

@@ -253,3 +253,52 @@ def test_bloom_compress_front_ends_match_reference_bytes(ctx):
         blob, ratio = comp.compress_text(txt, 8)
         assert blob == z[name + "_blob"].tobytes() and float(ratio).hex() == meta[name]["ratio_hex"]
         assert comp.decompress_text(blob) == txt
+
+
+def test_device_packed_record_matches_rows(ctx):
+    """rbf_pack_records: the exact-size record the multi-GPU gather moves holds the same filters and
+    witnesses as the padded rows, incl. frames the reference does not Bloom-code (their mask travels),
+    more than 128 frames (several kernel-argument chunks), and a block that is too small."""
+    from new_bloom_filter_repo_amd.dist import record_used_bytes, unpack_device_record
+    from new_bloom_filter_repo_amd.gop import GopCoder
+    base = make_gop(41, 64, 48, 1)[0]
+    rng = np.random.default_rng(6)
+    frames = [base]
+    for p in (0.05, 0.5, 0.0, 0.2, 0.001):
+        frames.append(next_frame(rng, frames[-1], p) if p else frames[-1].copy())
+    for fr in (np.stack(frames), np.stack(make_gop(42, 32, 16, 140, p=0.08))):
+        F, H, W = fr.shape[:3]
+        n = H * W
+        coder = GopCoder(ctx, W, H, F)
+        coder.load_frames(fr)
+        coder.encode()
+        block = coder.pack()
+        res = coder.results()
+        raw = block.numpy(ctx)
+        used = record_used_bytes(raw)
+        want_used = 32 + 64 * (F - 1) + sum(((r["l"] or n) + 63) // 64 * 8 + (r["witness_bits"] + 63) // 64 * 8 for r in res)
+        assert used == want_used <= len(raw)
+        recs = unpack_device_record(raw[:used], n)
+        assert len(recs) == F - 1
+        for r, g in zip(res, recs):
+            assert (g["l"], g["floor_k"], g["threshold"], g["k"], g["witness_bits"], g["filter_ones"]) == \
+                   (r["l"], r["floor_k"], r["threshold"], r["k"], r["witness_bits"], r["filter_ones"])
+            if r["l"]:
+                assert np.array_equal(g["filter"], r["filter"]) and "mask" not in g
+            else:
+                assert np.array_equal(g["mask"], r["mask"]) and g["witness_bits"] == 0
+            assert np.array_equal(g["witness"], r["witness"])
+        # a block that is too small is flagged, never overrun
+        small = ctx.alloc(used - 8 + 64)
+        nat.check(nat.lib().rbf_memset(ctx.handle, small.ptr, 0xEE, small.nbytes))
+        from new_bloom_filter_repo_amd.gop import _OwnedBlock
+        class Cut(_OwnedBlock):
+            pass
+        cut = Cut(small); cut.nbytes = used - 8
+        coder.pack(cut)
+        got = small.download()
+        assert np.all(got[used - 8:] == 0xEE)
+        with pytest.raises(ValueError, match="truncated"):
+            unpack_device_record(got[:used - 8], n)
+        small.free()
+    assert nat.lib().rbf_pack_records(ctx.handle, 1, 64, coder.params, None, 1, 8, 1, 8, 1, 8, 1, 1, 8) != 0   # capacity < header
