@@ -32,6 +32,9 @@ struct Seeds { uint64_t h1, h2, act; };
 constexpr int MAX_BATCH = 128;
 struct FrameTable { FrameDev f[MAX_BATCH]; };
 
+// 32-bit words of an m-bit filter; m may be 2^32 - 1, so the rounding is done in 64 bits
+__device__ __forceinline__ uint32_t filter_words(uint32_t m) { return (uint32_t)(((uint64_t)m + 31u) >> 5); }
+
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
 // Packed vectors are MSB-first per byte (numpy.packbits).  In a little-endian 32-bit word the

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const FrameDev fd = tab.f[f];
     if (fd.m == 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t fwords = (fd.m + 31u) >> 5;
+    const uint32_t fwords = filter_words(fd.m);
     const uint32_t tile0 = blockIdx.z * tile_words;               // first word of my tile
     if (tile0 >= fwords) return;
     const uint32_t tile_bit0 = tile0 << 5, tile_bits = tile_words << 5;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
     __shared__ uint32_t red[WG_WAVES];
     const uint32_t f = blockIdx.y;
     const uint32_t m = tab.f[f].m;
-    const uint32_t fwords = m ? ((m + 31u) >> 5) : 0u;
+    const uint32_t fwords = m ? filter_words(m) : 0u;
     uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
     const uint32_t *part = partials + (uint64_t)f * S * part_stride_words32;
     uint32_t pc = 0;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     uint32_t cur = 0;
     if (DOUBLE_BUFFER && k < nframes && !(AB & 8)) {
         const uint32_t f0 = frame_at(k);
-        dma_filter(lds, filters + (uint64_t)f0 * filter_stride_words32, (tab.f[f0].m + 31u) >> 5, wave, lane, nwaves);
+        dma_filter(lds, filters + (uint64_t)f0 * filter_stride_words32, filter_words(tab.f[f0].m), wave, lane, nwaves);
     }
     while (k < nframes) {
         k = __builtin_amdgcn_readfirstlane(k);                    // frame indices are wave-uniform: scalar table loads
@@ -400,12 +400,12 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
             filt = lds + cur * bufwords;
             if (kn < nframes && !(AB & 8))
                 dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
-                           ((tab.f[fn].m + 31u) >> 5) >> ((AB & 128) ? 1 : 0), wave, (AB & 256) ? (wave < 4 ? lane : 64u) : lane,
+                           filter_words(tab.f[fn].m) >> ((AB & 128) ? 1 : 0), wave, (AB & 256) ? (wave < 4 ? lane : 64u) : lane,
                            (AB & 256) ? 4u : nwaves);
             cur ^= 1u;
         } else {
             __syncthreads();          // previous frame's probes are done
-            if (!(AB & 8)) dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, (fd.m + 31u) >> 5, wave, lane, nwaves);
+            if (!(AB & 8)) dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, filter_words(fd.m), wave, lane, nwaves);
             dma_wait_all();
             __syncthreads();
             filt = lds;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_tiled(
         const uint32_t Thi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.T >> 32));
         const uint32_t Tlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.T);
         const uint64_t T = ((uint64_t)Thi << 32) | Tlo, M = ((uint64_t)Mh << 32) | Ml;
-        const uint32_t fwords = (m + 31u) >> 5;
+        const uint32_t fwords = filter_words(m);
         uint32_t pos0[TQ_P], step[TQ_P], acc[TQ_P];
 #pragma unroll
         for (int it = 0; it < TQ_P; ++it) {

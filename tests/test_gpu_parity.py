@@ -214,3 +214,41 @@ def test_adversarial_filter_lengths(eng, oracle):
         assert np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8)), (m, k)
         dec = eng.decode(n, pl, [r["filter"]], [r["witness"]])
         assert np.array_equal(unpack(dec[0], n), mask), (m, k)
+
+
+def test_filter_lengths_up_to_the_abi_limit(oracle):
+    """m beyond 2^30 (where the small-m reduction no longer applies) up to the ABI limit 2^32 - 1:
+    set bits, witness and round trip against positions computed with the oracle's primitives (a
+    byte-per-bit oracle filter of 4 Gbit would not fit the host)."""
+    import math
+    ctx = nat.Context(0)
+    eng = BloomEngine(ctx)
+    n = 2000
+    mask = make_mask(99, n, 0.15)
+    s1, s2, sa = P.SEEDS_VIDEO
+    for m, k in (((1 << 30) + 7, 2.3), ((1 << 31) + 11, 1.5), ((1 << 32) - 1, 3.25)):
+        fk, pa = math.floor(k), k - math.floor(k)
+
+        def positions(i):
+            h1, h2 = oracle.hash_index(i, s1), oracle.hash_index(i, s2)
+            cnt = fk + (1 if oracle.normalize(oracle.hash_index(i, sa)) < pa else 0)
+            return [oracle.position(h1, h2, j, m) for j in range(cnt)]
+        want = set()
+        for i in np.flatnonzero(mask):
+            want.update(positions(int(i)))
+        pl = [P.filter_params(k, m)]
+        eng.upload_masks(np.packbits(mask)[None, :], n)
+        r = eng.encode(n, pl)[0]
+        filt = r["filter"]
+        assert r["filter_ones"] == len(want)
+        idx = np.fromiter(want, dtype=np.int64)
+        assert np.all((filt[idx >> 3] >> (7 - (idx & 7))) & 1)
+        nz = np.flatnonzero(filt)
+        assert int(np.unpackbits(filt[nz]).sum()) == len(want)             # and nothing else is set
+        wit = [int(mask[i]) for i in range(n) if all(p in want for p in positions(i))]
+        assert r["witness_bits"] == len(wit)
+        assert np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8))
+        dec = eng.decode(n, pl, [r["filter"]], [r["witness"]])
+        assert np.array_equal(unpack(dec[0], n), mask)
+    eng.close()
+    ctx.close()
