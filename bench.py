@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="GOP pipelines in flight per GPU (each its own HIP stream)")
     ap.add_argument("--lds-tile-kib", type=int, default=0, help="cap the LDS filter tile (KiB) -> tiled kernels; 0 = auto (BASELINE config 4 sweep)")
     ap.add_argument("--gather-every", type=int, default=4, help="N>1: steps whose records travel in one RCCL gather")
+    ap.add_argument("--generic-kernels", action="store_true", help="diagnostic: global-memory insert / query kernels instead of the LDS ones")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and gather) even with one rank (smoke-tests the N>1 path)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-kernel HIP events in the timed region")
@@ -91,9 +92,9 @@ def main():
     # of step s overlaps the kernels of step s+1.  Every step still does all of its work inside the
     # timed region.
     ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
-    if args.lds_tile_kib:
+    if args.lds_tile_kib or args.generic_kernels:
         for c in ctxs:
-            c.force_generic((args.lds_tile_kib * 1024 // 256) << 16)      # knob unit: 64 dwords
+            c.force_generic(((args.lds_tile_kib * 1024 // 256) << 16) | (1 if args.generic_kernels else 0))      # tile unit: 64 dwords
     ctx = ctxs[0]
     arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
     coders = []
@@ -246,7 +247,7 @@ def main():
                                % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3"),
                    "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
                    "gather_bytes_per_rank_per_step": box["slot_words"] * 8 if gather else 0, "steps_per_gather": G if gather else 0,
-                   "lds_tile_kib": args.lds_tile_kib or "auto",
+                   "lds_tile_kib": args.lds_tile_kib or "auto", "generic_kernels": bool(args.generic_kernels),
                    "stages": "residual mask -> host params -> insert -> query+witness"},
     }
     if rank == 0 and gather:

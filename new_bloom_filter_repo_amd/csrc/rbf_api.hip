@@ -382,6 +382,8 @@ struct Plan {
     uint64_t nseg; uint32_t words_per_seg;
 };
 
+constexpr uint32_t MAX_INSERT_TILES = 7, MAX_QUERY_TILES = 3;     // measured crossovers, see make_plan
+
 static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n)
 {
     Plan p{};
@@ -403,7 +405,13 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     p.insert_tiles = (p.fwords_max + p.insert_tile_words - 1) / p.insert_tile_words;
     if (p.insert_tiles < 1) p.insert_tiles = 1;
     p.insert_lds_bytes = (size_t)p.insert_tile_words * 4 + queue_bytes;
-    p.fast_insert = !ctx->force_generic && mmax > 0;
+    // Tiling re-hashes (insert) / re-probes (query) every key once per tile, so its cost grows with the
+    // tile count while the global-memory kernels' does not.  Measured ps per (pixel, frame), 4K..16K frames:
+    // insert tiled 3.1 / 5.2 / 6.3 / 10.4 at 3 / 5 / 7 / 10 tiles vs 7.8 generic; query tiled 5.8 / 11.2 at
+    // 2 / 4 tiles vs 8.1-9.0 generic (profiles/r01_large_frames.txt).  Past the crossover the generic kernels run
+    // (16K frames: 59 instead of 9 Gpixel/s).
+    const bool auto_tiles = ctx->tile_words == 0;
+    p.fast_insert = !ctx->force_generic && mmax > 0 && !(auto_tiles && p.insert_tiles > MAX_INSERT_TILES);
     // query
     p.double_buffer = 2 * fbytes <= LDS_LIMIT && !ctx->single_buffer;
     p.query_kind = 0;
@@ -417,6 +425,7 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
             if (ctx->tile_words && ctx->tile_words < p.query_tile_words) p.query_tile_words = ctx->tile_words & ~3u;
             if (p.query_tile_words < 4) p.query_tile_words = 4;
             p.query_lds_bytes = (size_t)(p.query_tile_words < ((p.fwords_max + 3u) & ~3u) ? p.query_tile_words : ((p.fwords_max + 3u) & ~3u)) * 4;
+            if (auto_tiles && (p.fwords_max + p.query_tile_words - 1) / p.query_tile_words > MAX_QUERY_TILES) p.query_kind = 0;
         }
     }
     // slices per frame so that S * tiles * frames ~ one workgroup per CU (256 CUs), at most 32
