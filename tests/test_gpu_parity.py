@@ -252,3 +252,44 @@ def test_filter_lengths_up_to_the_abi_limit(oracle):
         assert np.array_equal(unpack(dec[0], n), mask)
     eng.close()
     ctx.close()
+
+
+def test_three_gigapixel_vector_round_trip(oracle):
+    """n > 2^31 (10-digit keys, 64-bit bit offsets everywhere): encode -> decode reproduces the mask, the
+    counters agree with the data, and sampled keys from the top of the range sit where the oracle's
+    hash puts them.  Size-independent properties only: the CPU oracle would need minutes for 3 Gpixel."""
+    import math
+    n = 3 * (1 << 30) + 5
+    rng = np.random.default_rng(2024)
+    nb = (n + 7) // 8
+    packed = rng.integers(0, 256, nb, dtype=np.uint8)
+    packed &= rng.integers(0, 256, nb, dtype=np.uint8)
+    packed &= rng.integers(0, 256, nb, dtype=np.uint8)                      # density 1/8
+    packed[-1] &= 0xFF << (8 * nb - n) & 0xFF                               # pad bits are zero
+    ones = int(np.bitwise_count(packed).sum(dtype=np.int64))
+    k, l = P.optimal_params(n, np.uint64(ones) / n)
+    assert (1 << 29) < l < (1 << 32) and 1 < k < 2
+    pl = [P.filter_params(k, l)]
+    ctx = nat.Context(0)
+    eng = BloomEngine(ctx)
+    eng.upload_masks(packed[None, :], n)
+    r = eng.encode(n, pl)[0]
+    filt = r["filter"]
+    assert r["filter_ones"] == int(np.bitwise_count(filt).sum(dtype=np.int64))
+    assert ones <= r["witness_bits"] <= n
+    # sampled set pixels from the last bytes of the vector: 10-digit decimal keys
+    s1, s2, sa = P.SEEDS_VIDEO
+    fk, pa = math.floor(k), k - math.floor(k)
+    tail = np.flatnonzero(np.unpackbits(packed[-4096:])) + (nb - 4096) * 8
+    assert len(tail) > 1000 and tail.min() > 3_000_000_000
+    for i in tail[::17]:
+        i = int(i)
+        h1, h2 = oracle.hash_index(i, s1), oracle.hash_index(i, s2)
+        cnt = fk + (1 if oracle.normalize(oracle.hash_index(i, sa)) < pa else 0)
+        for j in range(cnt):
+            pos = oracle.position(h1, h2, j, l)
+            assert (filt[pos >> 3] >> (7 - (pos & 7))) & 1, (i, j)
+    dec = eng.decode(n, pl, [filt], [r["witness"]])
+    assert np.array_equal(dec[0][:nb], packed)
+    eng.close()
+    ctx.close()
