@@ -854,7 +854,7 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
                            (uint64_t *)nullptr, 0u);
     }
     {
-        const uint64_t bx = (pl.nseg + WG_WAVES - 1) / WG_WAVES;
+        const uint64_t bx = ((n + 63) / 64 + WG_THREADS - 1) / WG_THREADS;       // one lane per 64-position word
         LaunchTimer t(ctx, RBF_K_EXPAND);
         hipLaunchKernelGGL(k_expand_mask_p, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                            ctx->pass_words, ctx->seg_off, pl.nseg, wps, (const uint32_t *)witnesses_dev, witness_stride_bytes / 4,

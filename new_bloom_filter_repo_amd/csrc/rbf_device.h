@@ -45,6 +45,8 @@ __device__ __forceinline__ uint32_t msb_bit(uint32_t i) { return 1u << msb_pos(i
 // natural (bit i at position i) <-> MSB-first-per-byte, 32- and 64-bit words (an involution).
 __device__ __forceinline__ uint32_t flip_bytes32(uint32_t x) { return __builtin_bswap32(__builtin_bitreverse32(x)); }
 __device__ __forceinline__ uint64_t flip_bytes64(uint64_t x) { return __builtin_bswap64(__builtin_bitreverse64(x)); }
+// packed dword -> stream bit b at bit 31 - b (MSB-first across the whole dword)
+__device__ __forceinline__ uint32_t flip_order32(uint32_t x) { return __builtin_bswap32(x); }
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // number of set bits of `mask` strictly below this lane

@@ -625,34 +625,44 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     }
 }
 
-// expand for QL_P-word segments (decode fast path)
+// A6 expand: out[i] = witness[rank(i)] where position i passes, else 0 (:299-304).  One lane per 64-position
+// word: its witness bits are the `popc(pass)` stream bits starting at seg_off + (passes of the segment's earlier
+// words); they are fetched as one left-aligned 64-bit window and dealt out to the set bits of the pass word
+// from the lowest position up (a software pdep; ~18 iterations at k* = 2.3).  Reads never leave the row.
 __global__ __launch_bounds__(WG_THREADS) void k_expand_mask_p(
     const uint64_t *__restrict__ pass_words, const uint64_t *__restrict__ seg_off, uint64_t nseg, uint32_t words_per_seg,
     const uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32,
     uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n)
 {
     const uint32_t f = blockIdx.y;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
-    if (seg >= nseg) return;
-    const uint64_t *pw = pass_words + ((uint64_t)f * nseg + seg) * words_per_seg;
-    const uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
-    uint64_t *mask = masks + (uint64_t)f * mask_stride_words64;
-    uint64_t o = seg_off[(uint64_t)f * nseg + seg];
     const uint64_t nwords = (n + 63) >> 6;
-    for (uint32_t it = 0; it < words_per_seg; ++it) {
-        const uint64_t w = seg * words_per_seg + it;
-        if (w >= nwords) break;
-        const uint64_t p = pw[it];
-        bool bit = false;
-        if ((p >> lane) & 1ull) {
-            const uint64_t src = o + rank_below(p);
-            bit = (wit[src >> 5] >> msb_pos((uint32_t)src)) & 1u;
+    const uint64_t w = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x;      // words of consecutive segments are consecutive
+    if (w >= nwords) return;
+    const uint64_t seg = w / words_per_seg;
+    const uint64_t *pwf = pass_words + (uint64_t)f * nseg * words_per_seg;
+    const uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
+    uint64_t o = seg_off[(uint64_t)f * nseg + seg];
+    for (uint64_t j = seg * words_per_seg; j < w; ++j) o += __popcll(pwf[j]);
+    uint64_t p = pwf[w];
+    uint64_t out = 0;
+    if (p) {
+        const uint32_t c = __popcll(p);
+        const uint64_t d0 = o >> 5, dl = (o + c - 1) >> 5;
+        // bswap turns a packed (MSB-first per byte) dword into "stream bit b at bit 31 - b"
+        const uint64_t x0 = d0 < witness_stride_words32 ? flip_order32(wit[d0]) : 0u;
+        const uint64_t x1 = (d0 + 1 <= dl && d0 + 1 < witness_stride_words32) ? flip_order32(wit[d0 + 1]) : 0u;
+        const uint64_t x2 = (d0 + 2 <= dl && d0 + 2 < witness_stride_words32) ? flip_order32(wit[d0 + 2]) : 0u;
+        const uint32_t r = (uint32_t)o & 31u;
+        uint64_t win = ((x0 << 32) | x1) << r;                    // stream bit o + t at bit 63 - t
+        win |= r ? x2 >> (32 - r) : 0ull;
+        while (p) {
+            const uint64_t lsb = p & (0 - p);
+            out |= (int64_t)win < 0 ? lsb : 0ull;
+            win <<= 1;
+            p ^= lsb;
         }
-        const uint64_t word = __ballot(bit);
-        if (lane == 0) mask[w] = flip_bytes64(word);
-        o += __popcll(p);
     }
+    masks[(uint64_t)f * mask_stride_words64 + w] = flip_bytes64(out);
 }
 
 }  // namespace rbf
