@@ -37,9 +37,9 @@ def main():
     ap.add_argument("--frames", type=int, default=30, help="frames per GOP (frames-1 inter-frames are coded)")
     ap.add_argument("--bits", type=int, default=8, choices=(8, 16))
     ap.add_argument("--density", type=float, default=0.0, help="fraction of changed pixels per inter-frame (0 = 0.08889, i.e. k*=2.3; SURVEY 8d density sweep)")
-    ap.add_argument("--streams", type=int, default=2, help="GOP pipelines in flight per GPU (each its own HIP stream)")
+    ap.add_argument("--streams", type=int, default=4, help="GOP pipelines in flight per GPU (each its own HIP stream)")
     ap.add_argument("--lds-tile-kib", type=int, default=0, help="cap the LDS filter tile (KiB) -> tiled kernels; 0 = auto (BASELINE config 4 sweep)")
-    ap.add_argument("--gather-every", type=int, default=4, help="N>1: steps whose records travel in one RCCL gather")
+    ap.add_argument("--gather-every", type=int, default=16, help="N>1: steps whose records travel in one RCCL gather")
     ap.add_argument("--generic-kernels", action="store_true", help="diagnostic: global-memory insert / query kernels instead of the LDS ones")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and gather) even with one rank (smoke-tests the N>1 path)")
@@ -76,6 +76,7 @@ def main():
         torch.cuda.synchronize(device)
     ncoders = max(1, args.streams)
     streams = [torch.cuda.Stream(device) for _ in range(ncoders)]      # none of them is the null stream
+    comm_stream = torch.cuda.Stream(device) if use_dist else None      # orders the gathers after the packs
 
     from new_bloom_filter_repo_amd import _native as nat
     from new_bloom_filter_repo_amd.gop import GopCoder, TorchArena, torch_allocator
@@ -126,12 +127,12 @@ def main():
     packed_ev = [torch.cuda.Event() for _ in range(ncoders)]
     state = {"s": 0}
 
-    def send(ob, k):
-        """Gather outbox `ob` from stream k once the other pipelines' packs into it are done."""
-        for k2 in range(ncoders):
-            if k2 != k:
-                streams[k].wait_event(packed_ev[k2])
-        box["pend"][ob] = dist.gather(box["out"][ob].view(-1), box["gl"][ob], dst=0, async_op=True)
+    def send(ob):
+        """Gather outbox `ob` once every pipeline's packs into it are done; no pipeline stream waits for that."""
+        with torch.cuda.stream(comm_stream):
+            for k2 in range(ncoders):
+                comm_stream.wait_event(packed_ev[k2])
+            box["pend"][ob] = dist.gather(box["out"][ob].view(-1), box["gl"][ob], dst=0, async_op=True)
         box["sent"] += 1
 
     def step():
@@ -153,13 +154,11 @@ def main():
             coders[k].pack(box["slots"][ob][j])
             packed_ev[k].record(streams[k])
             if j == G - 1:
-                send(ob, k)
+                send(ob)
 
     def drain():
         if gather and box["slot_words"] and state["s"] % G:       # a partly filled outbox
-            k = (state["s"] - 1) % ncoders
-            with torch.cuda.stream(streams[k]):
-                send((state["s"] // G) % 2, k)
+            send((state["s"] // G) % 2)
             state["s"] += G - state["s"] % G
         for ob in range(2):
             if gather and box["pend"][ob] is not None:

@@ -18,7 +18,7 @@ def short(name):
 
 for f in sorted(glob.glob(os.path.join(root, "stats*", "**", "*kernel_stats.csv"), recursive=True)):
     print("== kernel stats:", os.path.relpath(f, root),
-          "(default command: 2 GOP pipelines, kernels overlap)" if "stats_default" in f else "(--streams 1: kernels run alone)")
+          "(default command: 4 GOP pipelines, kernels overlap)" if "stats_default" in f else "(--streams 1: kernels run alone)")
     for row in csv.DictReader(open(f)):
         print("  %-60s calls %5s  avg %10.1f ns  total %12s ns  %5s%%" % (
             short(row.get("Name", "")), row.get("Calls"), float(row.get("AverageNs", 0)), row.get("TotalDurationNs"), row.get("Percentage")))
