@@ -242,6 +242,17 @@ int rbf_filter_query_keys(rbf_ctx *ctx, const void *filter_dev, const rbf_filter
 int rbf_gather_values(rbf_ctx *ctx, const void *frame_dev, uint32_t width, uint32_t height,
                       uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes, uint32_t sample_bytes,
                       uint32_t channels, const void *mask_dev, void *values_dev, uint64_t *count_dev);
+/* The same for every pair of a GOP in one call: pair f (f = 0..nframes-2) gathers from frame f+1
+ * under mask f; the blocks are concatenated in frame order, pair f starting at pixel offsets_dev[f]
+ * (offsets_dev: nframes entries, the last one = total changed pixels), i.e. at sample
+ * offsets_dev[f]*channels of values_dev.  Nothing is written past capacity_pixels pixels.
+ * uncovered_dev (nullable, nframes-1 entries): pixels whose mask bit is 0 although some channel
+ * differs between frame f and f+1 -- changes a luma-only mask cannot carry (:849-909 applies the
+ * mask to all channels), which a lossless caller must route to a keyframe. */
+int rbf_gather_values_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes, uint32_t nframes,
+                            uint32_t width, uint32_t height, uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                            uint32_t sample_bytes, uint32_t channels, const void *masks_dev, uint64_t mask_stride_bytes,
+                            void *values_dev, uint64_t capacity_pixels, uint64_t *offsets_dev, uint64_t *uncovered_dev);
 /* Inverse: write values back at the mask's '1' pixels (frame_dev is updated in place). */
 int rbf_scatter_values(rbf_ctx *ctx, void *frame_dev, uint32_t width, uint32_t height,
                        uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes, uint32_t sample_bytes,

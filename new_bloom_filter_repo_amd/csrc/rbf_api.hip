@@ -1005,7 +1005,7 @@ static int values_common(rbf_ctx *ctx, void *frame_dev, uint32_t width, uint32_t
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nseg * 8)) return r;
     const uint64_t bx = (nseg + WG_WAVES - 1) / WG_WAVES;
     LaunchTimer t(ctx, scatter ? RBF_K_SCATTER : RBF_K_GATHER);
-    hipLaunchKernelGGL(k_mask_segment_counts, dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (const uint64_t *)mask_dev, n, ctx->seg_cnt, nseg);
+    hipLaunchKernelGGL(k_mask_segment_counts, dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (const uint64_t *)mask_dev, 0ull, n, ctx->seg_cnt, nseg);
     hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, nseg, count_dev, 1u);
     if (sample_bytes == 1) {
         if (scatter) hipLaunchKernelGGL((k_values<uint8_t, true>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint8_t *)values_dev);
@@ -1014,6 +1014,58 @@ static int values_common(rbf_ctx *ctx, void *frame_dev, uint32_t width, uint32_t
         if (scatter) hipLaunchKernelGGL((k_values<uint16_t, true>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint16_t *)values_dev);
         else hipLaunchKernelGGL((k_values<uint16_t, false>), dim3((uint32_t)bx), dim3(WG_THREADS), 0, ctx->stream, (uint8_t *)frame_dev, width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)mask_dev, ctx->seg_off, nseg, (uint16_t *)values_dev);
     }
+    return RBF_OK;
+}
+
+int rbf_gather_values_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes, uint32_t nframes,
+                            uint32_t width, uint32_t height, uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                            uint32_t sample_bytes, uint32_t channels, const void *masks_dev, uint64_t mask_stride_bytes,
+                            void *values_dev, uint64_t capacity_pixels, uint64_t *offsets_dev, uint64_t *uncovered_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!frames_dev || !masks_dev || !values_dev || !offsets_dev) return fail(RBF_EINVAL, "null device pointer");
+    if (nframes < 2) return fail(RBF_EINVAL, "need at least 2 frames, got %u", nframes);
+    if (width == 0 || height == 0) return fail(RBF_EINVAL, "empty frame");
+    if (sample_bytes != 1 && sample_bytes != 2) return fail(RBF_EINVAL, "sample_bytes must be 1 or 2");
+    if (channels == 0 || channels > 4) return fail(RBF_EINVAL, "channels must be 1..4");
+    if (pixel_stride_bytes < channels * sample_bytes || pixel_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "pixel stride incompatible with channels*sample_bytes");
+    if (row_pitch_bytes < (uint64_t)width * pixel_stride_bytes || row_pitch_bytes % sample_bytes) return fail(RBF_EINVAL, "row pitch too small or misaligned");
+    if (frame_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "frame stride misaligned");
+    const uint64_t n = (uint64_t)width * height;
+    const uint32_t pairs = nframes - 1;
+    if (pairs > 65535) return fail(RBF_ERANGE, "at most 65536 frames per call");
+    if (int r = check_frame_geometry(n, pairs, mask_stride_bytes)) return r;
+    const uint64_t nseg = nseg_of(n), nwords = (n + 63) / 64;
+    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)pairs * nseg * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)pairs * nseg * 8)) return r;
+    if (int r = grow((void **)&ctx->pack_base, &ctx->pack_base_cap, ((size_t)pairs + 2) * 8)) return r;     // per-pair totals
+    LaunchTimer t(ctx, RBF_K_GATHER);
+    hipLaunchKernelGGL(k_mask_segment_counts, dim3((uint32_t)((nseg + WG_WAVES - 1) / WG_WAVES), pairs), dim3(WG_THREADS), 0, ctx->stream,
+                       (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, ctx->seg_cnt, nseg);
+    hipLaunchKernelGGL(k_scan_segments, dim3(pairs), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, nseg, ctx->pack_base, 1u);
+    hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(64), 0, ctx->stream, ctx->pack_base, offsets_dev, pairs);
+    const dim3 grid((uint32_t)((nwords + WG_THREADS - 1) / WG_THREADS), pairs);
+    if (sample_bytes == 1)
+        hipLaunchKernelGGL(k_gather_words<uint8_t>, grid, dim3(WG_THREADS), 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes, width, n,
+                           row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)masks_dev, mask_stride_bytes / 8, ctx->seg_off, nseg,
+                           offsets_dev, (uint8_t *)values_dev, capacity_pixels);
+    else
+        hipLaunchKernelGGL(k_gather_words<uint16_t>, grid, dim3(WG_THREADS), 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes, width, n,
+                           row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)masks_dev, mask_stride_bytes / 8, ctx->seg_off, nseg,
+                           offsets_dev, (uint16_t *)values_dev, capacity_pixels);
+    if (uncovered_dev) {
+        HIP_TRY(hipMemsetAsync(uncovered_dev, 0, (size_t)pairs * 8, ctx->stream));
+        uint64_t bx = (n + WG_THREADS * 8 - 1) / (WG_THREADS * 8);
+        if (bx < 1) bx = 1;
+        if (bx > 4096) bx = 4096;
+        if (sample_bytes == 1)
+            hipLaunchKernelGGL(k_uncovered_changes<uint8_t>, dim3((uint32_t)bx, pairs), dim3(WG_THREADS), 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
+                               width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)masks_dev, mask_stride_bytes / 8, (unsigned long long *)uncovered_dev);
+        else
+            hipLaunchKernelGGL(k_uncovered_changes<uint16_t>, dim3((uint32_t)bx, pairs), dim3(WG_THREADS), 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
+                               width, n, row_pitch_bytes, pixel_stride_bytes, channels, (const uint64_t *)masks_dev, mask_stride_bytes / 8, (unsigned long long *)uncovered_dev);
+    }
+    HIP_TRY(hipGetLastError());
     return RBF_OK;
 }
 

@@ -338,19 +338,20 @@ __global__ __launch_bounds__(WG_THREADS) void k_keys(
 // ------------------------------------------------------------------------------------------
 // A2 / A8  changed-value gather / scatter in raster order (:811-842, :886-903)
 // ------------------------------------------------------------------------------------------
-// segment popcounts of a packed mask (one wave per segment)
+// segment popcounts of packed masks (one wave per segment; blockIdx.y = mask of the batch)
 __global__ __launch_bounds__(WG_THREADS) void k_mask_segment_counts(
-    const uint64_t *__restrict__ mask, uint64_t n, uint32_t *__restrict__ seg_cnt, uint64_t nseg)
+    const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n, uint32_t *__restrict__ seg_cnt, uint64_t nseg)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
     if (seg >= nseg) return;
+    const uint64_t *mask = masks + (uint64_t)blockIdx.y * mask_stride_words64;
     const uint64_t nwords = (n + 63) >> 6;
     const uint64_t w = seg * SEG_ITERS + lane;
     uint32_t c = (lane < SEG_ITERS && w < nwords) ? __popcll(mask[w]) : 0u;
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) c += __shfl_down(c, d);
-    if (lane == 0) seg_cnt[seg] = c;
+    if (lane == 0) seg_cnt[(uint64_t)blockIdx.y * nseg + seg] = c;
 }
 
 template <typename SAMPLE, bool SCATTER>
@@ -379,6 +380,86 @@ __global__ __launch_bounds__(WG_THREADS) void k_values(
         }
         o += __popcll(p);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// A2 for a whole GOP: the changed values of every pair, concatenated in frame order
+// ------------------------------------------------------------------------------------------
+// exclusive scan of a short array by one thread (one entry per frame pair)
+__global__ void k_frame_offsets(const uint64_t *__restrict__ totals, uint64_t *__restrict__ offsets, uint32_t count)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < count; ++i) { offsets[i] = acc; acc += totals[i]; }
+        offsets[count] = acc;
+    }
+}
+
+// One lane per 64-pixel mask word of pair f = blockIdx.y; the pair's values come from frame f+1 (`curr`, :811-842)
+// and land at (frame_off[f] + rank of the pixel within the mask) * channels.  Nothing is written past `capacity`
+// pixels (the caller sizes the buffer from the ones counts it already has).
+template <typename SAMPLE>
+__global__ __launch_bounds__(WG_THREADS) void k_gather_words(
+    const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t width, uint64_t n, uint64_t row_pitch, uint32_t pixel_stride,
+    uint32_t channels, const uint64_t *__restrict__ masks, uint64_t mask_stride_words64,
+    const uint64_t *__restrict__ seg_off, uint64_t nseg, const uint64_t *__restrict__ frame_off,
+    SAMPLE *__restrict__ values, uint64_t capacity)
+{
+    const uint32_t f = blockIdx.y;
+    const uint64_t nwords = (n + 63) >> 6;
+    const uint64_t w = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x;
+    if (w >= nwords) return;
+    const uint64_t *mask = masks + (uint64_t)f * mask_stride_words64;
+    uint64_t p = flip_bytes64(mask[w]);                           // natural order: bit b = pixel 64w + b
+    if (!p) return;
+    const uint64_t seg = w / SEG_ITERS;
+    uint64_t o = frame_off[f] + seg_off[(uint64_t)f * nseg + seg];
+    for (uint64_t j = seg * SEG_ITERS; j < w; ++j) o += __popcll(mask[j]);
+    const uint8_t *cur = frames + (uint64_t)(f + 1) * frame_stride;
+    const bool flat = row_pitch == (uint64_t)width * pixel_stride;
+    while (p) {
+        const uint32_t b = __builtin_ctzll(p);
+        p &= p - 1;
+        const uint64_t i = w * 64 + b;
+        uint64_t off;
+        if (flat) off = i * pixel_stride;
+        else { const uint64_t y = i / width; off = y * row_pitch + (i - y * width) * pixel_stride; }
+        if (o < capacity) {
+            const SAMPLE *px = (const SAMPLE *)(cur + off);
+            SAMPLE *v = values + o * channels;
+            for (uint32_t c = 0; c < channels; ++c) v[c] = px[c];
+        }
+        ++o;
+    }
+}
+
+// Pixels whose mask bit is 0 although some channel differs between frame f and f+1: the residual the
+// luma-only mask cannot carry (SURVEY 8a row A8 "lossy by construction").  uncovered[f] gets their number.
+template <typename SAMPLE>
+__global__ __launch_bounds__(WG_THREADS) void k_uncovered_changes(
+    const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t width, uint64_t n, uint64_t row_pitch, uint32_t pixel_stride,
+    uint32_t channels, const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, unsigned long long *__restrict__ uncovered)
+{
+    const uint32_t f = blockIdx.y, lane = threadIdx.x & 63u;
+    const uint8_t *prev = frames + (uint64_t)f * frame_stride, *cur = prev + frame_stride;
+    const uint64_t *mask = masks + (uint64_t)f * mask_stride_words64;
+    const bool flat = row_pitch == (uint64_t)width * pixel_stride;
+    uint32_t cnt = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x; i < ((n + 63) & ~63ull); i += (uint64_t)gridDim.x * WG_THREADS) {
+        bool bad = false;
+        if (i < n) {
+            uint64_t off;
+            if (flat) off = i * pixel_stride;
+            else { const uint64_t y = i / width; off = y * row_pitch + (i - y * width) * pixel_stride; }
+            const SAMPLE *a = (const SAMPLE *)(prev + off), *b = (const SAMPLE *)(cur + off);
+            bool diff = false;
+            for (uint32_t c = 0; c < channels; ++c) diff |= a[c] != b[c];
+            const uint64_t word = flip_bytes64(mask[i >> 6]);
+            bad = diff && !((word >> (i & 63)) & 1ull);
+        }
+        cnt += __popcll(__ballot(bad));
+    }
+    if (lane == 0 && cnt) atomicAdd(&uncovered[f], (unsigned long long)cnt);
 }
 
 }  // namespace rbf

@@ -323,6 +323,36 @@ def gather_values(ctx, frame, mask_packed):
     return vals
 
 
+def apply_chain(ctx, base, masks_packed, values_list):
+    """A8 for a run of inter-frames: frame t = frame t-1 with `values_list[t]` written at mask t's '1' pixels
+    (improved_video_compressor.py:849-909).  The frame stays on the device between steps; every
+    reconstructed frame is downloaded once.  Returns the list of frames (copies)."""
+    base = np.ascontiguousarray(base)
+    H, W = base.shape[:2]
+    C = base.shape[2] if base.ndim == 3 else 1
+    sb = base.dtype.itemsize
+    n = H * W
+    stride = nat.packed_stride(n)
+    fb = ctx.alloc(base.nbytes).upload(base)
+    mb = ctx.alloc(stride)
+    vcap = max([8] + [np.asarray(v).nbytes for v in values_list])
+    vb = ctx.alloc(vcap)
+    out = []
+    row = np.zeros(stride, dtype=np.uint8)
+    for mask_packed, values in zip(masks_packed, values_list):
+        row[:] = 0
+        row[:(n + 7) // 8] = np.asarray(mask_packed, dtype=np.uint8)[:(n + 7) // 8]
+        mb.upload(row)
+        values = np.ascontiguousarray(values, dtype=base.dtype).reshape(-1)
+        if values.nbytes:
+            vb.upload(values)
+        nat.check(nat.lib().rbf_scatter_values(ctx.handle, fb.ptr, W, H, W * C * sb, C * sb, sb, C, mb.ptr, vb.ptr))
+        out.append(fb.download(base.nbytes).view(base.dtype).reshape(base.shape).copy())
+    for b in (fb, mb, vb):
+        b.free()
+    return out
+
+
 def scatter_values(ctx, frame, mask_packed, values):
     """Copy of `frame` with `values` written at the mask's '1' pixels, raster order (A8)."""
     frame = np.ascontiguousarray(frame)

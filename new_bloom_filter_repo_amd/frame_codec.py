@@ -212,28 +212,52 @@ class VideoFrameCompressor:
         return YUVFrame(out) if isinstance(base_frame, YUVFrame) else out
 
     # ---- A3-A5 + A7
+    def _build_record(self, p, n, k, bitmap_bits, bitmap_packed, witness_bits, witness_packed, value_count, values_z):
+        """The wire record of improved_video_compressor.py:933-959 from already packed parts
+        (bitmap_packed / witness_packed: numpy.packbits bytes; values_z: zlib-9 of the value bytes)."""
+        bm, wb = bytes(bitmap_packed), bytes(witness_packed)
+        return b"".join([
+            struct.pack("<f", p), struct.pack("<I", n),
+            struct.pack("<f" if self.wire_format == "reference" else "<d", k),
+            struct.pack("<I", bitmap_bits), struct.pack("<I", witness_bits),
+            struct.pack("<I", len(bm)), bm, struct.pack("<I", len(wb)), wb,
+            struct.pack("<I", len(values_z)), struct.pack("<I", value_count), values_z])
+
     def _compress_frame_differences(self, binary_diff, changed_values):
         """(record bytes, ratio) -- improved_video_compressor.py:911-967."""
         flat = np.asarray(binary_diff).flatten()
         bitmap, witness, p, n, _ = self.bloom_compressor.compress(flat)
         k, _l = self.bloom_compressor._calculate_optimal_params(n, p)
-        buf = io.BytesIO()
-        buf.write(struct.pack("<f", p))
-        buf.write(struct.pack("<I", n))
-        buf.write(struct.pack("<f" if self.wire_format == "reference" else "<d", k))
-        buf.write(struct.pack("<I", len(bitmap)))
-        buf.write(struct.pack("<I", len(witness)))
-        bm = np.packbits(bitmap).tobytes()
-        buf.write(struct.pack("<I", len(bm))); buf.write(bm)
-        wb = np.packbits(np.array(witness, dtype=np.uint8)).tobytes()
-        buf.write(struct.pack("<I", len(wb))); buf.write(wb)
         vals = np.asarray(changed_values)
-        vz = zlib.compress(vals.tobytes(), level=9)
-        buf.write(struct.pack("<I", len(vz)))
-        buf.write(struct.pack("<I", len(vals)))
-        buf.write(vz)
-        ratio = (buf.tell() * 8) / (n + len(vals) * 8)
-        return buf.getvalue(), ratio
+        rec = self._build_record(p, n, k, len(bitmap), np.packbits(bitmap).tobytes(), len(witness),
+                                 np.packbits(np.array(witness, dtype=np.uint8)).tobytes(), len(vals),
+                                 zlib.compress(vals.tobytes(), level=9))
+        ratio = (len(rec) * 8) / (n + len(vals) * 8)
+        return rec, ratio
+
+    def _parse_record(self, compressed_data):
+        """Fields of a wire record without decoding anything (:983-1012): dict with p, n, k, bitmap_bits,
+        witness_bits, bitmap (packed bytes), witness (packed bytes), values_z, value_count."""
+        mv = memoryview(compressed_data)
+        off = 0
+
+        def take(fmt):
+            nonlocal off
+            v = struct.unpack_from(fmt, mv, off)[0]
+            off += struct.calcsize(fmt)
+            return v
+        out = {"p": take("<f"), "n": take("<I"), "k": take("<f" if self.wire_format == "reference" else "<d"),
+               "bitmap_bits": take("<I"), "witness_bits": take("<I")}
+        size = take("<I")
+        out["bitmap"] = np.frombuffer(mv[off:off + size], dtype=np.uint8)
+        off += size
+        size = take("<I")
+        out["witness"] = np.frombuffer(mv[off:off + size], dtype=np.uint8)
+        off += size
+        vsize = take("<I")
+        out["value_count"] = take("<I")
+        out["values_z"] = bytes(mv[off:off + vsize])
+        return out
 
     def _decompress_frame_differences(self, compressed_data, frame_shape, dtype=np.uint8):
         """(binary_diff, changed_values) -- improved_video_compressor.py:969-1027."""

@@ -74,7 +74,14 @@ class GopCoder:
         self.thr = 0 if threshold is None else threshold_floor(threshold)
         self.adaptive = adaptive if threshold is None else None
         self.thr_tab = None
-        alloc = allocator or owned_allocator(ctx)
+        base_alloc = allocator or owned_allocator(ctx)
+        self._blocks = []
+
+        def alloc(nbytes):                        # remember what this coder allocated, for close()
+            b = base_alloc(nbytes)
+            self._blocks.append(b)
+            return b
+        self._alloc_any = alloc
         self.frame_bytes = self.n * channels * sample_bytes
         self.mask_stride, self.filter_stride, self.witness_stride = self.strides(self.n)
         oalloc = self._out_alloc = out_allocator or alloc
@@ -103,6 +110,13 @@ class GopCoder:
         _, fs, ws = GopCoder.strides(n)
         r = lambda x: (x + 255) // 256 * 256
         return r(fs * pairs) + r(ws * pairs) + r(8 * nat.STATS_PER_FRAME * pairs)
+
+    def close(self):
+        """Free the library-owned blocks this coder allocated (torch-backed blocks die with their tensors)."""
+        for b in self._blocks:
+            if isinstance(b, _OwnedBlock):
+                b.buf.free()
+        self._blocks = []
 
     def load_frames(self, frames):
         frames = np.ascontiguousarray(frames)
@@ -159,6 +173,32 @@ class GopCoder:
             self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr,
             block.ptr, block.nbytes // 8 * 8))
         return block
+
+    def gather_values(self, check_uncovered=False):
+        """A2 for the whole GOP (rbf_gather_values_batch): list of per-pair arrays of the changed pixels'
+        samples (all channels, raster order, frame dtype) taken from frame f+1; with check_uncovered also
+        the per-pair count of pixels that changed in some channel although their mask bit is 0."""
+        self.ctx.sync()
+        ones = self.ones.numpy(self.ctx)[:8 * self.pairs].view(np.uint64)
+        total = int(ones.sum())
+        if getattr(self, "_values", None) is None or self._values.nbytes < max(8, total * self.C * self.sb):
+            self._values = self._alloc_any(max(8, total * self.C * self.sb))
+        if getattr(self, "_voff", None) is None:
+            self._voff = self._alloc_any(8 * (self.pairs + 1))
+            self._uncov = self._alloc_any(8 * self.pairs)
+        nat.check(nat.lib().rbf_gather_values_batch(
+            self.ctx.handle, self.frames.ptr, self.frame_bytes, self.F, self.W, self.H, self.W * self.C * self.sb, self.C * self.sb,
+            self.sb, self.C, self.masks.ptr, self.mask_stride, self._values.ptr, total, self._voff.ptr,
+            self._uncov.ptr if check_uncovered else None))
+        self.ctx.sync()
+        off = self._voff.numpy(self.ctx)[:8 * (self.pairs + 1)].view(np.uint64)
+        assert int(off[-1]) == total, "mask changed since the ones counts were taken"
+        dt = np.uint8 if self.sb == 1 else np.uint16
+        flat = self._values.numpy(self.ctx)[:total * self.C * self.sb].view(dt)
+        vals = [flat[int(off[f]) * self.C:int(off[f + 1]) * self.C].copy() for f in range(self.pairs)]
+        if not check_uncovered:
+            return vals
+        return vals, self._uncov.numpy(self.ctx)[:8 * self.pairs].view(np.uint64).copy()
 
     def results(self):
         """Download: list of per-frame dicts (mask/filter/witness packed uint8, counts, k, l)."""

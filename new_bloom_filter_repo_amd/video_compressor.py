@@ -15,9 +15,12 @@ type-byte precedent of VideoFrameCompressor.compress_frame (:1053).
 import os
 import struct
 import time
+import zlib
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+from . import params as P
 from .frame_codec import FixedVideoCompressor, VideoFrameCompressor, YUVFrame, frame_data
 
 KEY, INTER = 1, 2
@@ -33,6 +36,8 @@ class ImprovedVideoCompressor:
         self.max_diff_threshold = max_diff_threshold
         self.bloom_threshold_modifier = bloom_threshold_modifier
         self.batch_size = batch_size
+        self.num_threads = max(1, num_threads or min(32, os.cpu_count() or 1))     # zlib of keyframes / changed values
+        self.gop_batching = True                 # False: code every inter-frame with its own C-ABI calls
         self.use_direct_yuv = use_direct_yuv
         self.verbose = verbose
         self.compressor = FixedVideoCompressor(verbose=verbose)
@@ -64,6 +69,54 @@ class ImprovedVideoCompressor:
         record, _ = self.inter._compress_frame_differences(mask, values)
         return struct.pack("<B", b.dtype.itemsize) + record
 
+    def _encode_gop(self, seg, pool):
+        """Inter-frame records of one GOP in one pass over the GPU: seg[0] is the keyframe, seg[1:] are
+        coded against their predecessor.  One upload, rbf_encode_gop, one batched gather of the changed
+        values (with the count of changes the luma mask cannot carry); zlib runs in `pool`.
+        Returns a list of futures / None per inter-frame (None = needs a keyframe), or None when the
+        GOP cannot be batched (mixed shapes or dtypes)."""
+        from .gop import GopCoder
+        from . import _native as nat
+        data = [frame_data(f) for f in seg]
+        a = data[0]
+        if a.dtype not in (np.uint8, np.uint16) or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] < 3):
+            return None
+        if any(d.shape != a.shape or d.dtype != a.dtype for d in data[1:]):
+            return None
+        H, W = a.shape[:2]
+        C = a.shape[2] if a.ndim == 3 else 1
+        ctx = self._ctx or nat.default_context()
+        key = (W, H, len(seg), C, a.dtype.itemsize)
+        if getattr(self, "_gop_key", None) != key:
+            if getattr(self, "_gop_coder", None) is not None:
+                self._gop_coder.close()
+            self._gop_coder, self._gop_key = GopCoder(ctx, W, H, len(seg), channels=C, sample_bytes=a.dtype.itemsize), key
+        coder = self._gop_coder
+        coder.load_frames(np.stack(data))
+        coder.encode()
+        res = coder.results()
+        values, uncovered = coder.gather_values(check_uncovered=True)
+        n = H * W
+        inter = self.inter
+        out = []
+        for f, r in enumerate(res):
+            if int(uncovered[f]):                # chroma moved where luma did not: not representable
+                out.append(None)
+                continue
+            p = np.uint64(r["ones"]) / n
+            k, _l = P.optimal_params(n, p)
+            if r["l"]:
+                parts = (r["l"], r["filter"].tobytes(), r["witness_bits"], r["witness"].tobytes())
+            else:                                # the reference passes the mask itself through (:215-225)
+                parts = (n, r["mask"].tobytes(), 0, b"")
+            vals = values[f]
+
+            def job(p=p, k=k, parts=parts, vals=vals):
+                vz = zlib.compress(vals.tobytes(), level=9)
+                return struct.pack("<B", vals.dtype.itemsize) + inter._build_record(p, n, k, *parts, len(vals), vz)
+            out.append(pool.submit(job))
+        return out
+
     def compress_video(self, frames, output_path=None, input_color_space="BGR"):
         if not frames:
             raise ValueError("No frames provided for compression")
@@ -75,12 +128,29 @@ class ImprovedVideoCompressor:
                 if not hasattr(frames[i], "yuv_info"):
                     frames[i] = self.compressor.add_yuv_info_to_frame(frames[i])
         original_size = sum(f.nbytes for f in frames)
-        records = []
-        for t, frame in enumerate(frames):
-            rec = None
-            if yuv and t % self.keyframe_interval != 0:
-                rec = self._encode_inter(frames[t - 1], frame)
-            records.append((INTER, rec) if rec is not None else (KEY, self.compressor.compress_frame(frame)))
+        records = [None] * len(frames)
+        with ThreadPoolExecutor(self.num_threads) as pool:
+            pending = {}                          # frame index -> future of (type, record)
+            for s0 in range(0, len(frames), self.keyframe_interval):
+                seg = frames[s0:s0 + self.keyframe_interval]
+                inter = self._encode_gop(seg, pool) if yuv and self.gop_batching and len(seg) > 1 else None
+                for j, frame in enumerate(seg):
+                    t = s0 + j
+                    fut = None
+                    if j and yuv:
+                        if inter is not None:
+                            fut = inter[j - 1]
+                        else:
+                            rec = self._encode_inter(seg[j - 1], frame)
+                            if rec is not None:
+                                records[t] = (INTER, rec)
+                                continue
+                    if fut is not None:
+                        pending[t] = (INTER, fut)
+                    else:
+                        pending[t] = (KEY, pool.submit(self.compressor.compress_frame, frame))
+            for t, (ty, fut) in pending.items():
+                records[t] = (ty, fut.result())
         self.last_compressed_frames = records
         keyframes = sum(1 for ty, _ in records if ty == KEY)
         blob = self._container(records)
@@ -139,16 +209,27 @@ class ImprovedVideoCompressor:
         if not records:
             raise ValueError("No compressed frames provided")
         frames = []
-        for ty, rec in records:
+        i = 0
+        while i < len(records):
+            ty, rec = records[i]
             if ty == KEY:
                 frames.append(self.compressor.decompress_frame(rec))
+                i += 1
             elif ty == INTER:
                 if not frames:
                     raise ValueError("inter-frame without a preceding keyframe")
-                base = frames[-1]
-                dtype = np.uint8 if rec[0] == 1 else np.uint16
-                mask, values = self.inter._decompress_frame_differences(rec[1:], base.shape, dtype=dtype)
-                frames.append(self.inter._apply_frame_diff(base, mask, values))
+                j = i
+                while j < len(records) and records[j][0] == INTER:
+                    j += 1
+                if self.gop_batching:
+                    frames += self._decode_run(frames[-1], [r for _, r in records[i:j]])
+                else:
+                    for _, r in records[i:j]:
+                        base = frames[-1]
+                        dtype = np.uint8 if r[0] == 1 else np.uint16
+                        mask, values = self.inter._decompress_frame_differences(r[1:], base.shape, dtype=dtype)
+                        frames.append(self.inter._apply_frame_diff(base, mask, values))
+                i = j
             else:
                 raise ValueError(f"unknown record type {ty}")
         if output_path:
@@ -156,6 +237,40 @@ class ImprovedVideoCompressor:
         if self.verbose:
             print(f"Decompressed {len(frames)} frames in {time.time() - start:.2f} seconds")
         return frames
+
+    def _decode_run(self, base, recs):
+        """A run of inter-frame records after `base`: the masks of all Bloom-coded frames are decoded in
+        ONE rbf_bloom_decode_batch, the changed values are inflated in threads, and the frames are
+        rebuilt in sequence on the device (engine.apply_chain)."""
+        from .engine import apply_chain
+        inter = self.inter
+        base_arr = frame_data(base)
+        n = base_arr.shape[0] * base_arr.shape[1]
+        parsed = []
+        for r in recs:
+            d = inter._parse_record(r[1:])
+            if d["n"] != n:
+                raise ValueError("inter-frame record of %d pixels after a frame of %d" % (d["n"], n))
+            d["dtype"] = np.uint8 if r[0] == 1 else np.uint16
+            parsed.append(d)
+        coded = [d for d in parsed if d["witness_bits"] > 0]
+        if coded:
+            plist = [P.filter_params(d["k"], d["bitmap_bits"]) for d in coded]
+            masks = inter._engine.decode(n, plist, [d["bitmap"] for d in coded], [d["witness"] for d in coded])
+            for d, m in zip(coded, masks):
+                d["mask"] = m
+        with ThreadPoolExecutor(self.num_threads) as pool:
+            vals = list(pool.map(lambda d: np.frombuffer(zlib.decompress(d["values_z"]), dtype=d["dtype"])[:d["value_count"]], parsed))
+        masks = [d["mask"] if "mask" in d else d["bitmap"][:(n + 7) // 8] for d in parsed]
+        ch = base_arr.shape[2] if base_arr.ndim == 3 else 1
+        for i, (m, v) in enumerate(zip(masks, vals)):
+            ones = int(np.bitwise_count(np.asarray(m, dtype=np.uint8)[:(n + 7) // 8]).sum())
+            if len(v) != ones * ch:              # same rule as _apply_frame_diff (:886-903)
+                if ch == 1:
+                    raise ValueError("changed_values does not match the mask")
+                masks[i], vals[i] = np.zeros((n + 7) // 8, np.uint8), v[:0]      # color: frame left untouched
+        out = apply_chain(inter._ctx, base_arr, masks, vals)
+        return [YUVFrame(f) for f in out] if isinstance(base, YUVFrame) else out
 
     def verify_lossless(self, original_frames, decompressed_frames):
         return self.compressor.verify_lossless(original_frames, decompressed_frames)

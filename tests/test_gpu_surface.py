@@ -129,6 +129,18 @@ def test_improved_video_compressor_round_trip(ctx, tmp_path, dtype):
     # in-memory records decode as well
     dec2 = comp.decompress_video(compressed_frames=comp.last_compressed_frames)
     assert all(np.array_equal(a, np.asarray(getattr(b, "data", b))) for a, b in zip(frames, dec2))
+    # the GOP-batched route (default) and the frame-by-frame route write the same bytes and decode alike
+    single = pkg.ImprovedVideoCompressor(keyframe_interval=4, verbose=False, ctx=ctx)
+    single.gop_batching = False
+    single.compress_video([f.copy() for f in frames], None, input_color_space="YUV")
+    assert single.last_compressed_frames == comp.last_compressed_frames
+    dec3 = single.decompress_video(compressed_frames=comp.last_compressed_frames)
+    assert all(np.array_equal(a, np.asarray(getattr(b, "data", b))) for a, b in zip(frames, dec3))
+    # luma-only (2-D) frames take the same routes
+    gray = [f[:, :, 0].copy() for f in frames[:4]]
+    comp.compress_video([pkg.YUVFrame(g[:, :, None].repeat(3, axis=2)) for g in gray], None, input_color_space="YUV")
+    dec4 = comp.decompress_video(compressed_frames=comp.last_compressed_frames)
+    assert all(np.array_equal(g, np.asarray(getattr(b, "data", b))[:, :, 0]) for g, b in zip(gray, dec4))
 
 
 def test_sharded_encode_single_rank_container(ctx):
@@ -302,3 +314,58 @@ def test_device_packed_record_matches_rows(ctx):
             unpack_device_record(got[:used - 8], n)
         small.free()
     assert nat.lib().rbf_pack_records(ctx.handle, 1, 64, coder.params, None, 1, 8, 1, 8, 1, 8, 1, 1, 8) != 0   # capacity < header
+
+
+def test_gather_values_batch_matches_per_frame(ctx, oracle):
+    """rbf_gather_values_batch: concatenated changed values of every pair == the per-frame gather == the
+    oracle's frame_diff values; uncovered counts == numpy; padded rows (non-flat frames) and a small capacity."""
+    from new_bloom_filter_repo_amd.engine import gather_values
+    from new_bloom_filter_repo_amd.gop import GopCoder
+    for dtype, C in ((np.uint8, 3), (np.uint16, 3), (np.uint8, 1)):
+        frames = np.stack(make_gop(91, 70, 33, 5, p=0.07, dtype=dtype))
+        frames[3, 5, 7, 1] ^= 1                                   # a chroma-only change in pair 2
+        frames[4] = frames[3]                                     # nothing changes in pair 3
+        if C == 1:
+            frames = np.ascontiguousarray(frames[..., 0])
+        F, H, W = frames.shape[:3]
+        coder = GopCoder(ctx, W, H, F, channels=C, sample_bytes=np.dtype(dtype).itemsize)
+        coder.load_frames(frames)
+        coder.encode()
+        res = coder.results()
+        vals, unc = coder.gather_values(check_uncovered=True)
+        for f in range(F - 1):
+            a, b = frames[f], frames[f + 1]
+            _, want, _ = oracle.frame_diff(a, b, 0.0, yuv_planes=False)
+            assert np.array_equal(vals[f], want) and vals[f].dtype == dtype
+            assert np.array_equal(vals[f], gather_values(ctx, b, res[f]["mask"]))
+            ch = (a != b) if C == 1 else (a != b).any(axis=2)
+            lum = (a != b) if C == 1 else (a[..., 0] != b[..., 0])
+            assert int(unc[f]) == int((ch & ~lum).sum())
+        assert int(unc[2]) == (1 if C == 3 else 0) and len(vals[3]) == 0
+        coder.close()
+    # padded rows and a capacity smaller than the total: nothing is written past it
+    frames = np.stack(make_gop(92, 40, 12, 3, p=0.2))
+    F, H, W, C = frames.shape
+    padded = np.zeros((F, H, W + 9, C), np.uint8)
+    padded[:, :, :W] = frames
+    n, pairs = H * W, F - 1
+    stride = nat.packed_stride(n)
+    masks = np.zeros((pairs, stride), np.uint8)
+    want = []
+    for f in range(pairs):
+        m, v, _ = oracle.frame_diff(frames[f], frames[f + 1], 0.0, yuv_planes=False)
+        masks[f, :(n + 7) // 8] = np.packbits(m.reshape(-1))
+        want.append(v)
+    total = sum(len(v) for v in want) // C
+    fb, mb = ctx.alloc(padded.nbytes).upload(padded), ctx.alloc(masks.nbytes).upload(masks)
+    vb, ob = ctx.alloc(total * C + 64), ctx.alloc(8 * F)
+    nat.check(nat.lib().rbf_memset(ctx.handle, vb.ptr, 0xEE, vb.nbytes))
+    cap = total - 5
+    nat.check(nat.lib().rbf_gather_values_batch(ctx.handle, fb.ptr, padded[0].nbytes, F, W, H, (W + 9) * C, C, 1, C, mb.ptr, stride,
+                                                vb.ptr, cap, ob.ptr, None))
+    off = ob.download(8 * F, dtype=np.uint64)
+    assert off.tolist() == [0, len(want[0]) // C, total]
+    got = vb.download()
+    assert np.array_equal(got[:cap * C], np.concatenate(want)[:cap * C]) and np.all(got[cap * C:] == 0xEE)
+    for b in (fb, mb, vb, ob):
+        b.free()
