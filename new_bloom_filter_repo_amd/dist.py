@@ -119,13 +119,8 @@ def encode_video_sharded(frames, first_index, nframes_total, keyframe_interval=3
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     start, stop = shard_range(nframes_total, world, rank)
     comp = ImprovedVideoCompressor(keyframe_interval=keyframe_interval, ctx=ctx)
-    records = []
-    for t in range(start, stop):
-        cur = frames[t - first_index]
-        rec = None
-        if t % keyframe_interval != 0:
-            rec = comp._encode_inter(frames[t - 1 - first_index], cur)
-        records.append((t, INTER, rec) if rec is not None else (t, KEY, comp.compressor.compress_frame(cur)))
+    coded = comp.encode_range(frames, first_index, start, stop)          # one GOP pass per run of inter-frames
+    records = [(start + i, ty, rec) for i, (ty, rec) in enumerate(coded)]
     merged = gather_records(records, dst=dst, group=group)
     if merged is None:
         return None

@@ -70,8 +70,8 @@ class ImprovedVideoCompressor:
         return struct.pack("<B", b.dtype.itemsize) + record
 
     def _encode_gop(self, seg, pool):
-        """Inter-frame records of one GOP in one pass over the GPU: seg[0] is the keyframe, seg[1:] are
-        coded against their predecessor.  One upload, rbf_encode_gop, one batched gather of the changed
+        """Inter-frame records of one GOP in one pass over the GPU: seg[0] is only read (the keyframe, or a
+        shard's halo frame), seg[1:] are coded against their predecessor.  One upload, rbf_encode_gop, one batched gather of the changed
         values (with the count of changes the luma mask cannot carry); zlib runs in `pool`.
         Returns a list of futures / None per inter-frame (None = needs a keyframe), or None when the
         GOP cannot be batched (mixed shapes or dtypes)."""
@@ -117,6 +117,41 @@ class ImprovedVideoCompressor:
             out.append(pool.submit(job))
         return out
 
+    def encode_range(self, frames, first_index, start, stop, inter_frames=True):
+        """[(type, record)] for the frames with global indices [start, stop); frames[i] is global frame
+        first_index + i (a shard passes its halo frame too, dist.halo_start).  Frame t is a keyframe iff
+        t % keyframe_interval == 0; the inter-frames between two keyframes are coded as one GOP."""
+        records = {}
+        with ThreadPoolExecutor(self.num_threads) as pool:
+            pending = {}
+
+            def key(t):
+                pending[t] = (KEY, pool.submit(self.compressor.compress_frame, frames[t - first_index]))
+            t = start
+            while t < stop:
+                if not inter_frames or t % self.keyframe_interval == 0 or t - 1 < first_index:
+                    key(t)
+                    t += 1
+                    continue
+                end = min(stop, (t // self.keyframe_interval + 1) * self.keyframe_interval)
+                seg = frames[t - 1 - first_index:end - first_index]          # predecessor + the run t..end-1
+                inter = self._encode_gop(seg, pool) if self.gop_batching else None
+                for j in range(1, len(seg)):
+                    fut = inter[j - 1] if inter is not None else None
+                    if inter is None:
+                        rec = self._encode_inter(seg[j - 1], seg[j])
+                        if rec is not None:
+                            records[t - 1 + j] = (INTER, rec)
+                            continue
+                    if fut is not None:
+                        pending[t - 1 + j] = (INTER, fut)
+                    else:
+                        key(t - 1 + j)
+                t = end
+            for u, (ty, fut) in pending.items():
+                records[u] = (ty, fut.result())
+        return [records[u] for u in range(start, stop)]
+
     def compress_video(self, frames, output_path=None, input_color_space="BGR"):
         if not frames:
             raise ValueError("No frames provided for compression")
@@ -128,29 +163,7 @@ class ImprovedVideoCompressor:
                 if not hasattr(frames[i], "yuv_info"):
                     frames[i] = self.compressor.add_yuv_info_to_frame(frames[i])
         original_size = sum(f.nbytes for f in frames)
-        records = [None] * len(frames)
-        with ThreadPoolExecutor(self.num_threads) as pool:
-            pending = {}                          # frame index -> future of (type, record)
-            for s0 in range(0, len(frames), self.keyframe_interval):
-                seg = frames[s0:s0 + self.keyframe_interval]
-                inter = self._encode_gop(seg, pool) if yuv and self.gop_batching and len(seg) > 1 else None
-                for j, frame in enumerate(seg):
-                    t = s0 + j
-                    fut = None
-                    if j and yuv:
-                        if inter is not None:
-                            fut = inter[j - 1]
-                        else:
-                            rec = self._encode_inter(seg[j - 1], frame)
-                            if rec is not None:
-                                records[t] = (INTER, rec)
-                                continue
-                    if fut is not None:
-                        pending[t] = (INTER, fut)
-                    else:
-                        pending[t] = (KEY, pool.submit(self.compressor.compress_frame, frame))
-            for t, (ty, fut) in pending.items():
-                records[t] = (ty, fut.result())
+        records = self.encode_range(frames, 0, 0, len(frames), inter_frames=yuv)
         self.last_compressed_frames = records
         keyframes = sum(1 for ty, _ in records if ty == KEY)
         blob = self._container(records)

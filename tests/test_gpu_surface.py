@@ -157,6 +157,12 @@ def test_sharded_encode_single_rank_container(ctx):
         comp = pkg.ImprovedVideoCompressor(keyframe_interval=3, ctx=ctx)
         comp.compress_video([f.copy() for f in frames], None, input_color_space="YUV")
         assert blob == comp._container(comp.last_compressed_frames)
+        # a shard that starts inside a GOP reads one halo frame and produces the same records
+        full = comp.last_compressed_frames
+        for start, stop in ((1, 3), (2, 6), (4, 5), (3, 6)):
+            first = D.halo_start(start, 3)
+            part = comp.encode_range([pkg.YUVFrame(f) for f in frames[first:stop]], first, start, stop)
+            assert part == full[start:stop], (start, stop)
         dec = comp.decompress_video(compressed_frames=comp._parse_container(blob))
         assert all(np.array_equal(a, np.asarray(getattr(b, "data", b))) for a, b in zip(frames, dec))
     finally:
