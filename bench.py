@@ -112,8 +112,8 @@ def main():
     # N > 1: every step compacts its output rows into an exact-size record on the device
     # (rbf_pack_records) inside an outbox of `--gather-every` slots; a full outbox goes to rank 0 in ONE
     # asynchronous RCCL gather (fewer, larger collectives; two outboxes alternate so packing never waits
-    # for a transfer).  RCCL's gather needs one size on all ranks, so the slot size is agreed once, after
-    # the warm-up steps (max of the ranks' record sizes + 2 %); a record that outgrew its slot would be
+    # for a transfer).  RCCL's gather needs one size on all ranks, so the slot size is agreed once, in setup
+    # (max of the ranks' record sizes + 2 %); a record that outgrew its slot would be
     # flagged in its header (checked on rank 0 after the timed region).
     G = max(1, args.gather_every)
     record_max = (int(nat.lib().rbf_record_max_bytes(pairs, n)) + 255) // 256 * 256
@@ -143,10 +143,6 @@ def main():
             if not gather:
                 coders[k].encode()
                 return
-            if not box["slot_words"]:             # warm-up: pack only, to learn the record size
-                coders[k].encode()
-                coders[k].pack(box["probe"][k])
-                return
             j, ob = s % G, (s // G) % 2
             if j < ncoders and box["pend"][ob] is not None:
                 box["pend"][ob].wait()            # stream-side: this outbox's previous transfer has left
@@ -165,19 +161,19 @@ def main():
                 box["pend"][ob].wait()
                 box["pend"][ob] = None
 
-    for _ in range(args.warmup):
-        step()
-    drain()
+    # setup (not warm-up steps): every pipeline sizes its scratch once, and for N > 1 the ranks agree on the slot
+    for k in range(ncoders):
+        coders[k].encode()
+        if gather:
+            coders[k].pack(box["probe"][k])
+    torch.cuda.synchronize(device)
     if gather:
-        torch.cuda.synchronize(device)
-        done = min(ncoders, args.warmup)
         heads = []
-        for k in range(done):
+        for k in range(ncoders):
             buf = np.zeros(4, dtype=np.uint64)
             nat.check(nat.lib().rbf_memcpy_d2h(ctxs[k].handle, buf.ctypes.data, box["probe"][k].ptr, 32))
             heads.append(int(buf[2]))
-        used = max(heads) if heads else record_max
-        agreed = torch.tensor([used], dtype=torch.int64, device=device)
+        agreed = torch.tensor([max(heads)], dtype=torch.int64, device=device)
         dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
         slot_bytes = min(record_max, (int(agreed.item()) * 102 // 100 + 4096 + 255) // 256 * 256)
         box["slot_words"] = slot_bytes // 8
@@ -186,10 +182,13 @@ def main():
         box["gl"] = [[torch.empty(G * box["slot_words"], dtype=torch.int64, device=device) for _ in range(world)] if rank == 0 else None
                      for _ in range(2)]
         box["probe"] = None
-        state["s"] = 0
-        for _ in range(2 * G):                    # untimed: the first RCCL transfer of both outboxes
+        for _ in range(2 * G):                    # untimed: the first RCCL transfer of both outboxes (connection setup)
             step()
         drain()
+        state["s"] = 0
+    for _ in range(args.warmup):
+        step()
+    drain()
     torch.cuda.synchronize(device)
     if not args.no_kernel_timing:
         # HIP events around the DOMINANT kernel only (query): two events per step on the launching
