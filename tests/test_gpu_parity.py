@@ -293,3 +293,48 @@ def test_three_gigapixel_vector_round_trip(oracle):
     assert np.array_equal(dec[0][:nb], packed)
     eng.close()
     ctx.close()
+
+
+def test_random_geometry_fuzz(oracle):
+    """Seeded fuzz over frame sizes, dtypes, channel layouts, GOP lengths, densities and seed variants: the one-call
+    GOP encoder against the oracle (mask, geometry, filter, witness), and decode back to the mask."""
+    from new_bloom_filter_repo_amd.gop import GopCoder
+    from new_bloom_filter_repo_amd.synthetic import next_frame
+    rng = np.random.default_rng(20250926)
+    ctx = nat.Context(0)
+    eng = BloomEngine(ctx)
+    for case in range(120):
+        W, H = int(rng.integers(1, 260)), int(rng.integers(1, 120))
+        C = int(rng.choice([1, 3]))
+        dtype = [np.uint8, np.uint16][int(rng.integers(0, 2))]
+        F = int(rng.integers(2, 6))
+        seeds = [P.SEEDS_VIDEO, P.SEEDS_BLOOM_COMPRESS, (7, 11, 13)][case % 3]
+        top = np.iinfo(dtype).max
+        frames = [rng.integers(0, top + 1, (H, W, 3), dtype=dtype)]
+        for _ in range(F - 1):
+            p = float(rng.choice([0.0, 0.0005, 0.01, 0.05, 0.0889, 0.15, 0.25, 0.31, 0.33, 0.6, 1.0]))
+            frames.append(next_frame(rng, frames[-1], p) if p else frames[-1].copy())
+        frames = np.stack(frames)
+        if C == 1:
+            frames = np.ascontiguousarray(frames[..., 0])
+        n = W * H
+        coder = GopCoder(ctx, W, H, F, channels=C, sample_bytes=np.dtype(dtype).itemsize, seeds=seeds)
+        coder.load_frames(frames)
+        coder.encode()
+        for f, r in enumerate(coder.results()):
+            y0, y1 = (frames[f], frames[f + 1]) if C == 1 else (frames[f][..., 0], frames[f + 1][..., 0])
+            want = oracle.residual_mask(np.ascontiguousarray(y0), np.ascontiguousarray(y1), 0.0).reshape(-1)
+            assert np.array_equal(unpack(r["mask"], n), want), (case, f)
+            bm, wit, p, _, _ = oracle.compress(want, seeds=seeds)
+            if len(wit) == 0:
+                assert r["l"] == 0 and r["witness_bits"] == 0, (case, f)
+                continue
+            k, l = oracle.optimal_params(n, p)
+            assert (r["k"], r["l"]) == (k, l), (case, f)
+            assert np.array_equal(unpack(r["filter"], l), bm), (case, f, W, H, l)
+            assert r["witness_bits"] == len(wit) and np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8)), (case, f)
+            dec = eng.decode(n, [P.filter_params(k, l)], [r["filter"]], [r["witness"]], seeds=seeds)
+            assert np.array_equal(unpack(dec[0], n), want), (case, f)
+        coder.close()
+    eng.close()
+    ctx.close()
