@@ -375,3 +375,47 @@ def test_gather_values_batch_matches_per_frame(ctx, oracle):
     assert np.array_equal(got[:cap * C], np.concatenate(want)[:cap * C]) and np.all(got[cap * C:] == 0xEE)
     for b in (fb, mb, vb, ob):
         b.free()
+
+
+def test_theoretical_vs_empirical_like_the_reference(ctx, oracle):
+    """The reference's own (print-only) FPR experiment, test_bloom_filters.py:139-201: m = 100, n = 10,
+    10 trials x 100 000 random 10-letter lookups on the string-keyed Standard and Rational filters.  Here
+    with assertions: membership equals the oracle's for every lookup, and the empirical false-positive
+    rate of the standard filter lands where the reference's formula puts it."""
+    import math
+    import random
+    import string
+    from new_bloom_filter_repo_amd.rational_bloom_filter import StandardBloomFilter, StringRationalBloomFilter
+    rnd = random.Random(42)
+
+    def strings(count):
+        return ["".join(rnd.choice(string.ascii_lowercase) for _ in range(10)) for _ in range(count)]
+    m, n = 100, 10
+    k_star = StringRationalBloomFilter.get_optimal_hash_count(m, n)
+    k_std = StandardBloomFilter.get_optimal_hash_count(m, n)
+    assert k_star == (m / n) * math.log(2) and k_std == max(1, round(k_star))
+    theory_std = (1 - math.exp(-k_std * n / m)) ** k_std
+    std_fprs, rat_fprs = [], []
+    for trial in range(10):
+        elements = sorted(set(strings(n)))
+        tests = strings(100000 if trial < 2 else 20000)
+        std, rat = StandardBloomFilter(m, k_std, ctx=ctx), StringRationalBloomFilter(m, k_star, ctx=ctx)
+        ostd, orat = oracle.StandardFilter(m, k_std), oracle.RationalFilter(m, k_star, oracle.string_filter_seeds(k_star))
+        std.add_many(elements[:5]); rat.add_many(elements[:5])
+        for e in elements[5:]:
+            std.add(e); rat.add(e)
+        for e in elements:
+            ostd.add(e); orat.add(e)
+        assert np.array_equal(std.bit_array, ostd.bit_array) and np.array_equal(rat.bit_array, orat.bit_array)
+        got_std, got_rat = std.contains_many(tests), rat.contains_many(tests)
+        assert list(got_std) == [ostd.contains(e) for e in tests] and list(got_rat) == [orat.contains(e) for e in tests]
+        assert all(std.contains(e) and rat.contains(e) for e in elements)           # no false negatives
+        members = set(elements)
+        std_fprs.append(sum(1 for e, hit in zip(tests, got_std) if hit and e not in members) / len(tests))
+        rat_fprs.append(sum(1 for e, hit in zip(tests, got_rat) if hit and e not in members) / len(tests))
+    # m = 100 is tiny, so trial-to-trial scatter is large; the standard filter's mean sits within a factor 1.5
+    # of its formula (0.0082).  The rational filter's double hashing does worse than either of the reference's
+    # two formulas at this size (0.027 here, as with the reference's own classes: 0.00094 "exact", 0.0083
+    # "simple") -- membership above is pinned to the oracle, so only the order of magnitude is checked.
+    assert theory_std / 1.5 < np.mean(std_fprs) < theory_std * 1.5, (np.mean(std_fprs), theory_std)
+    assert 0.005 < np.mean(rat_fprs) < 0.08, np.mean(rat_fprs)
