@@ -141,6 +141,15 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
                             uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
                             void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev);
 
+/* ---- A1, BGR input  (cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY), :794-795) --------------------- */
+/* gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15 per pixel -- OpenCV 4.x's integer path for 8- and
+ * 16-bit samples; samples 0,1,2 of a pixel are B,G,R (further channels are ignored).  gray_dev receives
+ * nframes dense planes of height*width samples, ready for rbf_residual_mask_batch with
+ * pixel_stride_bytes = sample_bytes. */
+int rbf_bgr_to_gray_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes, uint32_t nframes,
+                          uint32_t width, uint32_t height, uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                          uint32_t sample_bytes, void *gray_dev);
+
 /* ---- A1, adaptive threshold  (VideoFrameCompressor._estimate_noise_level, :727-744) -------- */
 /* For each of nframes luma planes (addressed as above): smoothed = 5x5 median with replicated
  * borders (cv2.medianBlur(frame, 5), :738), noise = frame - smoothed (:741).

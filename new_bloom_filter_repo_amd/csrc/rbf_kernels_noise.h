@@ -104,4 +104,28 @@ __global__ __launch_bounds__(NZ_THREADS) void k_noise_moments(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// A1, BGR input: luma = cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) (improved_video_compressor.py:794-795)
+// ------------------------------------------------------------------------------------------
+// OpenCV 4.x integer path for 8- and 16-bit samples (imgproc color_rgb: RGB2Gray<uchar> / <ushort>):
+//     gray = (B*3735 + G*19235 + R*9798 + (1 << 14)) >> 15        coefficients sum to 1 << 15
+// One lane per pixel, any channel count >= 3 (a 4th channel is ignored, as OpenCV does for BGRA).
+template <typename SAMPLE>
+__global__ __launch_bounds__(256) void k_bgr_to_gray(
+    const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t width, uint64_t n, uint64_t row_pitch, uint32_t pixel_stride,
+    SAMPLE *__restrict__ gray /* [nframes][n] */)
+{
+    const uint8_t *src = frames + (uint64_t)blockIdx.y * frame_stride;
+    SAMPLE *dst = gray + (uint64_t)blockIdx.y * n;
+    const bool flat = row_pitch == (uint64_t)width * pixel_stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t off;
+        if (flat) off = i * pixel_stride;
+        else { const uint64_t y = i / width; off = y * row_pitch + (i - y * width) * pixel_stride; }
+        const SAMPLE *px = (const SAMPLE *)(src + off);
+        const uint32_t v = (uint32_t)px[0] * 3735u + (uint32_t)px[1] * 19235u + (uint32_t)px[2] * 9798u + (1u << 14);
+        dst[i] = (SAMPLE)(v >> 15);
+    }
+}
+
 }  // namespace rbf

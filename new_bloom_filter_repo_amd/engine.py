@@ -77,6 +77,16 @@ class BloomEngine:
         self.n, self.mask_stride = n, stride
         return masks, ones
 
+    def bgr_to_gray(self, frames):
+        """cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) for every (H, W, >=3) frame of the stack (:794-795):
+        OpenCV 4.x's integer path, (B*3735 + G*19235 + R*9798 + 2^14) >> 15.  Returns (F, H, W)."""
+        fb, F, H, W, C, sb = self._upload_frames(frames, 1)
+        if C < 3:
+            raise ValueError("BGR frames need at least 3 channels")
+        gb = self._buf("gray", F * H * W * sb)
+        nat.check(nat.lib().rbf_bgr_to_gray_batch(self.ctx.handle, fb.ptr, H * W * C * sb, F, W, H, W * C * sb, C * sb, sb, gb.ptr))
+        return gb.download(F * H * W * sb, dtype=np.uint8 if sb == 1 else np.uint16).reshape(F, H, W).copy()
+
     # ------------------------------------------------------------------ A1, adaptive threshold
     def _noise(self, fb, first, count, H, W, C, sb, want_planes):
         """Launch the 5x5-median residual kernel on frames [first, first+count) of the uploaded block."""

@@ -161,10 +161,18 @@ class VideoFrameCompressor:
         if a.dtype not in (np.uint8, np.uint16):
             raise ValueError("8- or 16-bit unsigned samples expected")
         is_color = a.ndim > 2 and a.shape[2] > 1
-        if is_color and not (self.use_direct_yuv and a.shape[2] >= 3):
-            raise NotImplementedError("BGR/RGB input needs OpenCV's BGR2GRAY (improved_video_compressor.py:794); "
-                                      "pass YUV frames with use_direct_yuv=True or 2-D luma frames")
+        if is_color and a.shape[2] < 3:
+            raise ValueError("color frames need at least 3 channels")          # cv2.cvtColor would raise as well
         return a, b, is_color
+
+    def _luma_planes(self, a, b, is_color):
+        """(prev_gray, curr_gray) of improved_video_compressor.py:787-798."""
+        if not is_color:
+            return a, b
+        if self.use_direct_yuv:
+            return a[:, :, 0], b[:, :, 0]
+        gray = self._engine.bgr_to_gray(np.stack([a, b]))                     # cv2.COLOR_BGR2GRAY on the GPU
+        return gray[0], gray[1]
 
     # ---- A1, adaptive threshold
     def _estimate_noise_level(self, frame):
@@ -184,9 +192,10 @@ class VideoFrameCompressor:
         """(binary_diff HxW uint8, changed_values, density) -- improved_video_compressor.py:768-847.
         threshold=None: noise-adaptive threshold of the current luma plane (:804-805)."""
         a, b, is_color = self._luma_pair(prev_frame, curr_frame)
+        ya, yb = self._luma_planes(a, b, is_color)
         if threshold is None:
-            threshold = self._adaptive_diff_threshold(b[:, :, 0] if is_color else b)
-        masks, ones = self._engine.residual_masks(np.stack([a, b]), threshold)
+            threshold = self._adaptive_diff_threshold(yb)
+        masks, ones = self._engine.residual_masks(np.stack([ya, yb]), threshold)
         h, w = a.shape[:2]
         n = h * w
         packed = masks[0][:(n + 7) // 8]

@@ -15,9 +15,10 @@ Reference anchors (/root/reference):
   improved_video_compressor.py:768-847  _calculate_frame_diff       -> frame_diff
   improved_video_compressor.py:727-766  _estimate_noise_level / _adaptive_diff_threshold
                                         -> median_blur5, estimate_noise_level, adaptive_diff_threshold
-      PARITY UNPINNED for this one row: cv2 (opencv-python, requirements.txt, unpinned) is absent
+      PARITY UNPINNED for this one row: cv2 (opencv-python >= 4.5.0, requirements.txt) is absent
       here, so cv2.medianBlur(frame, 5) is restated from OpenCV's documented behaviour (median of
-      the 5x5 neighbourhood, border pixels replicated) and no golden vector exists; everything
+      the 5x5 neighbourhood, border pixels replicated) and cv2.cvtColor(BGR2GRAY) (:794-795, bgr_to_gray)
+      from OpenCV 4.x's integer coefficients; no golden vector exists for either; everything
       around it (float32 subtraction, np.std, clamp) is the reference's numpy code verbatim in
       behaviour and runs on the same numpy.
   improved_video_compressor.py:849-909  _apply_frame_diff           -> apply_frame_diff
@@ -250,7 +251,16 @@ def adaptive_diff_threshold(plane, noise_tolerance=10.0, min_thr=3.0, max_thr=30
     return max(min_thr, min(max_thr, noise_level * noise_tolerance))
 
 
-def frame_diff(prev_frame, curr_frame, threshold, yuv_planes=True, adaptive=(10.0, 3.0, 30.0)):
+def bgr_to_gray(frame):
+    """cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) for uint8 / uint16 (improved_video_compressor.py:794-795),
+    restated from OpenCV 4.x's integer path (imgproc, RGB2Gray<uchar>/<ushort>: coefficients
+    BY15 = 3735, GY15 = 19235, RY15 = 9798, descale by 15 bits with rounding).  Parity unpinned like
+    median_blur5: OpenCV is not installed here; the reference asks for opencv-python >= 4.5.0."""
+    f = np.asarray(frame).astype(np.uint64)
+    return ((f[..., 0] * 3735 + f[..., 1] * 19235 + f[..., 2] * 9798 + (1 << 14)) >> 15).astype(np.asarray(frame).dtype)
+
+
+def frame_diff(prev_frame, curr_frame, threshold, yuv_planes=True, adaptive=(10.0, 3.0, 30.0), bgr=False):
     """_calculate_frame_diff (:768-847) for direct-YUV H x W x 3 or 2-D frames; threshold None ->
     adaptive threshold of the current luma (:804-805) with adaptive = (tolerance, min, max).
 
@@ -260,7 +270,9 @@ def frame_diff(prev_frame, curr_frame, threshold, yuv_planes=True, adaptive=(10.
     prev_frame = np.asarray(prev_frame)
     curr_frame = np.asarray(curr_frame)
     is_color = prev_frame.ndim > 2 and prev_frame.shape[2] > 1
-    if is_color:
+    if is_color and bgr:
+        prev_gray, curr_gray = bgr_to_gray(prev_frame), bgr_to_gray(curr_frame)
+    elif is_color:
         prev_gray, curr_gray = prev_frame[:, :, 0], curr_frame[:, :, 0]
     else:
         prev_gray, curr_gray = prev_frame, curr_frame

@@ -159,3 +159,26 @@ def test_gop_coder_adaptive(ctx, oracle):
     assert coded >= 2
     with pytest.raises(ValueError):
         GopCoder(ctx, W, H, F, threshold=None)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_bgr_input_goes_through_bgr2gray(ctx, oracle, dtype):
+    """use_direct_yuv=False on color frames: luma = cv2.COLOR_BGR2GRAY (OpenCV 4.x integer weights), then
+    the usual mask / values; explicit and adaptive thresholds.  (OpenCV itself is unpinned here.)"""
+    top = np.iinfo(dtype).max
+    eng = E.BloomEngine(ctx)
+    corners = np.array([[[0, 0, 0], [top, top, top], [top, 0, 0], [0, top, 0], [0, 0, top], [1, 2, 3], [top - 1, top, top - 2]]], dtype=dtype)
+    assert np.array_equal(eng.bgr_to_gray(corners[None])[0], oracle.bgr_to_gray(corners))
+    assert eng.bgr_to_gray(corners[None])[0, 0].tolist()[:2] == [0, top]
+    rng = np.random.default_rng(4)
+    frames = smooth_video(31, 2, 60, 110, 3, dtype, sigma=0.6, moving=0.002)
+    frames[..., 1:] = frames[..., :1] // 2 + rng.integers(0, 3, frames[..., 1:].shape).astype(dtype)   # correlated channels
+    bgra = np.concatenate([frames, rng.integers(0, top + 1, frames.shape[:3] + (1,)).astype(dtype)], axis=-1)
+    assert np.array_equal(eng.bgr_to_gray(bgra), np.stack([oracle.bgr_to_gray(f) for f in frames]))      # 4th channel ignored
+    eng.close()
+    vc = VideoFrameCompressor(ctx=ctx)                                   # use_direct_yuv=False
+    for thr in (0.0, 2.5, None):
+        mask, vals, dens = vc._calculate_frame_diff(frames[0], frames[1], thr)
+        wmask, wvals, wdens = oracle.frame_diff(frames[0], frames[1], thr, yuv_planes=False, bgr=True)
+        assert np.array_equal(mask, wmask) and np.array_equal(vals, wvals) and dens == wdens, thr
+        assert vals.dtype == dtype and (thr != 0.0 or mask.sum() > 0)

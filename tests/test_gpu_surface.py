@@ -102,8 +102,8 @@ def test_video_frame_compressor_matches_reference_fixture(ctx):
     assert len(blob64) == len(blob) + 4
     m3, v3 = v64._decompress_frame_differences(blob64, prev.shape)
     assert np.array_equal(m3, mask) and np.array_equal(v3, values)
-    with pytest.raises(NotImplementedError):                 # BGR input needs OpenCV's BGR2GRAY
-        pkg.VideoFrameCompressor(ctx=ctx)._calculate_frame_diff(prev, curr, 0.0)
+    with pytest.raises(ValueError):                          # two-channel "color" frames: cv2.cvtColor would refuse too
+        pkg.VideoFrameCompressor(ctx=ctx)._calculate_frame_diff(prev[:, :, :2], curr[:, :, :2], 0.0)
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
