@@ -208,6 +208,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    # every pipeline coded the same GOP, concurrently with the others: their output records must be identical
+    for k in range(1, ncoders):
+        if not torch.equal(arenas[0].tensor, arenas[k].tensor):
+            raise SystemExit("pipeline %d produced a different record than pipeline 0" % k)
     ktimes = None
     if not args.no_kernel_timing:
         ktimes = {}
@@ -243,7 +247,7 @@ def main():
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), %s, threshold 0"
                                % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3"),
-                   "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
+                   "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders, "pipelines_agree": True,
                    "gather_bytes_per_rank_per_step": box["slot_words"] * 8 if gather else 0, "steps_per_gather": G if gather else 0,
                    "lds_tile_kib": args.lds_tile_kib or "auto", "generic_kernels": bool(args.generic_kernels),
                    "stages": "residual mask -> host params -> insert -> query+witness"},
