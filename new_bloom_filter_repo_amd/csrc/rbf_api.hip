@@ -376,7 +376,8 @@ struct Plan {
     bool fast_insert;            // LDS partial-filter insert (any filter size, tiled when needed)
     int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles
     bool double_buffer, small_m;
-    uint32_t fwords_max, S;
+    uint32_t fwords_max, S /* most slices of a frame */, per_tile /* sum of slices */;
+    SliceTable slices;
     uint32_t insert_tile_words, insert_tiles, query_tile_words;
     size_t insert_lds_bytes, query_lds_bytes;
     uint64_t nseg; uint32_t words_per_seg;
@@ -429,10 +430,20 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
         }
     }
     // slices per frame so that S * tiles * frames ~ one workgroup per CU (256 CUs), at most 32
-    uint32_t S = active ? 256u / (active * p.insert_tiles) : 1u;
-    if (S < 1) S = 1;
-    if (S > 32) S = 32;
-    p.S = S;
+    // (handing the remainder out as one extra slice to some frames was measured and buys nothing: the launch
+    // lasts as long as its largest slice)
+    const uint32_t units = 256u / p.insert_tiles;                           // workgroups per tile layer
+    uint32_t base = active ? units / active : 1u, extra = 0u;
+    if (base < 1) base = 1;
+    if (base > 32) base = 32;
+    p.S = 1;
+    p.per_tile = 0;
+    for (uint32_t f = 0, a = 0; f < nframes; ++f) {
+        const uint32_t sf = params[f].m ? base + (a++ < extra ? 1u : 0u) : 0u;
+        p.slices.n[f] = (uint8_t)sf;
+        p.per_tile += sf;
+        if (sf > p.S) p.S = sf;
+    }
     const uint32_t segpx = p.query_kind == 1 ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
     p.nseg = (n + segpx - 1) / segpx;
     p.words_per_seg = segpx / 64;
@@ -610,8 +621,9 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         if (int r = allow_big_lds((const void *)ikern)) return r;
         {
             LaunchTimer t(ctx, RBF_K_INSERT);
-            hipLaunchKernelGGL(ikern, dim3(pl.S, nframes, pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
-                               (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.insert_tile_words);
+            hipLaunchKernelGGL(ikern, dim3(pl.per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                               (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.insert_tile_words,
+                               pl.slices, pl.per_tile, pl.S);
         }
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);
@@ -620,7 +632,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
             uint32_t bx = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx < 1) bx = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)ctx->partials, part_stride, pl.S, tab, (uint32_t *)filters_dev, words, stats_dev, vec_ok);
+                               (const uint32_t *)ctx->partials, part_stride, pl.S, pl.slices, tab, (uint32_t *)filters_dev, words, stats_dev, vec_ok);
         }
     } else {
         HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
@@ -635,11 +647,13 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         }
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);        // S = 1 in place: only counts the set bits
+            SliceTable ones;
+            memset(ones.n, 1, sizeof ones.n);
             const uint64_t words = filter_stride_bytes / 4;
             uint32_t bx2 = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx2 < 1) bx2 = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx2, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)filters_dev, words, 1u, tab, (uint32_t *)filters_dev, words, stats_dev, 0u);
+                               (const uint32_t *)filters_dev, words, 1u, ones, tab, (uint32_t *)filters_dev, words, stats_dev, 0u);
         }
     }
     // ---- query: pass word of every 64 positions + per-segment pass counts

@@ -31,6 +31,7 @@ struct Seeds { uint64_t h1, h2, act; };
 // no upload, no device buffer, and the per-frame fields arrive through scalar loads.
 constexpr int MAX_BATCH = 128;
 struct FrameTable { FrameDev f[MAX_BATCH]; };
+struct SliceTable { uint8_t n[MAX_BATCH]; };     // insert: partial filters (mask slices) per frame, 0 = frame not coded
 
 // 32-bit words of an m-bit filter; m may be 2^32 - 1, so the rounding is done in 64 bits
 __device__ __forceinline__ uint32_t filter_words(uint32_t m) { return (uint32_t)(((uint64_t)m + 31u) >> 5); }

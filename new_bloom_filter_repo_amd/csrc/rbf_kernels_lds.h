@@ -58,20 +58,29 @@ template <bool SMALL_M, int IAB = 0>
 __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
     const FrameTable tab, Seeds seeds,
-    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t tile_words /* even */)
+    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t tile_words /* even */,
+    const SliceTable slices, uint32_t per_tile /* sum of slices.n */, uint32_t Smax /* max of slices.n: row pitch of the partials */)
 {
-    // blockIdx.z = filter tile: this workgroup keeps words [tile0, tile0 + tile_words) of the partial
-    // filter in LDS and sets only the positions that fall into them.  Filters that fit LDS whole
+    // 1-D grid of tiles * per_tile workgroups: frame f is cut into slices.n[f] mask slices (0 for a frame that is
+    // not Bloom-coded), chosen on the host so that the workgroups fill the 256 CUs whatever the frame count is
+    // (29 frames: 24 x 9 + 5 x 8).  The grid is one-dimensional on purpose: consecutive workgroup ids go to
+    // consecutive XCDs, and a 2-D grid whose x extent is not a multiple of 8 left some XCDs with more workgroups
+    // than CUs (measured: grid (9, 29) -> 114 us instead of 70 us for the same 242 workgroups).
+    // The tile index is the slowest coordinate: this workgroup keeps words [tile0, tile0 + tile_words) of the
+    // partial filter in LDS and sets only the positions that fall into them.  Filters that fit LDS whole
     // (1080p: 76 KB) have one tile; a 4K filter (306 KB) is built in 3 tiles (keys re-hashed per tile).
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *filt = lds;                                         // [tile_words]
     uint32_t *queues = lds + tile_words;                          // [IL_WAVES][IL_QUEUE]
-    const uint32_t f = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+    const uint32_t tile = blockIdx.x / per_tile;
+    uint32_t s = blockIdx.x - tile * per_tile, f = 0;
+    while (s >= slices.n[f]) { s -= slices.n[f]; ++f; }          // workgroup-uniform walk over <= 128 bytes
+    const uint32_t S = slices.n[f];
     const FrameDev fd = tab.f[f];
     if (fd.m == 0) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t fwords = filter_words(fd.m);
-    const uint32_t tile0 = blockIdx.z * tile_words;               // first word of my tile
+    const uint32_t tile0 = tile * tile_words;                     // first word of my tile
     if (tile0 >= fwords) return;
     const uint32_t tile_bit0 = tile0 << 5, tile_bits = tile_words << 5;
     if (!(IAB & 4)) for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     }
     drain_at(0, qn);
     __syncthreads();
-    uint32_t *part = partials + ((uint64_t)f * S + s) * part_stride_words32 + tile0;
+    uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;
     const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
     const uint32_t pairs = (IAB & 4) ? 1u : (mine + 1) >> 1;      // tile0 is even: 8-byte aligned
     for (uint32_t i = threadIdx.x; i < pairs; i += IL_THREADS)
@@ -154,17 +163,19 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
 // 16-byte accesses (rows are 8-byte padded and 16-byte aligned bases are not guaranteed, so the
 // vector path is taken only when both strides are multiples of 4 words and the bases are aligned).
 __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
-    const uint32_t *partials, uint64_t part_stride_words32, uint32_t S,
+    const uint32_t *partials, uint64_t part_stride_words32, uint32_t Smax /* row pitch of the partials, in slices */,
+    const SliceTable slices /* partial filters per frame */,
     const FrameTable tab,
-    uint32_t *filters /* may alias partials when S == 1 */, uint64_t filter_stride_words32,
+    uint32_t *filters /* may alias partials when Smax == 1 */, uint64_t filter_stride_words32,
     uint64_t *__restrict__ stats, uint32_t vec_ok)
 {
     __shared__ uint32_t red[WG_WAVES];
     const uint32_t f = blockIdx.y;
+    const uint32_t S = slices.n[f];
     const uint32_t m = tab.f[f].m;
     const uint32_t fwords = m ? filter_words(m) : 0u;
     uint32_t *filt = filters + (uint64_t)f * filter_stride_words32;
-    const uint32_t *part = partials + (uint64_t)f * S * part_stride_words32;
+    const uint32_t *part = partials + (uint64_t)f * Smax * part_stride_words32;
     uint32_t pc = 0;
     if (vec_ok) {
         const uint64_t quads = filter_stride_words32 >> 2;
