@@ -171,6 +171,83 @@ __device__ __forceinline__ Hash3 hash3_index(uint32_t v, bool active, const Seed
     return hash3_generic(active ? v : 0u, s);
 }
 
+// ---- the hashes of 8 CONSECUTIVE indices (the query kernel's lane) ------------------------------
+// str(i) and str(i+1) differ in the last character only (unless a decade ends), and XXH64's short-input
+// path consumes the key front to back: the state after all characters but the last is the same for the
+// up-to-ten indices of a decade.  A lane owning indices v0 .. v0+7 touches at most two decades, so it runs the
+// 4-byte round and the inner byte rounds twice (decade A = v0/10, decade B = A+1) instead of eight times
+// and only the last byte round + avalanche per index.  Taken when every lane of the wave agrees on a key
+// length of 5, 6 or 7 for all of its indices; anything else goes through hash3_index.
+struct Prefix3 { uint64_t h1, h2, ha; };
+
+template <int LEN>
+__device__ __forceinline__ Prefix3 hash3_decade_prefix(uint32_t decade /* LEN-1 digits */, const Seeds &s)
+{
+    static_assert(LEN >= 5 && LEN <= 7, "key = decade digits + one more character");
+    constexpr uint32_t P10[7] = {1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u};
+    uint32_t q[LEN];                                          // q[k] = decade / 10^k
+#pragma unroll
+    for (int k = 0; k < LEN; ++k) q[k] = k < LEN - 1 ? decade / P10[k] : 0u;
+    uint32_t d[LEN - 1];                                      // d[0] = most significant digit
+#pragma unroll
+    for (int k = 0; k < LEN - 1; ++k) d[LEN - 2 - k] = q[k] - 10u * q[k + 1];
+    const uint64_t lane4 = (uint64_t)(0x30303030u + d[0] + (d[1] << 8) + (d[2] << 16) + (d[3] << 24)) * P1;
+    uint64_t h[3] = {s.h1 + P5 + (uint64_t)LEN, s.h2 + P5 + (uint64_t)LEN, s.act + P5 + (uint64_t)LEN};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) h[c] = rotl64(h[c] ^ lane4, 23) * P2 + P3;
+#pragma unroll
+    for (int t = 4; t < LEN - 1; ++t) {
+        const uint64_t term = (uint64_t)(0x30u + d[t]) * P5;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) h[c] = rotl64(h[c] ^ term, 11) * P1;
+    }
+    return Prefix3{h[0], h[1], h[2]};
+}
+
+__device__ __forceinline__ uint64_t xxh64_last_byte(uint64_t h, uint64_t term /* byte * P5 */)
+{
+    h = rotl64(h ^ term, 11) * P1;
+    h ^= h >> 33; h *= P2;
+    h ^= h >> 29; h *= P3;
+    h ^= h >> 32;
+    return h;
+}
+
+// Hashes of v0 + j, j = 0..7.  `valid` bit j: index v0 + j is meaningful.  Returns false (nothing written)
+// when the wave cannot take the shared-prefix path; the caller then hashes index by index.
+template <int LEN>
+__device__ __forceinline__ void hash3_run8_fixed(uint32_t v0, const Seeds &s, uint64_t (&h1)[8], uint64_t (&h2)[8], uint64_t (&ha)[8])
+{
+    const uint32_t decade = v0 / 10u, r0 = v0 - decade * 10u;
+    const Prefix3 a = hash3_decade_prefix<LEN>(decade, s);
+    const Prefix3 b = hash3_decade_prefix<LEN>(decade + 1u, s);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t t = r0 + (uint32_t)j;
+        const bool in_b = t >= 10u;
+        const uint64_t term = (uint64_t)(0x30u + (in_b ? t - 10u : t)) * P5;
+        h1[j] = xxh64_last_byte(in_b ? b.h1 : a.h1, term);
+        h2[j] = xxh64_last_byte(in_b ? b.h2 : a.h2, term);
+        ha[j] = xxh64_last_byte(in_b ? b.ha : a.ha, term);
+    }
+}
+
+__device__ __forceinline__ bool hash3_run8(uint32_t v0, uint32_t valid, const Seeds &s, uint64_t (&h1)[8], uint64_t (&h2)[8], uint64_t (&ha)[8])
+{
+    // every index of an active lane must have the same length; a lane whose run ends inside the frame's
+    // last segment may own fewer than 8 valid indices -- their (unused) neighbours still hash fine as long
+    // as the length agrees, so the test is on the whole run v0 .. v0+7
+    const bool active = valid != 0u;
+    const uint32_t v7 = v0 + 7u;
+    const bool in7 = v0 >= 1000000u && v7 < 10000000u;
+    const bool in6 = v0 >= 100000u && v7 < 1000000u;
+    const bool in5 = v0 >= 10000u && v7 < 100000u;
+    if (__all(!active || in7)) { hash3_run8_fixed<7>(active ? v0 : 1000000u, s, h1, h2, ha); return true; }
+    if (__all(!active || in6)) { hash3_run8_fixed<6>(active ? v0 : 100000u, s, h1, h2, ha); return true; }
+    if (__all(!active || in5)) { hash3_run8_fixed<5>(active ? v0 : 10000u, s, h1, h2, ha); return true; }
+    return false;
+}
+
 // h mod m, exact, via Barrett with M = floor(2^64/m): q in {floor(h/m)-1, floor(h/m)}.
 __device__ __forceinline__ uint32_t mod_m(uint64_t h, uint32_t m, uint64_t M)
 {

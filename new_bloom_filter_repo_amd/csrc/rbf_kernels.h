@@ -132,7 +132,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_insert(
 // ------------------------------------------------------------------------------------------
 // A5 / A6  query: test every position in order (check_index, :116-138) -- generic path, filter
 // probed in global memory.  One wave per segment of 1024 pixels:
-//   pass_words[(f*nseg + seg)*16 + it]  64-bit pass word of wave-iteration it
+//   pass_words[(f*nseg + seg)*16 + it]  pass word of wave-iteration it, PACKED like masks and witnesses
+//                                       (numpy.packbits order: position 64*it + 8b + r at byte b, bit 7 - r)
 //   seg_cnt[f*nseg + seg]               passing positions of the segment
 // k_compact_witness (encode) / k_expand_mask_p (decode) consume them.
 // ------------------------------------------------------------------------------------------
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_query(
             if (p.extra) pass = pass && ((filt[p.pos >> 5] >> msb_pos(p.pos)) & 1u);
         }
         const uint64_t pw = __ballot(pass);
-        if (lane == 0) pw_out[it] = pw;
+        if (lane == 0) pw_out[it] = flip_bytes64(pw);
         woff += __popcll(pw);
     }
     if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = woff;

@@ -290,22 +290,24 @@ __device__ __forceinline__ uint32_t probe_word(const uint32_t *filt, uint32_t po
     return filt[w];
 }
 
-// One frame's pass over a wave's QL_P x 64 pixels: reductions mod m, LDS probes, ballot.
+// One frame's pass over a lane's QL_P consecutive pixels: reductions mod m, LDS probes, verdict.
 // FK >= 0: floor(k*) known at compile time (fully unrolled probes); FK < 0: runtime fk.
-// Lane `it` (it < QL_P) ends up holding the 64-bit pass word of wave-iteration `it`; returns the
-// number of passing positions.  Branch-free for FK >= 0 so the QL_P dependency chains interleave.
+// The verdict of pixel j is the sign bit of `acc`; it is shifted into `pb` (one v_alignbit), so after
+// the loop pb holds the lane's QL_P verdicts MSB-first -- exactly one byte of the packed pass vector.
+// Returns the wave's number of passing positions.  Branch-free for FK >= 0 so the QL_P dependency
+// chains interleave.
 // AB (ablation mask, tools/bench_query.hip only; 0 in the library): 1 = no reductions, 2 = no LDS
 // probes, 4 = no ballot, 8 = no filter staging, 16 = no hashing, 32 = no barrier, 64 = no output.
 template <bool SMALL_M, int FK, int AB = 0>
 __device__ __forceinline__ uint32_t frame_pass(
     const uint64_t (&h1)[QL_P], const uint64_t (&h2)[QL_P], const uint64_t (&ha)[QL_P], uint32_t validmask,
-    const uint32_t *filt, uint32_t m, uint64_t M, uint64_t T, uint32_t fk_rt, uint32_t &pw_lo, uint32_t &pw_hi)
+    const uint32_t *filt, uint32_t m, uint64_t M, uint64_t T, uint32_t fk_rt, uint32_t &pb)
 {
     const uint32_t Mh = (uint32_t)(M >> 32), Ml = (uint32_t)M;
     const uint32_t fk = FK >= 0 ? (uint32_t)FK : fk_rt;
     const uint32_t m2 = m << 1;
     uint32_t npass = 0;
-    uint64_t pw[QL_P];
+    pb = 0;
 #pragma unroll
     for (int it = 0; it < QL_P; ++it) {
         uint32_t pos, step;
@@ -323,26 +325,17 @@ __device__ __forceinline__ uint32_t frame_pass(
         }
         const uint32_t x = ((AB & 2) ? (pos * 0x85EBCA77u) : probe_word(filt, pos)) << ((pos ^ 24u) & 31u);
         acc &= (ha[it] < T) ? x : 0x80000000u;
-        if (AB & 4) { npass += acc >> 31; pw[it] = 0; continue; }
-        pw[it] = __ballot((int32_t)acc < 0);
-        npass += __popcll(pw[it]);
-    }
-    // lane `it` keeps iteration it's pass word (one hazard gap for all the ballots above)
-    static_assert(QL_P == 8, "the hazard gap threads 8 + 8 SGPR values");
-    uint32_t lo[8], hi[8];
-#pragma unroll
-    for (int it = 0; it < QL_P; ++it) { lo[it] = (uint32_t)pw[it]; hi[it] = (uint32_t)(pw[it] >> 32); }
-    valu_sgpr_hazard_gap(lo, hi);
-#pragma unroll
-    for (int it = 0; it < QL_P; ++it) {
-        write_lane(pw_lo, lo[it], it);
-        write_lane(pw_hi, hi[it], it);
+        pb = __builtin_amdgcn_alignbit(pb, acc, 31);          // (pb << 1) | (acc >> 31)
+        if (!(AB & 4)) npass += __popcll(__ballot((int32_t)acc < 0));
     }
     return npass;
 }
 
 // Query, frames-inner (A5 for encode, A6 for decode: both need the pass word of every 64 pixels).
-//   pass_words[(f*nseg + seg)*QL_P + it]  bit l = position (seg*QL_P + it)*64 + l passes filter f
+//   pass_words, as bytes: [(f*nseg + seg)*QL_SEG_PIXELS/8 + b]  bit 7-r = position seg*QL_SEG_PIXELS + 8b + r passes
+//                                          filter f, i.e. the packed (numpy.packbits) order of masks and witnesses
+// A lane owns QL_P = 8 CONSECUTIVE pixels (its verdicts are one byte of that vector, and their keys share all
+// but the last character, see hash3_run8); a wave owns 512 consecutive pixels.
 //   seg_cnt[f*nseg + seg]                  passing positions of the segment (= witness bits it owns)
 // SMALL_M: every filter of the batch has 2 <= m <= 2^30 (host-checked) -> cheap reductions.
 template <bool DOUBLE_BUFFER, bool SMALL_M, int AB = 0>
@@ -359,29 +352,34 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     const bool live = seg < nseg;
     const uint64_t base = seg * QL_SEG_PIXELS;
 
-    // ---- frame-independent part: the three hashes of my P pixel indices ------------------
+    // ---- frame-independent part: the three hashes of my P consecutive pixel indices ------
+    static_assert(QL_P == 8, "a lane's verdicts fill one byte; hash3_run8 hashes runs of 8");
     uint64_t h1[QL_P], h2[QL_P], ha[QL_P];
     uint32_t validmask = 0;
+    const uint64_t i0 = base + (uint64_t)lane * QL_P;
 #pragma unroll
     for (int it = 0; it < QL_P; ++it) {
-        const uint64_t i = base + (uint64_t)it * WAVE + lane;
         h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
-        if (live && i < n) {
-            if (AB & 16) { h1[it] = i * P1; h2[it] = i * P2 + seeds.h2; ha[it] = i * P3; }
-            validmask |= 1u << it;
-        }
-        if (!(AB & 16)) {
+        if (live && i0 + it < n) validmask |= 1u << it;
+    }
+    if (AB & 16) {
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) { h1[it] = (i0 + it) * P1; h2[it] = (i0 + it) * P2 + seeds.h2; ha[it] = (i0 + it) * P3; }
+    } else if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {                      // mixed key lengths in this wave: index by index
             const bool act = (validmask >> it) & 1u;
-            const Hash3 h = hash3_index((uint32_t)i, act, seeds);
-            if (act) { h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha; }
+            const Hash3 h = hash3_index((uint32_t)(i0 + it), act, seeds);
+            h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
         }
     }
+    uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
 
     // passthrough frames (m == 0): nothing passes
     for (uint32_t g = 0; g < nframes; ++g) {
         if (tab.f[g].m == 0) {
             if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
-            if (live && lane < QL_P) pass_words[((uint64_t)g * nseg + seg) * QL_P + lane] = 0;
+            if (live) pass_bytes[((uint64_t)g * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = 0;
         }
     }
     // Every workgroup walks the frames in the same order: all CUs then pull the same 76 KB filter at
@@ -432,18 +430,18 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
         const uint64_t T = ((uint64_t)Thi << 32) | Tlo;
         const uint64_t M = ((uint64_t)Mh << 32) | Ml;
 
-        uint32_t pw_lo = 0, pw_hi = 0, npass;
+        uint32_t pb = 0, npass;
         // floor(k*) is a small integer: straight-line code for the common values lets the compiler
         // issue every LDS probe of all QL_P pixels back to back instead of one round trip at a time.
         switch (fk) {
-        case 1: npass = frame_pass<SMALL_M, 1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
-        case 2: npass = frame_pass<SMALL_M, 2, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
-        case 3: npass = frame_pass<SMALL_M, 3, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
-        case 4: npass = frame_pass<SMALL_M, 4, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
-        default: npass = frame_pass<SMALL_M, -1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pw_lo, pw_hi); break;
+        case 1: npass = frame_pass<SMALL_M, 1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        case 2: npass = frame_pass<SMALL_M, 2, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        case 3: npass = frame_pass<SMALL_M, 3, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        case 4: npass = frame_pass<SMALL_M, 4, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        default: npass = frame_pass<SMALL_M, -1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
         }
         if (!(AB & 64) && live) {
-            if (lane < QL_P) pass_words[((uint64_t)f * nseg + seg) * QL_P + lane] = ((uint64_t)pw_hi << 32) | pw_lo;
+            pass_bytes[((uint64_t)f * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)pb;
             if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
         }
         k = kn;
@@ -530,7 +528,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_tiled(
             npass += __popcll(pw);
         }
         if (live) {
-            if (lane < TQ_P) pass_words[((uint64_t)f * nseg + seg) * TQ_P + lane] = ((uint64_t)pw_hi << 32) | pw_lo;
+            if (lane < TQ_P) pass_words[((uint64_t)f * nseg + seg) * TQ_P + lane] = flip_bytes64(((uint64_t)pw_hi << 32) | pw_lo);
             if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
         }
     }
@@ -583,7 +581,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
         for (uint32_t i = threadIdx.x; i < WG_THREADS * 2 + 2; i += WG_THREADS) buf[i] = 0;
         // my word and the block-exclusive scan of the pass counts
         const uint64_t w = w0 + threadIdx.x;
-        const uint64_t pw = (w < total && w < nwords) ? pwf[w] : 0ull;
+        const uint64_t pw = (w < total && w < nwords) ? flip_bytes64(pwf[w]) : 0ull;     // packed -> bit b = position 64w + b
         const uint32_t c = __popcll(pw);
         uint32_t incl = c;
 #pragma unroll
@@ -654,7 +652,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_expand_mask_p(
     const uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
     uint64_t o = seg_off[(uint64_t)f * nseg + seg];
     for (uint64_t j = seg * words_per_seg; j < w; ++j) o += __popcll(pwf[j]);
-    uint64_t p = pwf[w];
+    uint64_t p = flip_bytes64(pwf[w]);                           // packed -> bit b = position 64w + b
     uint64_t out = 0;
     if (p) {
         const uint32_t c = __popcll(p);
