@@ -115,7 +115,7 @@ def encode_video_sharded(frames, first_index, nframes_total, keyframe_interval=3
     (start, stop) = shard_range(nframes_total, world, rank); first_index = halo_start(start).
     Returns the container bytes on dst (ImprovedVideoCompressor._container), None elsewhere."""
     import torch.distributed as dist
-    from .video_compressor import ImprovedVideoCompressor, KEY, INTER
+    from .video_compressor import ImprovedVideoCompressor
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     start, stop = shard_range(nframes_total, world, rank)
     comp = ImprovedVideoCompressor(keyframe_interval=keyframe_interval, ctx=ctx)

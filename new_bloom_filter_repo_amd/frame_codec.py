@@ -13,14 +13,12 @@ Deliberate, documented divergences from the reference record format (SURVEY 8a r
     `wire_format="reference"` reproduces the reference bytes exactly (tests pin it to fixture G7).
   - changed values keep the frame dtype (the reference hard-codes uint8, which truncates 16-bit video).
 """
-import io
 import struct
 import zlib
 
 import numpy as np
 
 from . import _native as nat
-from . import params as P
 from .bloom_compressor import BloomFilterCompressor
 from .engine import BloomEngine, adaptive_threshold, gather_values, scatter_values
 

@@ -1,4 +1,4 @@
-import sys, numpy as np, ctypes, time
+import sys, numpy as np
 sys.path.insert(0, '/root/repo')
 from new_bloom_filter_repo_amd import _native as nat
 from new_bloom_filter_repo_amd.gop import GopCoder
