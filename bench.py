@@ -281,6 +281,7 @@ def main():
                                "avg_launch_ms_alone": (breakdown or {}).get("query"),   # same kernel, one pipeline, nothing co-running
                                "algorithmic_bytes_per_launch": int(alg_bytes),
                                "bytes_per_pixel": round(alg_bytes / (pairs * n), 4)}
+            out["roofline"]["issue"] = None if args.density else issue_roofline(W, H, F, args.bits, (breakdown or {}).get("query"))
             out["kernels_ms_per_step"] = breakdown
         else:
             out["roofline"] = None
@@ -293,6 +294,22 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def issue_roofline(W, H, F, bits, alone_ms):
+    """Companion to the HBM roofline ('expect the kernel to sit on the integer-ALU ceiling first; report
+    both'): the dominant kernel's measured VALU instruction count (committed rocprofv3 PMC pass) priced at
+    the measured issue rate of wave64 integer instructions.  Only valid for the workload it was measured on."""
+    path = os.path.join(REPO, "profiles", "r01_query_traffic.json")
+    if (W, H, F, bits) != (1920, 1080, 30, 8) or not os.path.exists(path) or not alone_ms:
+        return None
+    with open(path) as f:
+        insts = json.load(f).get("sq_insts_valu_per_launch")
+    if not insts:
+        return None
+    bound_ms = insts * 4.0 / 1024 / 2.34e9 * 1e3          # 4 cycles per wave instruction, 1024 SIMDs, 2.34 GHz
+    return {"bound": "valu-int", "wave_instructions_per_launch": int(insts), "issue_bound_ms": round(bound_ms, 4),
+            "launch_ms_alone": alone_ms, "frac": round(bound_ms / alone_ms, 3)}
 
 
 def measured_traffic(W, H, F, bits):
