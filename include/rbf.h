@@ -105,7 +105,8 @@ int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes); 
 #define RBF_K_COUNT   12
 int rbf_timing_enable(rbf_ctx *ctx, int on);
 /* Testing knob (bit mask): bit 0 = always use the generic (global-memory filter) kernels;
- * bit 1 = LDS fast path without double-buffering the filter.  0 (default) = pick the fastest
+ * bit 1 = LDS fast path without double-buffering the filter; bit 2 = per-pixel threshold compare in the
+ * GOP mask kernel even for threshold 0.  0 (default) = pick the fastest
  * variant that fits: the LDS-resident path needs the batch's largest filter to fit in LDS. */
 int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
 int rbf_timing_reset(rbf_ctx *ctx);

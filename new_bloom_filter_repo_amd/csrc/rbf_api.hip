@@ -54,6 +54,7 @@ struct rbf_ctx {
     int force_generic = 0;           // tests: 1 = never use the LDS fast path
     int single_buffer = 0;           // tests: 1 = fast query path without filter double-buffering
     uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
+    int force_generic_mask_bits = 0; // tests: 1 = per-pixel threshold compare even for threshold 0
     uint32_t tile_words = 0;         // tests/tuning: cap the LDS filter tile (dwords); forces the tiled kernels
     // host staging of encode_gop: device-visible pinned block [flag | ones...] the GPU publishes into
     uint64_t *ones_pinned = nullptr; size_t host_cap = 0;
@@ -251,6 +252,7 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     if (!ctx) return fail(RBF_EINVAL, "null context");
     ctx->force_generic = (on & 1) ? 1 : 0;
     ctx->single_buffer = (on & 2) ? 1 : 0;
+    ctx->force_generic_mask_bits = (on & 4) ? 1 : 0;
     ctx->mask_chunks = (uint32_t)(on >> 8) & 0xFF;           // tuning knob, bits 8..15
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
     return RBF_OK;
@@ -522,13 +524,16 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
         const uint32_t ppc = (pairs + chunks - 1) / chunks;
         chunks = (pairs + ppc - 1) / ppc;
         LaunchTimer t(ctx, RBF_K_MASK);
-#define RBF_MASK_GOP(S, PB) hipLaunchKernelGGL((k_residual_mask_gop<S, PB>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
+#define RBF_MASK_GOP(S, PB, Z) hipLaunchKernelGGL((k_residual_mask_gop<S, PB, false, Z>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
                                (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, thr_tab, (uint16_t *)masks_dev, \
                                mask_stride_bytes / 2, ones_dev, ppc)
-        if (sample_bytes == 1 && pixel_stride_bytes == 1) RBF_MASK_GOP(uint8_t, 1);
-        else if (sample_bytes == 1) RBF_MASK_GOP(uint8_t, 3);
-        else if (pixel_stride_bytes == 2) RBF_MASK_GOP(uint16_t, 2);
-        else RBF_MASK_GOP(uint16_t, 6);
+#define RBF_MASK_GOP2(S, PB) do { if (thr0) RBF_MASK_GOP(S, PB, true); else RBF_MASK_GOP(S, PB, false); } while (0)
+        const bool thr0 = !thr_tab && thr_floor == 0 && !(ctx->force_generic_mask_bits);     // "luma changed": no per-pixel extraction
+        if (sample_bytes == 1 && pixel_stride_bytes == 1) RBF_MASK_GOP2(uint8_t, 1);
+        else if (sample_bytes == 1) RBF_MASK_GOP2(uint8_t, 3);
+        else if (pixel_stride_bytes == 2) RBF_MASK_GOP2(uint16_t, 2);
+        else RBF_MASK_GOP2(uint16_t, 6);
+#undef RBF_MASK_GOP2
 #undef RBF_MASK_GOP
     }
     const uint64_t first_word = fast_segs * 16;

@@ -710,7 +710,52 @@ struct LanePixels {
     }
 };
 
-template <typename SAMPLE, int PIXEL_BYTES, bool NT = false>
+// Threshold 0 (the lossless setting, verify_true_lossless.py:244-246): the bit is "luma changed", which needs no
+// per-pixel extraction.  8-bit: XOR whole dwords, pull the luma bytes of four pixels into one dword (v_perm), turn
+// "byte != 0" into the byte's top bit with the carry trick and squeeze the four flags into a nibble with one
+// multiply: ~3 instructions per pixel instead of ~10.  16-bit: d = a - b per 16-bit half (v_pk_sub_u16); numpy's
+// int16 arithmetic makes abs(d) > 0 false for d == 0 AND for d == 0x8000 (abs(-32768) stays negative, :801), so
+// the bit is (d & 0x7FFF) != 0.
+template <typename SAMPLE, int PIXEL_BYTES>
+__device__ __forceinline__ uint32_t lane_bits_thr0(const LanePixels<SAMPLE, PIXEL_BYTES> &a, const LanePixels<SAMPLE, PIXEL_BYTES> &b)
+{
+    uint32_t bits = 0;
+    if (sizeof(SAMPLE) == 1) {
+        constexpr int shift_of_group[4] = {4, 0, 12, 8};       // pixels 4g..4g+3 -> bits (k ^ 7), MSB-first per byte
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t z;
+            if (PIXEL_BYTES == 1) z = a.d[g] ^ b.d[g];
+            else {                                              // 3-byte pixels: lumas at bytes 0, 3, 6, 9 of three dwords
+                const uint32_t x0 = a.d[3 * g] ^ b.d[3 * g], x1 = a.d[3 * g + 1] ^ b.d[3 * g + 1], x2 = a.d[3 * g + 2] ^ b.d[3 * g + 2];
+                const uint32_t y = __builtin_amdgcn_perm(x1, x0, 0x00060300u);   // {x0.b0, x0.b3, x1.b2, -}
+                z = __builtin_amdgcn_perm(x2, y, 0x05020100u);                   // {.., .., .., x2.b1}
+            }
+            const uint32_t f = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;   // top bit of every non-zero byte
+            bits |= (((f >> 7) * 0x08040201u) >> 24) << shift_of_group[g];            // flags at 0,8,16,24 -> 27,26,25,24
+        }
+    } else {
+        typedef unsigned short h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                           // pixels 2j, 2j+1
+            uint32_t d;
+            if (PIXEL_BYTES == 2) {
+                const h2 t = __builtin_bit_cast(h2, a.d[j]) - __builtin_bit_cast(h2, b.d[j]);
+                d = __builtin_bit_cast(uint32_t, t);
+            } else {                                            // 6-byte pixels: luma = low half of dword 3j, high half of dword 3j+1
+                const h2 t0 = __builtin_bit_cast(h2, a.d[3 * j]) - __builtin_bit_cast(h2, b.d[3 * j]);
+                const h2 t1 = __builtin_bit_cast(h2, a.d[3 * j + 1]) - __builtin_bit_cast(h2, b.d[3 * j + 1]);
+                d = (__builtin_bit_cast(uint32_t, t0) & 0x0000FFFFu) | (__builtin_bit_cast(uint32_t, t1) & 0xFFFF0000u);
+            }
+            const uint32_t f = ((d & 0x7FFF7FFFu) + 0x7FFF7FFFu) & 0x80008000u;          // top bit of every half with (d & 0x7FFF) != 0
+            const uint32_t two = ((f >> 14) & 2u) | (f >> 31);                          // pixel 2j -> bit 1, pixel 2j+1 -> bit 0
+            bits |= two << (((2 * j + 1) ^ 7));
+        }
+    }
+    return bits;
+}
+
+template <typename SAMPLE, int PIXEL_BYTES, bool NT = false, bool THR0 = false>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t nframes, uint64_t nsegs /* of 1024 px */,
     int32_t thr_all, const int32_t *__restrict__ thr_tab /* nullable: per pair */,
@@ -738,10 +783,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
             if (f + 1 <= f1) nxt.template load<NT>(p + (uint64_t)(f + 1) * frame_stride);
             const int32_t thr = thr_tab ? thr_tab[f - 1] : thr_all;
             uint32_t bits = 0;
+            if (THR0) bits = lane_bits_thr0<SAMPLE, PIXEL_BYTES>(prev, cur);      // host: no per-pair table and thr == 0
+            else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const bool b = residual_bit<SAMPLE>((SAMPLE)prev.luma(k), (SAMPLE)cur.luma(k), thr);
-                bits |= (b ? 1u : 0u) << (k ^ 7);             // MSB-first within each byte
+                for (int k = 0; k < 16; ++k) {
+                    const bool b = residual_bit<SAMPLE>((SAMPLE)prev.luma(k), (SAMPLE)cur.luma(k), thr);
+                    bits |= (b ? 1u : 0u) << (k ^ 7);         // MSB-first within each byte
+                }
             }
             out[(uint64_t)(f - 1) * mask_stride_u16] = (uint16_t)bits;
             uint32_t c = __popc(bits);

@@ -123,6 +123,10 @@ def test_residual_mask_gop_layouts(eng, oracle, dtype, channels):
     frames = rng.integers(0, hi, shape, dtype=dtype)
     frames[1:][rng.random(frames[1:].shape) < 0.7] = 0      # plenty of equal / extreme pairs
     frames[2] = frames[1]                                   # an all-zero mask
+    if dtype == np.uint16:                                  # |d| == 32768: numpy's abs(int16) stays negative -> bit 0, even at threshold 0
+        lum = frames if channels == 1 else frames[..., 0]
+        lum[3, 0, :6] = [32768, 0, 40000, 7232, 65535, 32767]
+        lum[4, 0, :6] = [0, 32768, 7232, 40000, 32767, 65535]
     for thr in (0.0, 2.5, 100.0, 32767.0, -3.0):
         masks, ones = eng.residual_masks(frames, thr)
         for f in range(F - 1):
