@@ -281,6 +281,10 @@ def main():
                                "avg_launch_ms_alone": (breakdown or {}).get("query"),   # same kernel, one pipeline, nothing co-running
                                "algorithmic_bytes_per_launch": int(alg_bytes),
                                "bytes_per_pixel": round(alg_bytes / (pairs * n), 4)}
+            # the whole fused path priced as SURVEY 8d does: 2 luma reads + packed mask, filter and witness per pixel
+            b_px = 2.0 * (args.bits // 8) + alg_bytes / (pairs * n)
+            out["roofline"]["end_to_end"] = {"bytes_per_pixel": round(b_px, 3), "achieved": round(value / world * 1e6 * b_px / 1e9, 1),
+                                             "unit": "GB/s per GPU", "frac": round(value / world * 1e6 * b_px / 1e9 / HBM_PEAK_GBPS, 4)}
             out["roofline"]["issue"] = None if args.density else issue_roofline(W, H, F, args.bits, (breakdown or {}).get("query"))
             out["kernels_ms_per_step"] = breakdown
         else:
