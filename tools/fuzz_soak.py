@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Parity soak: random GOP geometries / dtypes / densities / seeds / kernel families through the one-call GOP
+encoder, the decoder and the device-packed record, each checked against the CPU oracle (test infrastructure).
+Usage: python tools/fuzz_soak.py SECONDS [SEED]   -- prints the failing case (and exits 1) or a summary."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from new_bloom_filter_repo_amd import _native as nat
+from new_bloom_filter_repo_amd import params as P
+from new_bloom_filter_repo_amd.dist import unpack_device_record
+from new_bloom_filter_repo_amd.engine import BloomEngine
+from new_bloom_filter_repo_amd.gop import GopCoder
+from new_bloom_filter_repo_amd.synthetic import next_frame
+from oracle import oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int.from_bytes(os.urandom(4), "little")
+rng = np.random.default_rng(seed)
+print("seed", seed, flush=True)
+KNOBS = [0, 0, 0, 2, 1, 4 << 16, 32 << 16, 4]          # default (x3), single buffer, generic, tiled 1 KiB / 8 KiB, generic mask bits
+unpack = lambda a, nb: np.unpackbits(np.asarray(a, dtype=np.uint8))[:nb]
+t_end, cases, frames_done = time.time() + budget, 0, 0
+while time.time() < t_end:
+    knob = KNOBS[int(rng.integers(0, len(KNOBS)))]
+    big = rng.random() < 0.15
+    W, H = (int(rng.integers(200, 900)), int(rng.integers(100, 500))) if big else (int(rng.integers(1, 200)), int(rng.integers(1, 100)))
+    C = int(rng.choice([1, 3]))
+    dtype = [np.uint8, np.uint16][int(rng.integers(0, 2))]
+    F = int(rng.integers(2, 5))
+    seeds = [P.SEEDS_VIDEO, P.SEEDS_BLOOM_COMPRESS, tuple(int(x) for x in rng.integers(0, 2 ** 63, 3))][int(rng.integers(0, 3))]
+    thr = float(rng.choice([0.0, 0.0, 0.0, 1.0, 7.5]))
+    top = np.iinfo(dtype).max
+    frames = [rng.integers(0, top + 1, (H, W, 3), dtype=dtype)]
+    for _ in range(F - 1):
+        p = float(rng.choice([0.0, 0.0003, 0.01, 0.05, 0.0889, 0.15, 0.25, 0.31, 0.33, 0.6, 1.0]))
+        frames.append(next_frame(rng, frames[-1], p) if p else frames[-1].copy())
+    frames = np.stack(frames)
+    if C == 1:
+        frames = np.ascontiguousarray(frames[..., 0])
+    n = W * H
+    desc = dict(seed=seed, case=cases, knob=knob, W=W, H=H, C=C, dtype=np.dtype(dtype).name, F=F, seeds=seeds, thr=thr)
+    ctx = nat.Context(0)
+    ctx.force_generic(knob)
+    eng = BloomEngine(ctx)
+    coder = GopCoder(ctx, W, H, F, channels=C, sample_bytes=np.dtype(dtype).itemsize, seeds=seeds, threshold=thr)
+    coder.load_frames(frames)
+    coder.encode()
+    block = coder.pack()
+    res = coder.results()
+    recs = unpack_device_record(block.numpy(ctx), n)
+    try:
+        for f, r in enumerate(res):
+            y0, y1 = (frames[f], frames[f + 1]) if C == 1 else (frames[f][..., 0], frames[f + 1][..., 0])
+            want = oracle.residual_mask(np.ascontiguousarray(y0), np.ascontiguousarray(y1), thr).reshape(-1)
+            assert np.array_equal(unpack(r["mask"], n), want), "mask"
+            bm, wit, p, _, _ = oracle.compress(want, seeds=seeds)
+            g = recs[f]
+            if len(wit) == 0:
+                assert r["l"] == 0 and r["witness_bits"] == 0 and g["l"] == 0 and np.array_equal(g["mask"], r["mask"]), "passthrough"
+                continue
+            k, l = oracle.optimal_params(n, p)
+            assert (r["k"], r["l"]) == (k, l), "geometry"
+            assert np.array_equal(unpack(r["filter"], l), bm), "filter"
+            assert r["witness_bits"] == len(wit) and np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8)), "witness"
+            assert np.array_equal(g["filter"], r["filter"]) and np.array_equal(g["witness"], r["witness"]) and g["k"] == k, "record"
+            dec = eng.decode(n, [P.filter_params(k, l)], [r["filter"]], [r["witness"]], seeds=seeds)
+            assert np.array_equal(unpack(dec[0], n), want), "decode"
+            frames_done += 1
+    except AssertionError as e:
+        print("MISMATCH", e, "frame", f, desc, flush=True)
+        sys.exit(1)
+    coder.close()
+    eng.close()
+    ctx.close()
+    cases += 1
+print("ok: %d cases, %d coded frames checked in %.0f s (seed %d)" % (cases, frames_done, budget, seed))
