@@ -76,7 +76,6 @@ def main():
         torch.cuda.synchronize(device)
     ncoders = max(1, args.streams)
     streams = [torch.cuda.Stream(device) for _ in range(ncoders)]      # none of them is the null stream
-    comm_stream = torch.cuda.Stream(device) if use_dist else None      # orders the gathers after the packs
 
     from new_bloom_filter_repo_amd import _native as nat
     from new_bloom_filter_repo_amd.gop import GopCoder, TorchArena, torch_allocator
@@ -122,66 +121,45 @@ def main():
         def __init__(self, tensor):
             self.ptr, self.nbytes = tensor.data_ptr(), tensor.numel() * 8
 
-    box = {"slot_words": 0, "out": None, "slots": None, "gl": None, "pend": [None, None], "sent": 0,
-           "probe": [Slot(torch.zeros(record_max // 8, dtype=torch.int64, device=device)) for _ in range(ncoders)] if gather else None}
-    packed_ev = [torch.cuda.Event() for _ in range(ncoders)]
+    probe = [Slot(torch.zeros(record_max // 8, dtype=torch.int64, device=device)) for _ in range(ncoders)] if gather else None
+    og = None                                     # dist.OutboxGather once the slot size is agreed
+    slots = {}
     state = {"s": 0}
 
-    def send(ob):
-        """Gather outbox `ob` once every pipeline's packs into it are done; no pipeline stream waits for that."""
-        with torch.cuda.stream(comm_stream):
-            for k2 in range(ncoders):
-                comm_stream.wait_event(packed_ev[k2])
-            box["pend"][ob] = dist.gather(box["out"][ob].view(-1), box["gl"][ob], dst=0, async_op=True)
-        box["sent"] += 1
-
     def step():
-        s = state["s"]
+        k = state["s"] % ncoders
         state["s"] += 1
-        k = s % ncoders
         with torch.cuda.stream(streams[k]):
             if not gather:
                 coders[k].encode()
                 return
-            j, ob = s % G, (s // G) % 2
-            if j < ncoders and box["pend"][ob] is not None:
-                box["pend"][ob].wait()            # stream-side: this outbox's previous transfer has left
+            t = og.begin(k)                       # this step's slot (waits stream-side for the outbox's previous transfer)
             coders[k].encode()
-            coders[k].pack(box["slots"][ob][j])
-            packed_ev[k].record(streams[k])
-            if j == G - 1:
-                send(ob)
+            coders[k].pack(slots.setdefault(t.data_ptr(), Slot(t)))
+            og.end(k)                             # full outbox -> one asynchronous gather from the comm stream
 
     def drain():
-        if gather and box["slot_words"] and state["s"] % G:       # a partly filled outbox
-            send((state["s"] // G) % 2)
-            state["s"] += G - state["s"] % G
-        for ob in range(2):
-            if gather and box["pend"][ob] is not None:
-                box["pend"][ob].wait()
-                box["pend"][ob] = None
+        if og is not None:
+            og.flush()
 
     # setup (not warm-up steps): every pipeline sizes its scratch once, and for N > 1 the ranks agree on the slot
     for k in range(ncoders):
         coders[k].encode()
         if gather:
-            coders[k].pack(box["probe"][k])
+            coders[k].pack(probe[k])
     torch.cuda.synchronize(device)
     if gather:
+        from new_bloom_filter_repo_amd.dist import OutboxGather
         heads = []
         for k in range(ncoders):
             buf = np.zeros(4, dtype=np.uint64)
-            nat.check(nat.lib().rbf_memcpy_d2h(ctxs[k].handle, buf.ctypes.data, box["probe"][k].ptr, 32))
+            nat.check(nat.lib().rbf_memcpy_d2h(ctxs[k].handle, buf.ctypes.data, probe[k].ptr, 32))
             heads.append(int(buf[2]))
         agreed = torch.tensor([max(heads)], dtype=torch.int64, device=device)
         dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
         slot_bytes = min(record_max, (int(agreed.item()) * 102 // 100 + 4096 + 255) // 256 * 256)
-        box["slot_words"] = slot_bytes // 8
-        box["out"] = [torch.zeros(G, box["slot_words"], dtype=torch.int64, device=device) for _ in range(2)]
-        box["slots"] = [[Slot(o[j]) for j in range(G)] for o in box["out"]]
-        box["gl"] = [[torch.empty(G * box["slot_words"], dtype=torch.int64, device=device) for _ in range(world)] if rank == 0 else None
-                     for _ in range(2)]
-        box["probe"] = None
+        og = OutboxGather(slot_bytes // 8, G, device, streams=streams)
+        probe = None
         for _ in range(2 * G):                    # untimed: the first RCCL transfer of both outboxes (connection setup)
             step()
         drain()
@@ -248,7 +226,7 @@ def main():
         "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), %s, threshold 0"
                                % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3"),
                    "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders, "pipelines_agree": True,
-                   "gather_bytes_per_rank_per_step": box["slot_words"] * 8 if gather else 0, "steps_per_gather": G if gather else 0,
+                   "gather_bytes_per_rank_per_step": og.slot_words * 8 if gather else 0, "steps_per_gather": G if gather else 0,
                    "lds_tile_kib": args.lds_tile_kib or "auto", "generic_kernels": bool(args.generic_kernels),
                    "stages": "residual mask -> host params -> insert -> query+witness"},
     }
@@ -256,15 +234,15 @@ def main():
         # what arrived on rank 0 is complete: every slot of every rank has the right magic and frame
         # count, no overflow flag, a size that fits the slot; rank 0's own record matches its rows
         from new_bloom_filter_repo_amd.dist import RECORD_MAGIC, unpack_device_record
-        sw = box["slot_words"]
+        sw = og.slot_words
         for ob in range(2):
             for r in range(world):
-                heads = box["gl"][ob][r].view(G, sw)[:, :4].cpu().numpy().view(np.uint64)
+                heads = og.received(ob, r)[:, :4].cpu().numpy().view(np.uint64)
                 for j in range(G):
                     h = heads[j]
                     if int(h[0]) != RECORD_MAGIC or int(h[1]) != pairs or int(h[3]) != 0 or int(h[2]) > sw * 8:
                         raise SystemExit("gathered record of rank %d (outbox %d slot %d) is damaged: %s" % (r, ob, j, h.tolist()))
-        mine = box["gl"][0][0].view(G, sw)[0].cpu().numpy().view(np.uint8)
+        mine = og.received(0, 0)[0].cpu().numpy().view(np.uint8)
         for got, want in zip(unpack_device_record(mine, n), res):
             assert got["witness_bits"] == want["witness_bits"] and np.array_equal(got["witness"], want["witness"]), "gathered record differs"
     if rank == 0:

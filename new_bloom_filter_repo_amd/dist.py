@@ -81,6 +81,81 @@ def unpack_device_record(buf, n):
     return out
 
 
+class OutboxGather:
+    """Batched asynchronous gather of fixed-size record slots to rank 0 (bench.py's N > 1 path).
+
+    Every step writes one record into the next slot of an outbox of `steps_per_gather` slots; a full
+    outbox travels in ONE dist.gather (fewer, larger collectives), and two outboxes alternate so that
+    writing never waits for a transfer.  RCCL's gather needs equal sizes on all ranks, hence fixed slots.
+    On CUDA the gather is issued from its own stream, ordered after the writers' streams by events, so no
+    writer stream waits for a send; on CPU (gloo, tests) the same bookkeeping runs without streams.
+
+        slot = og.begin(k)      # on pipeline k's stream: where this step's record goes (int64 tensor)
+        ... enqueue the writes into `slot` on pipeline k's stream ...
+        og.end(k)               # record written; sends the outbox when this was its last slot
+        og.flush()              # send a partly filled outbox, wait for everything in flight
+    """
+
+    def __init__(self, slot_words, steps_per_gather, device, streams=None, group=None, dst=0):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self.group, self.dst = torch, dist, group, dst
+        self.G, self.slot_words = max(1, int(steps_per_gather)), int(slot_words)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.cuda = device.type == "cuda"
+        self.out = [torch.zeros(self.G, self.slot_words, dtype=torch.int64, device=device) for _ in range(2)]
+        self.inbox = [[torch.empty(self.G * self.slot_words, dtype=torch.int64, device=device) for _ in range(self.world)]
+                      if self.rank == dst else None for _ in range(2)]
+        self.pend = [None, None]
+        self.s = 0                      # steps begun so far (position in the slot sequence)
+        self.sent = 0
+        self.streams = list(streams) if streams else []
+        self.comm = torch.cuda.Stream(device) if self.cuda else None
+        self.events = [torch.cuda.Event() for _ in self.streams] if self.cuda else []
+
+    def _where(self):
+        return self.s % self.G, (self.s // self.G) % 2
+
+    def begin(self, k=0):
+        j, ob = self._where()
+        # the first write of every writer stream into this outbox waits for the outbox's previous transfer
+        if j < max(1, len(self.streams)) and self.pend[ob] is not None:
+            self.pend[ob].wait()
+        return self.out[ob][j]
+
+    def end(self, k=0):
+        if self.cuda and self.streams:
+            self.events[k].record(self.streams[k])
+        j, ob = self._where()
+        self.s += 1
+        if j == self.G - 1:
+            self._send(ob)
+
+    def _send(self, ob):
+        if self.cuda:
+            with self._torch.cuda.stream(self.comm):
+                for ev in self.events:
+                    self.comm.wait_event(ev)
+                self.pend[ob] = self._dist.gather(self.out[ob].view(-1), self.inbox[ob], dst=self.dst, group=self.group, async_op=True)
+        else:
+            self.pend[ob] = self._dist.gather(self.out[ob].view(-1), self.inbox[ob], dst=self.dst, group=self.group, async_op=True)
+        self.sent += 1
+
+    def flush(self):
+        j, ob = self._where()
+        if j:                           # a partly filled outbox: send it whole (stale slots ride along)
+            self._send(ob)
+            self.s += self.G - j
+        for ob in range(2):
+            if self.pend[ob] is not None:
+                self.pend[ob].wait()
+                self.pend[ob] = None
+
+    def received(self, ob, rank):
+        """On dst: the G slots last received from `rank` in outbox `ob`, as a (G, slot_words) view."""
+        return self.inbox[ob][rank].view(self.G, self.slot_words)
+
+
 def gather_records(records, dst=0, group=None, device=None):
     """Gather every rank's [(frame_index, type, bytes)] to `dst`; returns the merged list sorted by
     frame index on dst, None elsewhere.  Works on any backend (tensors live on `device`)."""

@@ -95,3 +95,57 @@ def test_unpack_device_record_parser():
         unpack_device_record(bad, n)
     with pytest.raises(ValueError, match="not a packed record"):
         unpack_device_record(np.zeros(64, np.uint8), n)
+
+
+def _outbox_worker(rank, world, port, q, G, steps, sw):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    from new_bloom_filter_repo_amd import dist as DD
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        og = DD.OutboxGather(sw, G, torch.device("cpu"))
+        for s in range(steps):
+            slot = og.begin(0)
+            slot.copy_(torch.arange(sw, dtype=torch.int64) + 1000 * s + 100000 * rank)     # this step's "record"
+            og.end(0)
+        og.flush()
+        if rank == 0:
+            got = {(ob, r): og.received(ob, r)[:, 0].tolist() for ob in range(2) for r in range(world)}
+            q.put((og.sent, og.s, got))
+        else:
+            q.put((og.sent, og.s, None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("G,steps", [(4, 11), (1, 3), (3, 6), (16, 5)])
+def test_outbox_gather_gloo_world2(G, steps):
+    """bench.py's N > 1 bookkeeping on CPU: slot sequence, alternating outboxes, one gather per full outbox,
+    a partly filled outbox flushed at the end, every rank's slots arriving on rank 0 in step order."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() * 7 + G * 13 + steps) % 2000
+    procs = [ctx.Process(target=_outbox_worker, args=(r, 2, port, q, G, steps, 6)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gathers = -(-steps // G)
+    for sent, s, got in outs:
+        assert sent == gathers and s == gathers * G            # every rank issued the same collectives
+        if got is None:
+            continue
+        # the last two rounds live in the two outboxes; round r used outbox r % 2 and holds steps r*G .. r*G+G-1
+        for rnd in range(max(0, gathers - 2), gathers):
+            for r in range(2):
+                firsts = got[(rnd % 2, r)]
+                for j in range(G):
+                    step = rnd * G + j
+                    if step < steps:
+                        assert firsts[j] == 1000 * step + 100000 * r, (rnd, r, j, firsts)
