@@ -24,6 +24,7 @@ __global__ __launch_bounds__(1024) void k_stage(const uint32_t *__restrict__ fil
         if (MODE == 0) {
             dma_filter(dst, src, words, wave, lane, nwaves);
         } else if (MODE == 2) {
+        } else if (MODE == 3) {
         } else {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const uint32_t npieces = words >> 2;
@@ -32,6 +33,12 @@ __global__ __launch_bounds__(1024) void k_stage(const uint32_t *__restrict__ fil
             for (int c = 0; c < 5; ++c) { const uint32_t piece = ((wave + c * nwaves) << 6) + lane; if (piece < npieces) v[c] = *reinterpret_cast<const u32x4 *>(src + (piece << 2)); }
 #pragma unroll
             for (int c = 0; c < 5; ++c) { const uint32_t piece = ((wave + c * nwaves) << 6) + lane; if (piece < npieces) *reinterpret_cast<u32x4 *>(dst + (piece << 2)) = v[c]; }
+        }
+        typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
+        u32x4b r3[5];
+        if (MODE == 3) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { const uint32_t piece = ((wave + c * nwaves) << 6) + lane; if (piece < npieces_d) r3[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4b *>(src + (piece << 2))); }
         }
         if (PROBE) {                                             // 24 random LDS reads per lane per frame from the OTHER buffer
             const uint32_t *probe = lds + (cur ^ 1u) * bufwords;
@@ -45,7 +52,11 @@ __global__ __launch_bounds__(1024) void k_stage(const uint32_t *__restrict__ fil
                 x = x * 1664525u + 1013904223u; acc += probe[(x >> 8) % words];
             }
         }
-        if (MODE != 1) dma_wait_all();
+        if (MODE == 3) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { const uint32_t piece = ((wave + c * nwaves) << 6) + lane; if (piece < npieces_d) *reinterpret_cast<u32x4b *>(dst + (piece << 2)) = r3[c]; }
+        }
+        if (MODE == 0 || MODE == 2) dma_wait_all();
         __syncthreads();
         cur ^= 1u;
     }
@@ -79,6 +90,7 @@ int main()
     printf("global_load + ds_write, no probes  %7.1f us\n", run<1, false>(df, stride, words, F, sink));
     printf("LDS-DMA + 24 LDS probes/lane/frame %7.1f us\n", run<0, true>(df, stride, words, F, sink));
     printf("load+ds_write + 24 probes          %7.1f us\n", run<1, true>(df, stride, words, F, sink));
+    printf("loads before / ds_write after probes %5.1f us\n", run<3, true>(df, stride, words, F, sink));
     printf("DMA piecemeal between probe groups %7.1f us\n", run<2, true>(df, stride, words, F, sink));
     return 0;
 }
