@@ -178,7 +178,6 @@ class ImprovedVideoCompressor:
                    "compression_ratio": ratio, "space_savings": 1.0 - ratio, "compression_time": elapsed,
                    "frames_per_second": len(frames) / elapsed if elapsed > 0 else float("inf"),
                    "keyframes": keyframes, "keyframe_ratio": keyframes / len(frames),
-                   "mpixels_per_second": (sum(int(np.prod(frame_data(f).shape[:2])) for f in frames) / elapsed / 1e6) if elapsed > 0 else float("inf"),
                    "output_path": output_path, "color_space": input_color_space, "overall_ratio": ratio}
         if self.verbose:
             print("\\nCompression Results:")
