@@ -776,10 +776,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         const uint64_t lane_off = (seg * 1024 + (uint64_t)lane * 16) * PIXEL_BYTES;
         const uint8_t *p = frames + lane_off;
         uint16_t *out = masks + seg * 64 + lane;
-        LP prev, cur, nxt;
-        prev.template load<NT>(p + (uint64_t)f0 * frame_stride);
-        cur.template load<NT>(p + (uint64_t)(f0 + 1) * frame_stride);
-        for (uint32_t f = f0 + 1; f <= f1; ++f) {
+        LP fa, fb, fc;                                            // three frames in registers, roles rotate
+        fa.template load<NT>(p + (uint64_t)f0 * frame_stride);
+        fb.template load<NT>(p + (uint64_t)(f0 + 1) * frame_stride);
+        // pair (prev, cur) = mask f-1; `nxt` receives frame f+1 meanwhile
+        auto step = [&](const LP &prev, const LP &cur, LP &nxt, uint32_t f) {
             if (f + 1 <= f1) nxt.template load<NT>(p + (uint64_t)(f + 1) * frame_stride);
             const int32_t thr = thr_tab ? thr_tab[f - 1] : thr_all;
             uint32_t bits = 0;
@@ -796,8 +797,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
 #pragma unroll
             for (int dlt = 32; dlt >= 1; dlt >>= 1) c += __shfl_down(c, dlt);
             if (lane == 0 && c) atomicAdd(&cnt[f - 1], c);
-            prev = cur;
-            cur = nxt;
+        };
+        // unrolled by three so that the rotation prev <- cur <- nxt costs no register moves (they were a
+        // quarter of the loop's VALU instructions)
+        for (uint32_t f = f0 + 1; f <= f1; f += 3) {
+            step(fa, fb, fc, f);
+            if (f + 1 <= f1) step(fb, fc, fa, f + 1);
+            if (f + 2 <= f1) step(fc, fa, fb, f + 2);
         }
     }
     __syncthreads();
