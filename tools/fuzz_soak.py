@@ -52,7 +52,14 @@ while time.time() < t_end:
     block = coder.pack()
     res = coder.results()
     recs = unpack_device_record(block.numpy(ctx), n)
+    vals, uncovered = coder.gather_values(check_uncovered=True)
     try:
+        for f in range(F - 1):                                   # A2: changed values of every pair + what the luma mask misses
+            a, b = frames[f], frames[f + 1]
+            m = np.unpackbits(res[f]["mask"])[:n].reshape(H, W).astype(bool)
+            assert np.array_equal(vals[f], b[m].reshape(-1)), "values"
+            ch = (a != b) if C == 1 else (a != b).any(axis=2)
+            assert int(uncovered[f]) == int((ch & ~m).sum()), "uncovered"
         for f, r in enumerate(res):
             y0, y1 = (frames[f], frames[f + 1]) if C == 1 else (frames[f][..., 0], frames[f + 1][..., 0])
             want = oracle.residual_mask(np.ascontiguousarray(y0), np.ascontiguousarray(y1), thr).reshape(-1)
