@@ -193,3 +193,41 @@ def test_bloom_compress_containers_parse_reference_blobs():
     assert BC._pack_text_data(BC, bm, wit, p, n, k, tl, bd) == z["sparse_text_blob"].tobytes()
     txt = meta["text"]["text"]
     assert BC._debinarize_text(BC._binarize_text(txt, 8), 8) == txt
+
+
+def test_header_is_plain_c():
+    """include/rbf.h is the drop-in boundary: it must compile as C99 and as C++ on its own."""
+    import subprocess
+    hdr = os.path.join(REPO, "include", "rbf.h")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                ["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def test_c_consumer_links_and_agrees(tmp_path):
+    """A plain C program built against include/rbf.h and linked with librbf_hip.so (what a cgo / JNI / FFI binding
+    does) gets the same filter geometry as params.py and the fixtures."""
+    import subprocess
+    pkg = os.path.join(REPO, "new_bloom_filter_repo_amd")
+    exe = str(tmp_path / "abi_smoke")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tests", "c", "abi_smoke.c"),
+                        "-L", pkg, "-lrbf_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cases = [(2073600, 184322), (57600, 5120), (8294400, 737288), (2073600, 100), (2073600, 700000), (1000, 0), (57600, 17000)]
+    out = subprocess.run([exe] + [str(v) for c in cases for v in c], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "version 1" and lines[-1].startswith("error ") and len(lines[-1]) > 8
+    assert lines[-2] == "record_max %d" % (8 * (4 + 8 * 29) + 29 * 2 * ((2073600 + 63) // 64 * 8))
+    for (n, ones), line in zip(cases, lines[1:]):
+        f = line.split()
+        k, l = P.optimal_params(n, np.uint64(ones) / n)
+        assert (int(f[1]), int(f[2])) == (n, ones) and float.fromhex(f[3]) == k and int(f[4]) == l, line
+        guard = l == 0 or l >= n or np.uint64(ones) / n >= P.P_STAR
+        if k > 0:
+            m, fk, thr = P.filter_params(k, l)
+            assert (int(f[5]), int(f[6])) == (fk, thr), line
+            assert [int(x) for x in f[8:11]] == ([0, 0, 0] if guard else [m, fk, thr]), line
+        else:
+            assert [int(x) for x in f[8:11]] == [0, 0, 0], line
