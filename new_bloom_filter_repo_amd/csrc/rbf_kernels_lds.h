@@ -316,7 +316,7 @@ __device__ __forceinline__ uint32_t frame_pass(
         else         { pos = mod_m(h1[it], m, M);            step = mod_m(h2[it], m, M); }
         // Each probe shifts its word LEFT so that the probed bit lands in bit 31: the verdict is the
         // sign bit of the AND of all probes.  MSB-first bit (pos & 31) ^ 7 -> shift (pos ^ 24) & 31.
-        uint32_t acc = (validmask >> it) << 31;
+        uint32_t acc = validmask << (31 - it);                // only the sign bit is ever looked at: bit `it` -> bit 31
 #pragma unroll
         for (uint32_t j = 0; j < fk; ++j) {
             acc &= ((AB & 2) ? (pos * 0x9E3779B1u) : probe_word(filt, pos)) << ((pos ^ 24u) & 31u);
