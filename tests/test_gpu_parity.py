@@ -342,3 +342,27 @@ def test_random_geometry_fuzz(oracle):
         coder.close()
     eng.close()
     ctx.close()
+
+
+def test_key_length_boundary_at_ten_million(eng, oracle):
+    """Indices around 10^7 (7- and 8-character keys in the same wave) through every kernel family: the LDS kernels'
+    fixed-length and shared-prefix hash paths must hand over to the generic one exactly at the boundary."""
+    import ctypes
+    n = 10_000_640                                            # the last 640 positions have 8-character keys
+    mask = np.zeros(n, dtype=np.uint8)
+    rng = np.random.default_rng(77)
+    mask[rng.integers(0, n, 18000)] = 1
+    mask[9_999_990:10_000_012] = [1, 0] * 11                   # straddle the boundary
+    k, l = 2.3, 400_003                                       # a filter that fits LDS (50 KB), not the optimal one for this n
+    pl = [P.filter_params(k, l)]
+    eng.upload_masks(np.packbits(mask)[None, :], n)
+    r = eng.encode(n, pl)[0]
+    bit_array = np.zeros(l, dtype=np.uint8)
+    witness = np.zeros(n, dtype=np.uint8)
+    seeds = (ctypes.c_uint64 * 3)(*P.SEEDS_VIDEO)
+    w = oracle.lib().orc_compress(mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n, l, k, seeds,
+                                  bit_array.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), witness.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    assert np.array_equal(unpack(r["filter"], l), bit_array)
+    assert r["witness_bits"] == w and np.array_equal(unpack(r["witness"], w), witness[:w])
+    dec = eng.decode(n, pl, [r["filter"]], [r["witness"]])
+    assert np.array_equal(unpack(dec[0], n), mask)
