@@ -366,3 +366,28 @@ def test_key_length_boundary_at_ten_million(eng, oracle):
     assert r["witness_bits"] == w and np.array_equal(unpack(r["witness"], w), witness[:w])
     dec = eng.decode(n, pl, [r["filter"]], [r["witness"]])
     assert np.array_equal(unpack(dec[0], n), mask)
+
+
+def test_key_length_boundary_at_hundred_million(oracle):
+    """8- and 9-character keys (indices around 10^8) through the default LDS kernels with a filter that fits LDS."""
+    import ctypes
+    n = 100_000_640
+    mask = np.zeros(n, dtype=np.uint8)
+    rng = np.random.default_rng(78)
+    mask[rng.integers(0, n, 30000)] = 1
+    mask[99_999_985:100_000_015] = [1, 1, 0] * 10
+    k, l = 1.7, 611_158
+    pl = [P.filter_params(k, l)]
+    ctx = nat.Context(0)
+    e = BloomEngine(ctx)
+    e.upload_masks(np.packbits(mask)[None, :], n)
+    r = e.encode(n, pl)[0]
+    bit_array = np.zeros(l, dtype=np.uint8)
+    witness = np.zeros(n, dtype=np.uint8)
+    seeds = (ctypes.c_uint64 * 3)(*P.SEEDS_VIDEO)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    w = oracle.lib().orc_compress(mask.ctypes.data_as(u8p), n, l, k, seeds, bit_array.ctypes.data_as(u8p), witness.ctypes.data_as(u8p))
+    assert np.array_equal(unpack(r["filter"], l), bit_array)
+    assert r["witness_bits"] == w and np.array_equal(unpack(r["witness"], w), witness[:w])
+    e.close()
+    ctx.close()
