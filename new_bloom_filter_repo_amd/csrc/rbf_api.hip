@@ -378,7 +378,7 @@ struct Plan {
     bool fast_insert;            // LDS partial-filter insert (any filter size, tiled when needed)
     int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles
     bool double_buffer, small_m;
-    uint32_t fwords_max, S /* most slices of a frame */, per_tile /* sum of slices */;
+    uint32_t fwords_max, S /* slices of a coded frame */, per_tile /* sum of slices */, insert_group /* coded frames per insert launch */;
     SliceTable slices;
     uint32_t insert_tile_words, insert_tiles, query_tile_words;
     size_t insert_lds_bytes, query_lds_bytes;
@@ -431,20 +431,26 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
             if (auto_tiles && (p.fwords_max + p.query_tile_words - 1) / p.query_tile_words > MAX_QUERY_TILES) p.query_kind = 0;
         }
     }
-    // slices per frame so that S * tiles * frames ~ one workgroup per CU (256 CUs), at most 32
-    // (handing the remainder out as one extra slice to some frames was measured and buys nothing: the launch
-    // lasts as long as its largest slice)
+    // Slices per frame so that one launch has about one workgroup per CU (256).  With many frames or several
+    // tiles the quotient gets small (4K, 29 frames, 3 tiles: 2 slices -> 174 long workgroups), so the frames are
+    // inserted in groups of `insert_group` coded frames, each group one launch with >= INSERT_SLICES slices per frame
+    // (4K: 10 frames x 8 slices x 3 tiles = 240 workgroups).  Handing out uneven slices to use all 256 CUs was
+    // measured and buys nothing: a launch lasts as long as its largest slice.
+    constexpr uint32_t INSERT_SLICES = 8;
     const uint32_t units = 256u / p.insert_tiles;                           // workgroups per tile layer
-    uint32_t base = active ? units / active : 1u, extra = 0u;
+    uint32_t group = units / INSERT_SLICES;                                  // coded frames per launch
+    if (group < 1) group = 1;
+    if (group > active) group = active ? active : 1;
+    uint32_t base = units / group;
     if (base < 1) base = 1;
     if (base > 32) base = 32;
-    p.S = 1;
+    p.insert_group = group;
+    p.S = base;
     p.per_tile = 0;
-    for (uint32_t f = 0, a = 0; f < nframes; ++f) {
-        const uint32_t sf = params[f].m ? base + (a++ < extra ? 1u : 0u) : 0u;
+    for (uint32_t f = 0; f < nframes; ++f) {
+        const uint32_t sf = params[f].m ? base : 0u;
         p.slices.n[f] = (uint8_t)sf;
         p.per_tile += sf;
-        if (sf > p.S) p.S = sf;
     }
     const uint32_t segpx = p.query_kind == 1 ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
     p.nseg = (n + segpx - 1) / segpx;
@@ -624,11 +630,20 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         if (int r = grow((void **)&ctx->partials, &ctx->partials_cap, (size_t)nframes * pl.S * part_stride * 4)) return r;
         auto ikern = pl.small_m ? k_insert_lds<true> : k_insert_lds<false>;
         if (int r = allow_big_lds((const void *)ikern)) return r;
-        {
+        for (uint32_t f0 = 0; f0 < nframes;) {                    // groups of pl.insert_group coded frames
+            SliceTable grp{};
+            uint32_t per_tile = 0, coded = 0, f = f0;
+            for (; f < nframes && coded < pl.insert_group; ++f) {
+                grp.n[f] = pl.slices.n[f];
+                per_tile += grp.n[f];
+                coded += grp.n[f] ? 1u : 0u;
+            }
+            f0 = f;
+            if (!per_tile) continue;
             LaunchTimer t(ctx, RBF_K_INSERT);
-            hipLaunchKernelGGL(ikern, dim3(pl.per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+            hipLaunchKernelGGL(ikern, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
                                (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.insert_tile_words,
-                               pl.slices, pl.per_tile, pl.S);
+                               grp, per_tile, pl.S);
         }
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);
