@@ -26,7 +26,7 @@ unpack = lambda a, nb: np.unpackbits(np.asarray(a, dtype=np.uint8))[:nb]
 t_end, cases, frames_done = time.time() + budget, 0, 0
 while time.time() < t_end:
     knob = KNOBS[int(rng.integers(0, len(KNOBS)))]
-    big = rng.random() < 0.15
+    big = rng.random() < float(os.environ.get("SOAK_BIG", "0.15"))        # share of cases with frames up to 900 x 500
     W, H = (int(rng.integers(200, 900)), int(rng.integers(100, 500))) if big else (int(rng.integers(1, 200)), int(rng.integers(1, 100)))
     C = int(rng.choice([1, 3]))
     dtype = [np.uint8, np.uint16][int(rng.integers(0, 2))]
