@@ -81,7 +81,7 @@ class GopCoder:
             b = base_alloc(nbytes)
             self._blocks.append(b)
             return b
-        self._alloc_any = alloc
+        self._alloc = alloc
         self.frame_bytes = self.n * channels * sample_bytes
         self.mask_stride, self.filter_stride, self.witness_stride = self.strides(self.n)
         oalloc = self._out_alloc = out_allocator or alloc
@@ -94,7 +94,6 @@ class GopCoder:
         if self.adaptive is not None:
             self.moments = alloc(16 * self.pairs)
             self.noise_plane = None                       # allocated on the first exact fallback
-            self._alloc = alloc
         self.params = (nat.FilterParams * self.pairs)()
         self.k = (ctypes.c_double * self.pairs)()
 
@@ -182,10 +181,10 @@ class GopCoder:
         ones = self.ones.numpy(self.ctx)[:8 * self.pairs].view(np.uint64)
         total = int(ones.sum())
         if getattr(self, "_values", None) is None or self._values.nbytes < max(8, total * self.C * self.sb):
-            self._values = self._alloc_any(max(8, total * self.C * self.sb))
+            self._values = self._alloc(max(8, total * self.C * self.sb))
         if getattr(self, "_voff", None) is None:
-            self._voff = self._alloc_any(8 * (self.pairs + 1))
-            self._uncov = self._alloc_any(8 * self.pairs)
+            self._voff = self._alloc(8 * (self.pairs + 1))
+            self._uncov = self._alloc(8 * self.pairs)
         nat.check(nat.lib().rbf_gather_values_batch(
             self.ctx.handle, self.frames.ptr, self.frame_bytes, self.F, self.W, self.H, self.W * self.C * self.sb, self.C * self.sb,
             self.sb, self.C, self.masks.ptr, self.mask_stride, self._values.ptr, total, self._voff.ptr,
