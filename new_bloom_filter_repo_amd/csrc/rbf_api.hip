@@ -107,7 +107,8 @@ struct LaunchTimer {
     {
         if (!on) return;
         (void)hipEventRecord(b, c->stream);
-        c->pending.push_back({id, a, b});
+        try { c->pending.push_back({id, a, b}); }                 // timing is best effort; nothing may throw across the C ABI
+        catch (...) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
     }
 };
 
@@ -121,8 +122,8 @@ static int drain_timing(rbf_ctx *ctx)
             ctx->total_ms[t.id] += ms;
             ctx->launches[t.id] += 1;
         }
-        ctx->pool.push_back(t.a);
-        ctx->pool.push_back(t.b);
+        try { ctx->pool.push_back(t.a); } catch (...) { (void)hipEventDestroy(t.a); }
+        try { ctx->pool.push_back(t.b); } catch (...) { (void)hipEventDestroy(t.b); }
     }
     ctx->pending.clear();
     return RBF_OK;
@@ -819,8 +820,12 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
         HIP_TRY(hipHostMalloc((void **)&ctx->ones_pinned, (size_t)(pairs + 17) * sizeof(uint64_t), hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void **)&ctx->ones_mapped_dev, ctx->ones_pinned, 0));
         ctx->ones_pinned[0] = 0;
-        ctx->plan.resize(pairs + 16);
-        ctx->plan_k.resize(pairs + 16);
+        try {                                                    // the C ABI never throws
+            ctx->plan.resize(pairs + 16);
+            ctx->plan_k.resize(pairs + 16);
+        } catch (...) {
+            return fail(RBF_ENOMEM, "out of host memory for %u frame plans", pairs);
+        }
         ctx->host_cap = pairs + 16;
     }
     // The GPU publishes the counts straight into host memory; meanwhile the output buffers are
