@@ -131,6 +131,47 @@ class FixedVideoCompressor:
         return YUVFrame(yuv_frame)
 
 
+# ----------------------------------------------------------------------------- wire record (A7)
+def build_record(wire_format, p, n, k, bitmap_bits, bitmap_packed, witness_bits, witness_packed, value_count, values_z):
+    """The inter-frame wire record of improved_video_compressor.py:933-959 from already packed parts
+    (bitmap_packed / witness_packed: numpy.packbits bytes; values_z: zlib-9 of the value bytes).
+    wire_format "reference": k as float32, the reference's bytes; "f64": k as float64 (module docstring)."""
+    bm, wb = bytes(bitmap_packed), bytes(witness_packed)
+    return b"".join([
+        struct.pack("<f", p), struct.pack("<I", n),
+        struct.pack("<f" if wire_format == "reference" else "<d", k),
+        struct.pack("<I", bitmap_bits), struct.pack("<I", witness_bits),
+        struct.pack("<I", len(bm)), bm, struct.pack("<I", len(wb)), wb,
+        struct.pack("<I", len(values_z)), struct.pack("<I", value_count), values_z])
+
+
+def parse_record(wire_format, compressed_data):
+    """Fields of a wire record without decoding anything (:983-1012): dict with p, n, k, bitmap_bits,
+    witness_bits, bitmap (packed bytes), witness (packed bytes), values_z, value_count."""
+    mv = memoryview(compressed_data)
+    off = 0
+
+    def take(fmt):
+        nonlocal off
+        v = struct.unpack_from(fmt, mv, off)[0]
+        off += struct.calcsize(fmt)
+        return v
+    out = {"p": take("<f"), "n": take("<I"), "k": take("<f" if wire_format == "reference" else "<d"),
+           "bitmap_bits": take("<I"), "witness_bits": take("<I")}
+    size = take("<I")
+    out["bitmap"] = np.frombuffer(mv[off:off + size], dtype=np.uint8)
+    off += size
+    size = take("<I")
+    out["witness"] = np.frombuffer(mv[off:off + size], dtype=np.uint8)
+    off += size
+    vsize = take("<I")
+    out["value_count"] = take("<I")
+    out["values_z"] = bytes(mv[off:off + vsize])
+    if off + vsize > len(mv):
+        raise ValueError("truncated inter-frame record")
+    return out
+
+
 # ----------------------------------------------------------------------------- inter-frames
 class VideoFrameCompressor:
     def __init__(self, noise_tolerance=10.0, keyframe_interval=30, min_diff_threshold=3.0,
@@ -220,15 +261,7 @@ class VideoFrameCompressor:
 
     # ---- A3-A5 + A7
     def _build_record(self, p, n, k, bitmap_bits, bitmap_packed, witness_bits, witness_packed, value_count, values_z):
-        """The wire record of improved_video_compressor.py:933-959 from already packed parts
-        (bitmap_packed / witness_packed: numpy.packbits bytes; values_z: zlib-9 of the value bytes)."""
-        bm, wb = bytes(bitmap_packed), bytes(witness_packed)
-        return b"".join([
-            struct.pack("<f", p), struct.pack("<I", n),
-            struct.pack("<f" if self.wire_format == "reference" else "<d", k),
-            struct.pack("<I", bitmap_bits), struct.pack("<I", witness_bits),
-            struct.pack("<I", len(bm)), bm, struct.pack("<I", len(wb)), wb,
-            struct.pack("<I", len(values_z)), struct.pack("<I", value_count), values_z])
+        return build_record(self.wire_format, p, n, k, bitmap_bits, bitmap_packed, witness_bits, witness_packed, value_count, values_z)
 
     def _compress_frame_differences(self, binary_diff, changed_values):
         """(record bytes, ratio) -- improved_video_compressor.py:911-967."""
@@ -243,28 +276,7 @@ class VideoFrameCompressor:
         return rec, ratio
 
     def _parse_record(self, compressed_data):
-        """Fields of a wire record without decoding anything (:983-1012): dict with p, n, k, bitmap_bits,
-        witness_bits, bitmap (packed bytes), witness (packed bytes), values_z, value_count."""
-        mv = memoryview(compressed_data)
-        off = 0
-
-        def take(fmt):
-            nonlocal off
-            v = struct.unpack_from(fmt, mv, off)[0]
-            off += struct.calcsize(fmt)
-            return v
-        out = {"p": take("<f"), "n": take("<I"), "k": take("<f" if self.wire_format == "reference" else "<d"),
-               "bitmap_bits": take("<I"), "witness_bits": take("<I")}
-        size = take("<I")
-        out["bitmap"] = np.frombuffer(mv[off:off + size], dtype=np.uint8)
-        off += size
-        size = take("<I")
-        out["witness"] = np.frombuffer(mv[off:off + size], dtype=np.uint8)
-        off += size
-        vsize = take("<I")
-        out["value_count"] = take("<I")
-        out["values_z"] = bytes(mv[off:off + vsize])
-        return out
+        return parse_record(self.wire_format, compressed_data)
 
     def _decompress_frame_differences(self, compressed_data, frame_shape, dtype=np.uint8):
         """(binary_diff, changed_values) -- improved_video_compressor.py:969-1027."""
