@@ -2,6 +2,7 @@
 missing or a call fails, the caller gets an exception."""
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -116,7 +117,9 @@ def device_count():
 
 
 class DeviceBuffer:
-    """A block of device memory owned by a Context (freed with it or by .free())."""
+    """A block of device memory.  Freed by .free(), when the last reference to it goes away, or with its
+    Context -- whichever comes first (the context only keeps a weak reference, so dropping a filter /
+    coder / compressor object returns its HBM)."""
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
@@ -128,9 +131,24 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            check(lib().rbf_free(self.ctx.handle, self.ptr))
-            self.ptr = None
+            ptr, self.ptr = self.ptr, None
             self.ctx._buffers.discard(self)
+            if self.ctx.handle:                       # a closed context has already released its blocks
+                check(lib().rbf_free(self.ctx.handle, ptr))
+
+    close = free
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
     def zero(self):
         check(lib().rbf_memset(self.ctx.handle, self.ptr, 0, self.nbytes))
@@ -158,7 +176,7 @@ class Context:
         check(lib().rbf_ctx_create(int(device), _vp(stream) if stream else None, ctypes.byref(h)))
         self.handle = h.value
         self.device = int(device)
-        self._buffers = set()
+        self._buffers = weakref.WeakSet()     # live blocks, so close() can release what is still referenced
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
@@ -170,8 +188,8 @@ class Context:
         if self.handle:
             for b in list(self._buffers):
                 b.free()
-            check(lib().rbf_ctx_destroy(self.handle))
-            self.handle = None
+            handle, self.handle = self.handle, None
+            check(lib().rbf_ctx_destroy(handle))
 
     def __enter__(self):
         return self

@@ -59,7 +59,9 @@ def record_used_bytes(buf):
 def unpack_device_record(buf, n):
     """Parse the block rbf_pack_records wrote (GopCoder.pack): list of per-frame dicts with the
     packed filter / witness bytes (numpy.packbits order), or the packed mask for frames the
-    reference does not Bloom-code (l == 0)."""
+    reference does not Bloom-code (l == 0).  buf: bytes-like, numpy array or (device) tensor."""
+    if hasattr(buf, "cpu"):
+        buf = buf.cpu().numpy()
     raw = np.frombuffer(bytes(buf), dtype=np.uint8)
     head = raw[:32].view("<u8")
     if int(head[0]) != RECORD_MAGIC:
@@ -181,6 +183,63 @@ def gather_records(records, dst=0, group=None, device=None):
         merged += unpack_records(slots[r][:int(lengths[r].item())].cpu().numpy().tobytes())
     merged.sort(key=lambda x: x[0])
     return merged
+
+
+def gather_device_records(records, device, dst=0, group=None):
+    """Exact-size gather of device-packed records (GopCoder.pack) to `dst`, RCCL has no gatherv:
+    every rank reads the used size of its records from their headers (one small D2H), the sizes are
+    all-gathered, then every rank but `dst` sends the used bytes of its records as ONE message and `dst`
+    posts one receive per peer -- grouped point-to-point (batch_isend_irecv = ncclGroupStart/End on RCCL),
+    so over xGMI each peer uses its own link into `dst`.  The records of `dst` itself never enter a
+    collective.  Nothing is padded to a common slot size, so a record cannot overflow.
+
+    records: list of int64 device tensors (one packed record each; any slack after the used bytes is ignored).
+    Returns on dst a list (rank-major, record order kept) of uint8 device tensors, one exact-size record each;
+    None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if records:
+        heads = torch.stack([r[:4] for r in records]).cpu().numpy().view(np.uint64)
+        if any(int(h[0]) != RECORD_MAGIC or int(h[3]) != 0 for h in heads):
+            raise ValueError("a record to gather is damaged or truncated")
+        used = [(int(h[2]) + 7) // 8 * 8 for h in heads]
+    else:
+        used = []
+    maxrec = torch.tensor([len(used)], dtype=torch.int64, device=device)
+    dist.all_reduce(maxrec, op=dist.ReduceOp.MAX, group=group)
+    maxrec = int(maxrec.item())
+    mine = torch.zeros(maxrec, dtype=torch.int64, device=device)
+    if used:
+        mine[:len(used)] = torch.tensor(used, dtype=torch.int64, device=device)
+    sizes = [torch.zeros(maxrec, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    sizes = [[int(x) for x in s.cpu().tolist() if int(x)] for s in sizes]
+    own = [r[:u // 8].view(torch.uint8) for r, u in zip(records, used)]
+    ops, inbox = [], {}
+    if rank == dst:
+        for r in range(world):
+            if r != dst and sum(sizes[r]):
+                inbox[r] = torch.empty(sum(sizes[r]), dtype=torch.uint8, device=device)
+                ops.append(dist.P2POp(dist.irecv, inbox[r], r, group))
+    elif used:
+        payload = torch.cat(own)
+        ops.append(dist.P2POp(dist.isend, payload, dst, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if rank != dst:
+        return None
+    out = []
+    for r in range(world):
+        if r == dst:
+            out += own
+            continue
+        off = 0
+        for u in sizes[r]:
+            out.append(inbox[r][off:off + u])
+            off += u
+    return out
 
 
 def encode_video_sharded(frames, first_index, nframes_total, keyframe_interval=30, ctx=None, dst=0, group=None):

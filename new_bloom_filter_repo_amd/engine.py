@@ -32,6 +32,12 @@ class BloomEngine:
             b.free()
         self._bufs = {}
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     # ------------------------------------------------------------------ A1
     def _upload_frames(self, frames, min_frames):
         frames = np.ascontiguousarray(frames)
@@ -243,6 +249,15 @@ class DeviceFilter:
         self.ctx, self.m = ctx, int(m)
         self.nbytes = nat.packed_stride(self.m)
         self.buf = ctx.alloc(self.nbytes).zero()
+
+    def close(self):
+        self.buf.free()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _params(self, floor_k, threshold):
         return nat.FilterParams(self.m, int(floor_k), int(threshold))

@@ -106,8 +106,30 @@ class FixedVideoCompressor:
         dtype = {1: np.uint8, 2: np.uint16}.get(item, np.float32)
         gray = h * w * item
         if len(raw) > gray and len(raw) % gray == 0:
-            return np.frombuffer(raw, dtype=dtype).reshape(h, w, len(raw) // gray)
-        return np.frombuffer(raw, dtype=dtype).reshape(h, w)
+            frame = np.frombuffer(raw, dtype=dtype).reshape(h, w, len(raw) // gray)
+        else:
+            frame = np.frombuffer(raw, dtype=dtype).reshape(h, w)
+        # trailer: '<B' has_yuv_info [| '<H' len, format | 3 x ('<I' len, zlib(plane), '<II' shape)]
+        # (fixed_video_compressor.py:108-184: a frame written with yuv_info comes back as the wrapper)
+        off = 16 + size
+        if off < len(blob) and blob[off] == 1:
+            off += 1
+            (flen,) = struct.unpack_from("<H", blob, off)
+            fmt = bytes(blob[off + 2:off + 2 + flen]).decode("utf-8")
+            off += 2 + flen
+            planes = []
+            for _ in range(3):
+                (zlen,) = struct.unpack_from("<I", blob, off)
+                z = blob[off + 4:off + 4 + zlen]
+                ph, pw = struct.unpack_from("<II", blob, off + 4 + zlen)
+                off += 12 + zlen
+                planes.append(np.frombuffer(zlib.decompress(z), dtype=dtype).reshape(ph, pw))
+            if frame.ndim != 3 or frame.shape[2] < 3 or any(not np.array_equal(planes[c], frame[:, :, c]) for c in range(3)):
+                raise ValueError("keyframe record: stored YUV planes do not match the frame channels")
+            out = YUVFrame(frame)
+            out.yuv_info["format"] = fmt
+            return out
+        return frame
 
     def compress_video(self, frames):
         if self.verbose:
@@ -191,6 +213,16 @@ class VideoFrameCompressor:
         self._ctx = ctx or nat.default_context()
         self.bloom_compressor = BloomFilterCompressor(verbose=False, ctx=self._ctx)
         self._engine = BloomEngine(self._ctx)
+
+    def close(self):
+        """Return the device scratch of this codec (also happens when the object is dropped)."""
+        self._engine.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     # ---- A1 + A2
     def _luma_pair(self, prev_frame, curr_frame):

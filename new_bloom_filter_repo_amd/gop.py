@@ -117,6 +117,12 @@ class GopCoder:
                 b.buf.free()
         self._blocks = []
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def load_frames(self, frames):
         frames = np.ascontiguousarray(frames)
         assert frames.nbytes == self.frame_bytes * self.F, (frames.shape, frames.dtype)

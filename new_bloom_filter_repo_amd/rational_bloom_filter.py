@@ -30,6 +30,16 @@ class RationalBloomFilter:
         _fk, self._threshold = P.activation_threshold(k_star)
         self._dev = DeviceFilter(ctx or nat.default_context(), self.size)
 
+    def close(self):
+        """Return the filter's device memory (also happens when the object is dropped)."""
+        self._dev.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     @property
     def _seeds(self):
         return (self.h1_seed, self.h2_seed, self.act_seed)
@@ -78,6 +88,16 @@ class StringRationalBloomFilter:
         _fk, self._threshold = P.activation_threshold(k_star)
         self._dev = DeviceFilter(ctx or nat.default_context(), self.size)
 
+    def close(self):
+        """Return the filter's device memory (also happens when the object is dropped)."""
+        self._dev.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     @property
     def _seeds(self):
         return (self.h1_seed, self.h2_seed, self.ceil_k)
@@ -115,6 +135,16 @@ class StandardBloomFilter:
         self.size = int(m)
         self.hash_count = int(k)
         self._dev = DeviceFilter(ctx or nat.default_context(), self.size)
+
+    def close(self):
+        """Return the filter's device memory (also happens when the object is dropped)."""
+        self._dev.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def add(self, item):
         self.add_many([item])

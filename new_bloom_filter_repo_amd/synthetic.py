@@ -44,6 +44,21 @@ def make_gop(seed, width, height, nframes, p=P_KSTAR_2_3, dtype=np.uint8):
     return frames
 
 
+def make_clip_shard(seed, width, height, first, stop, interval=30, p=P_KSTAR_2_3, dtype=np.uint8):
+    """Frames [first, stop) of a long synthetic clip, as an array (stop-first, H, W, 3).  The clip is a sequence
+    of independent GOPs of `interval` frames (GOP g = make_gop(seed * 1000 + g, ...)), so any rank can produce
+    its shard -- including a halo frame -- without generating the frames before it, and every rank sees the
+    same clip."""
+    out = []
+    g = first // interval
+    while g * interval < stop:
+        lo, hi = max(first, g * interval), min(stop, (g + 1) * interval)
+        gop = make_gop(seed * 1000 + g, width, height, hi - g * interval, p=p, dtype=dtype)
+        out += gop[lo - g * interval:]
+        g += 1
+    return np.stack(out)
+
+
 def make_mask(seed, n, p):
     """Flat 0/1 uint8 vector with Bernoulli(p) ones (the reference's `binary_input`)."""
     return (np.random.default_rng(seed).random(n) < p).astype(np.uint8)

@@ -24,12 +24,21 @@ from . import params as P
 from .frame_codec import FixedVideoCompressor, VideoFrameCompressor, YUVFrame, frame_data
 
 KEY, INTER = 1, 2
+_POPCOUNT8 = np.unpackbits(np.arange(256, dtype=np.uint8)[:, None], axis=1).sum(axis=1).astype(np.uint8)   # numpy 1.x has no bitwise_count
 
 
 class ImprovedVideoCompressor:
     def __init__(self, noise_tolerance=10.0, keyframe_interval=30, min_diff_threshold=3.0,
                  max_diff_threshold=30.0, bloom_threshold_modifier=1.0, batch_size=30,
-                 num_threads=None, use_direct_yuv=False, verbose=False, ctx=None):
+                 num_threads=None, use_direct_yuv=False, verbose=False, ctx=None, inter_frames=None,
+                 gop_batching=True):
+        """Reference signature (improved_video_compressor.py:318-327) plus three keyword-only extras:
+        ctx (library context), gop_batching (False: one set of C-ABI calls per inter-frame instead of one
+        per GOP; both write the same bytes) and inter_frames -- None (default): YUV input is coded with
+        Bloom inter-frames ('BFV2' container, which the reference's decompress_video rejects), anything
+        else as keyframes; False: always the reference's all-keyframe 'BFVC' container, readable by the
+        reference; True: inter-frames for every colour space (lossless fallback to keyframes per frame)."""
+        self.inter_frames = inter_frames
         self.noise_tolerance = noise_tolerance
         self.keyframe_interval = max(1, int(keyframe_interval))
         self.min_diff_threshold = min_diff_threshold
@@ -37,13 +46,29 @@ class ImprovedVideoCompressor:
         self.bloom_threshold_modifier = bloom_threshold_modifier
         self.batch_size = batch_size
         self.num_threads = max(1, num_threads or min(32, os.cpu_count() or 1))     # zlib of keyframes / changed values
-        self.gop_batching = True                 # False: code every inter-frame with its own C-ABI calls
+        self.gop_batching = bool(gop_batching)
         self.use_direct_yuv = use_direct_yuv
         self.verbose = verbose
         self.compressor = FixedVideoCompressor(verbose=verbose)
         self._ctx = ctx
         self._inter = None
         self.last_compressed_frames = None       # [(type, record bytes)] of the last compress_video call
+        self._gop_coder, self._gop_key = None, None
+
+    def close(self):
+        """Return the device memory this compressor holds (the cached GOP coder and the inter-frame codec's
+        scratch).  Also happens when the object is dropped; the compressor stays usable afterwards."""
+        if self._gop_coder is not None:
+            self._gop_coder.close()
+        self._gop_coder, self._gop_key = None, None
+        if self._inter is not None:
+            self._inter.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     @property
     def inter(self):
@@ -58,7 +83,7 @@ class ImprovedVideoCompressor:
         a, b = frame_data(prev), frame_data(curr)
         if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (np.uint8, np.uint16):
             return None
-        if a.ndim == 3 and a.shape[2] < 3:
+        if a.ndim == 3 and (a.shape[2] < 3 or a.shape[2] > 4):
             return None
         mask, values, _ = self.inter._calculate_frame_diff(a, b, threshold=0.0)
         changed = (a != b)
@@ -85,10 +110,12 @@ class ImprovedVideoCompressor:
             return None
         H, W = a.shape[:2]
         C = a.shape[2] if a.ndim == 3 else 1
+        if C > 4:                                # rbf_gather_values_batch carries at most 4 samples per pixel
+            return [None] * (len(seg) - 1)
         ctx = self._ctx or nat.default_context()
         key = (W, H, len(seg), C, a.dtype.itemsize)
-        if getattr(self, "_gop_key", None) != key:
-            if getattr(self, "_gop_coder", None) is not None:
+        if self._gop_key != key:
+            if self._gop_coder is not None:
                 self._gop_coder.close()
             self._gop_coder, self._gop_key = GopCoder(ctx, W, H, len(seg), channels=C, sample_bytes=a.dtype.itemsize), key
         coder = self._gop_coder
@@ -104,10 +131,14 @@ class ImprovedVideoCompressor:
                 out.append(None)
                 continue
             p = np.uint64(r["ones"]) / n
-            k, _l = P.optimal_params(n, p)
             if r["l"]:
+                # the filter and the witness were built with the k rbf_plan_batch computed in C: the record
+                # carries THAT value (the decoder derives floor_k and T from it); the Python twin must agree
+                k = r["k"]
+                assert P.optimal_params(n, p)[0] == k, "host parameter math diverged (C %r vs Python %r)" % (k, P.optimal_params(n, p)[0])
                 parts = (r["l"], r["filter"].tobytes(), r["witness_bits"], r["witness"].tobytes())
             else:                                # the reference passes the mask itself through (:215-225)
+                k, _l = P.optimal_params(n, p)
                 parts = (n, r["mask"].tobytes(), 0, b"")
             vals = values[f]
 
@@ -153,6 +184,9 @@ class ImprovedVideoCompressor:
         return [records[u] for u in range(start, stop)]
 
     def compress_video(self, frames, output_path=None, input_color_space="BGR"):
+        """improved_video_compressor.py:358-450, same result dict.  Divergence: with inter-frames enabled
+        (see the constructor's `inter_frames`; the default for YUV input) the container is 'BFV2', which only
+        this package reads; `inter_frames=False` (or keyframe_interval=1) writes the reference's 'BFVC'."""
         if not frames:
             raise ValueError("No frames provided for compression")
         start = time.time()
@@ -163,7 +197,13 @@ class ImprovedVideoCompressor:
                 if not hasattr(frames[i], "yuv_info"):
                     frames[i] = self.compressor.add_yuv_info_to_frame(frames[i])
         original_size = sum(f.nbytes for f in frames)
-        records = self.encode_range(frames, 0, 0, len(frames), inter_frames=yuv)
+        use_inter = yuv if self.inter_frames is None else bool(self.inter_frames)
+        try:
+            records = self.encode_range(frames, 0, 0, len(frames), inter_frames=use_inter)
+        finally:
+            if self._gop_coder is not None:      # a GOP of frames, masks, filters and witnesses: do not keep it between videos
+                self._gop_coder.close()
+                self._gop_coder, self._gop_key = None, None
         self.last_compressed_frames = records
         keyframes = sum(1 for ty, _ in records if ty == KEY)
         blob = self._container(records)
@@ -277,7 +317,7 @@ class ImprovedVideoCompressor:
         masks = [d["mask"] if "mask" in d else d["bitmap"][:(n + 7) // 8] for d in parsed]
         ch = base_arr.shape[2] if base_arr.ndim == 3 else 1
         for i, (m, v) in enumerate(zip(masks, vals)):
-            ones = int(np.bitwise_count(np.asarray(m, dtype=np.uint8)[:(n + 7) // 8]).sum())
+            ones = int(_POPCOUNT8[np.asarray(m, dtype=np.uint8)[:(n + 7) // 8]].sum(dtype=np.int64))
             if len(v) != ones * ch:              # same rule as _apply_frame_diff (:886-903)
                 if ch == 1:
                     raise ValueError("changed_values does not match the mask")

@@ -149,3 +149,76 @@ def test_outbox_gather_gloo_world2(G, steps):
                     step = rnd * G + j
                     if step < steps:
                         assert firsts[j] == 1000 * step + 100000 * r, (rnd, r, j, firsts)
+
+
+def _fake_record(nframes, payload_words, tag):
+    """A block with the header rbf_pack_records writes (magic, frames, used bytes, overflow) + recognisable payload."""
+    from new_bloom_filter_repo_amd.dist import RECORD_MAGIC
+    used = 32 + 64 * nframes + 8 * payload_words
+    words = np.zeros(used // 8 + 5, dtype=np.uint64)         # slack after the used bytes must not travel
+    words[:4] = [RECORD_MAGIC, nframes, used, 0]
+    words[4 + 8 * nframes:used // 8] = tag + np.arange(payload_words, dtype=np.uint64)
+    words[used // 8:] = 0xDEAD
+    return words.view(np.int64)
+
+
+def _devrec_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    from new_bloom_filter_repo_amd import dist as DD
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 holds 2 records, rank 1 three of other sizes, (world 3: rank 2 none at all)
+        shapes = {0: [(2, 7), (1, 3)], 1: [(3, 11), (1, 1), (2, 40)], 2: []}[rank]
+        recs = [torch.from_numpy(_fake_record(nf, pw, 1000 * rank + 100 * i)) for i, (nf, pw) in enumerate(shapes)]
+        got = DD.gather_device_records(recs, torch.device("cpu"))
+        if rank == 0:
+            q.put([(int(g.numel()), g.numpy().view(np.uint64)[[1, 2]].tolist(), int(g.numpy().view(np.uint64)[-1])) for g in got])
+        else:
+            assert got is None
+            q.put(None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_device_records_gloo(world):
+    """Exact-size gather of device-packed records: lengths first, then one point-to-point message per peer;
+    rank 0's own records never travel; ranks may hold different record counts (or none)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() * 3 + world) % 2000
+    procs = [ctx.Process(target=_devrec_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = [o for o in outs if o is not None][0]
+    want = []
+    for rank, shapes in ((0, [(2, 7), (1, 3)]), (1, [(3, 11), (1, 1), (2, 40)])):
+        for i, (nf, pw) in enumerate(shapes):
+            used = 32 + 64 * nf + 8 * pw
+            want.append((used, [nf, used], 1000 * rank + 100 * i + pw - 1))
+    assert got == want
+
+
+def test_clip_pieces_cover_every_inter_frame():
+    """bench.py --clip-frames: the runs a rank codes, with their halo frame, tile the clip's inter-frames exactly."""
+    import bench
+    for T, I in ((300, 30), (301, 30), (61, 7), (30, 30), (5, 1)):
+        for world in (1, 2, 3, 8):
+            coded = []
+            for r in range(world):
+                a, b = D.shard_range(T, world, r)
+                first = D.halo_start(a, I)
+                for f0, cnt in bench.clip_pieces(a, b, I):
+                    assert f0 >= first and cnt >= 2 and f0 + cnt <= b       # a rank only reads its shard + halo
+                    assert all((t % I) != 0 for t in range(f0 + 1, f0 + cnt))
+                    coded += list(range(f0 + 1, f0 + cnt))
+            assert coded == [t for t in range(T) if t % I], (T, I, world)

@@ -1,0 +1,147 @@
+"""The launch shapes bench.py times, checked against the CPU oracle frame by frame (not HIP vs HIP):
+
+* BASELINE config 2: 1920x1080 YUV444 uint8 x 30-frame GOP through GopCoder.encode() (= rbf_encode_gop, default
+  kernels: 29-frame frames-inner query, (29 frames x 8 slices) LDS insert), FOUR contexts in flight on four
+  HIP streams sharing the resident frames -- every pipeline's 29 (mask, k, l, filter, witness, counts) against
+  oracle.residual_mask / orc_compress, then decoded back on the GPU.
+* BASELINE config 4: 3840x2160 x 9 frames (tiled kernels) the same way.
+* BASELINE config 5, single-GPU half: 1920x1080 uint16 x 30 frames, GOP record vs the oracle and the whole
+  ImprovedVideoCompressor round trip under verify_lossless / verify_bit_exact
+  (verify_true_lossless.py:241-249,338-492 semantics).
+"""
+import ctypes
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from new_bloom_filter_repo_amd import _native as nat
+from new_bloom_filter_repo_amd import params as P
+from new_bloom_filter_repo_amd.engine import BloomEngine
+from new_bloom_filter_repo_amd.gop import GopCoder
+from new_bloom_filter_repo_amd.synthetic import make_gop
+
+pytestmark = pytest.mark.gpu
+
+U8P = ctypes.POINTER(ctypes.c_uint8)
+
+
+def oracle_gop(oracle, frames, seeds=P.SEEDS_VIDEO):
+    """Per inter-frame: (mask bits, k, l, bit_array, witness) from the CPU oracle, frames spread over host threads."""
+    F = frames.shape[0]
+    n = frames.shape[1] * frames.shape[2]
+    L = oracle.lib()
+    sd = (ctypes.c_uint64 * 3)(*seeds)
+
+    def one(f):
+        mask = oracle.residual_mask(np.ascontiguousarray(frames[f][..., 0]), np.ascontiguousarray(frames[f + 1][..., 0]), 0.0).reshape(-1)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        ones = int(mask.sum())
+        p = np.uint64(ones) / n
+        k, l = oracle.optimal_params(n, p)
+        if p >= P.P_STAR or l == 0 or l >= n:
+            return mask, ones, 0.0, 0, None, None
+        bit_array = np.zeros(l, dtype=np.uint8)
+        witness = np.zeros(n, dtype=np.uint8)
+        w = L.orc_compress(mask.ctypes.data_as(U8P), n, l, ctypes.c_double(k), sd, bit_array.ctypes.data_as(U8P), witness.ctypes.data_as(U8P))
+        return mask, ones, k, l, bit_array, witness[:w].copy()
+    with ThreadPoolExecutor(min(F - 1, os.cpu_count() or 1)) as pool:
+        return list(pool.map(one, range(F - 1)))
+
+
+def check_records(res, want, n, tag):
+    assert len(res) == len(want)
+    for f, (r, (mask, ones, k, l, bit_array, witness)) in enumerate(zip(res, want)):
+        assert np.array_equal(np.unpackbits(r["mask"])[:n], mask), (tag, f, "mask")
+        assert r["ones"] == ones, (tag, f, "ones")
+        assert (r["k"], r["l"]) == (k, l), (tag, f, "geometry", r["k"], r["l"], k, l)
+        if l == 0:
+            assert r["witness_bits"] == 0, (tag, f)
+            continue
+        assert np.array_equal(np.unpackbits(r["filter"])[:l], bit_array), (tag, f, "filter")
+        assert r["filter_ones"] == int(bit_array.sum()), (tag, f, "filter popcount")
+        assert r["witness_bits"] == len(witness), (tag, f, "witness length", r["witness_bits"], len(witness))
+        assert np.array_equal(np.unpackbits(r["witness"])[:len(witness)], witness), (tag, f, "witness")
+
+
+def decode_back(ctx, res, n, tag):
+    eng = BloomEngine(ctx)
+    coded = [r for r in res if r["l"]]
+    dec = eng.decode(n, [(r["l"], r["floor_k"], r["threshold"]) for r in coded], [r["filter"] for r in coded], [r["witness"] for r in coded])
+    for i, r in enumerate(coded):
+        assert np.array_equal(dec[i][:(n + 7) // 8], r["mask"]), (tag, i, "decode")
+    eng.close()
+
+
+def test_config2_1080p_gop_four_pipelines_vs_oracle(oracle):
+    import torch
+    W, H, F = 1920, 1080, 30
+    n = W * H
+    frames = np.stack(make_gop(2000, W, H, F))
+    want = oracle_gop(oracle, frames)
+    device = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device) for _ in range(4)]
+    ctxs = [nat.Context(0, s.cuda_stream) for s in streams]
+    coders = []
+    for c in ctxs:
+        coders.append(GopCoder(c, W, H, F, channels=3, sample_bytes=1, frames_block=coders[0].frames if coders else None))
+    coders[0].load_frames(frames)
+    ctxs[0].sync()
+    for rep in range(3):                                     # the bench's rotation: all four pipelines overlap on the GPU
+        for k in range(4):
+            with torch.cuda.stream(streams[k]):
+                coders[k].encode()
+    torch.cuda.synchronize(device)
+    for k in range(4):
+        res = coders[k].results()
+        check_records(res, want, n, "pipeline %d" % k)
+        if k == 0:
+            decode_back(ctxs[0], res, n, "pipeline 0")
+    for c in coders:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_config4_2160p_gop_vs_oracle(oracle):
+    W, H, F = 3840, 2160, 9
+    n = W * H
+    frames = np.stack(make_gop(4000, W, H, F))
+    want = oracle_gop(oracle, frames)
+    with nat.Context(0) as ctx:
+        coder = GopCoder(ctx, W, H, F, channels=3, sample_bytes=1)
+        coder.load_frames(frames)
+        coder.encode()
+        res = coder.results()
+        check_records(res, want, n, "2160p")
+        decode_back(ctx, res, n, "2160p")
+        coder.close()
+
+
+def test_config5_1080p_uint16_gop_and_surface_round_trip(oracle):
+    from new_bloom_filter_repo_amd import ImprovedVideoCompressor
+    from new_bloom_filter_repo_amd.verify import verify_bit_exact
+    W, H, F = 1920, 1080, 30
+    n = W * H
+    frames = np.stack(make_gop(5000, W, H, F, dtype=np.uint16))
+    want = oracle_gop(oracle, frames)
+    with nat.Context(0) as ctx:
+        coder = GopCoder(ctx, W, H, F, channels=3, sample_bytes=2)
+        coder.load_frames(frames)
+        coder.encode()
+        res = coder.results()
+        check_records(res, want, n, "uint16")
+        decode_back(ctx, res, n, "uint16")
+        coder.close()
+        # the product surface on the same clip: keyframe every 30 -> 1 keyframe + 29 Bloom inter-frames
+        comp = ImprovedVideoCompressor(noise_tolerance=0, min_diff_threshold=0, max_diff_threshold=10, keyframe_interval=30, ctx=ctx)
+        originals = [f.copy() for f in frames]
+        out = comp.compress_video([f for f in frames], None, input_color_space="YUV")
+        assert out["frame_count"] == F and out["keyframes"] == 1
+        decoded = comp.decompress_video(compressed_frames=comp.last_compressed_frames)
+        v = comp.verify_lossless(originals, decoded)
+        assert v["lossless"] and v["exact_frame_matches"] == F, v
+        b = verify_bit_exact(originals, decoded, color_space="YUV")
+        assert b["success"] and b["exact_matches"] == F and b["different_frames"] == 0, b
+        comp.close()

@@ -1,0 +1,113 @@
+"""RCCL (backend "nccl") inside the GPU test tier, at world size 1 (the GPU boxes have one device): the same
+calls the N > 1 path makes -- OutboxGather (fixed-slot batched gather), gather_records (length-exchanging
+container gather) and gather_device_records (exact-size point-to-point gather) -- run over RCCL on records the
+GPU packed, and what rank 0 holds afterwards is parsed and compared with the coder's own rows.  Also runs
+bench.py's two multi-GPU modes end to end with --force-dist."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(repo)r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", %(port)r)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+device = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+dist.barrier()
+from new_bloom_filter_repo_amd import _native as nat, dist as D
+from new_bloom_filter_repo_amd.gop import GopCoder, torch_allocator
+from new_bloom_filter_repo_amd.synthetic import make_gop
+W, H, F = 320, 180, 6
+n = W * H
+stream = torch.cuda.Stream(device)
+ctx = nat.Context(0, stream.cuda_stream)
+coder = GopCoder(ctx, W, H, F, allocator=torch_allocator(device))
+coder.load_frames(np.stack(make_gop(77, W, H, F, p=0.07)))
+slot_words = (int(nat.lib().rbf_record_max_bytes(F - 1, n)) + 255) // 256 * 256 // 8
+og = D.OutboxGather(slot_words, 2, device, streams=[stream])
+
+class Slot:
+    def __init__(self, t): self.ptr, self.nbytes = t.data_ptr(), t.numel() * 8
+for s in range(5):                                 # 2 full outboxes + a partly filled one
+    with torch.cuda.stream(stream):
+        t = og.begin(0)
+        coder.encode()
+        coder.pack(Slot(t))
+        og.end(0)
+og.flush()
+torch.cuda.synchronize()
+rows = coder.results()
+checked = 0
+for ob in range(2):
+    for j in range(2):
+        rec = og.received(ob, 0)[j]
+        if int(rec[0].item()) == 0:
+            continue
+        for got, want in zip(D.unpack_device_record(rec.view(torch.uint8), n), rows):
+            assert got["l"] == want["l"] and got["witness_bits"] == want["witness_bits"]
+            assert np.array_equal(got["witness"], want["witness"])
+            if want["l"]:
+                assert np.array_equal(got["filter"], want["filter"])
+            checked += 1
+# exact-size device gather
+blk = coder.pack()
+torch.cuda.synchronize()
+got = D.gather_device_records([blk.tensor], device)
+used = D.record_used_bytes(got[0][:32].cpu().numpy())
+assert len(got) == 1 and got[0].numel() == (used + 7) // 8 * 8
+for a, want in zip(D.unpack_device_record(got[0], n), rows):
+    assert np.array_equal(a["witness"], want["witness"])
+# container-record gather
+recs = [(t, 2, bytes(rows[t]["witness"])) for t in range(F - 1)]
+merged = D.gather_records(recs, device=device)
+assert [(t, ty) for t, ty, _ in merged] == [(t, 2) for t in range(F - 1)] and all(b == recs[i][2] for i, (_, _, b) in enumerate(merged))
+print(json.dumps({"slots_checked": checked, "sent": og.sent}))
+dist.destroy_process_group()
+'''
+
+
+def run(cmd, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=REPO)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    return p.stdout
+
+
+def test_rccl_world1_gathers_records_the_gpu_packed():
+    port = str(36000 + os.getpid() % 2000)
+    out = run([sys.executable, "-c", WORKER % {"repo": REPO, "port": port}])
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["sent"] == 3 and res["slots_checked"] >= 3 * 5
+
+
+def test_bench_force_dist_weak_mode():
+    os.environ["MASTER_PORT"] = str(38000 + os.getpid() % 2000)
+    out = run([sys.executable, "bench.py", "--force-dist", "--steps", "12", "--warmup", "2", "--width", "640", "--height", "360", "--frames", "8",
+               "--gather-every", "4", "--no-cpu-baseline", "--exact-steps"], timeout=900)
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["config"]["gather_to_rank0"] and res["verified_vs_oracle"]["frames"] == 7 * 4 and res["value"] > 0
+
+
+def test_bench_clip_mode_strong_scaling_world1():
+    os.environ["MASTER_PORT"] = str(40000 + os.getpid() % 2000)
+    out = run([sys.executable, "bench.py", "--force-dist", "--clip-frames", "40", "--keyframe-interval", "10", "--steps", "2", "--warmup", "1",
+               "--width", "640", "--height", "360"], timeout=900)
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["scaling"] == "strong" and res["verified_vs_oracle"]["frames"] == 36 == res["verified_vs_oracle"]["of"]
+    assert res["verified_vs_oracle"]["records_parsed_on_rank0"] == 36
+    out = run([sys.executable, "bench.py", "--clip-frames", "21", "--keyframe-interval", "10", "--steps", "2", "--warmup", "1",
+               "--width", "640", "--height", "360", "--bits", "16"], timeout=900)
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["verified_vs_oracle"]["frames"] == 18
