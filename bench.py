@@ -286,7 +286,7 @@ def main():
     if short:
         out["requested_region"] = short           # the exactly---steps region, too short to be the headline
     if rank == 0 and gather:
-        check_gathered(og, world, G, pairs, n, res)
+        check_gathered(og, world, G, pairs, n, res_all)
     if rank == 0:
         l_sum = sum(r["l"] for r in res)
         w_sum = sum(r["witness_bits"] for r in res)
@@ -323,15 +323,16 @@ def main():
             out["verified_vs_oracle"] = verify_all(host_gops, res_all, n, ncoders if not args.shared_gop else 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, n, args.cpu_frames)
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)        # the last thing on stdout (RCCL prints its own lines while it is alive)
 
 
-def check_gathered(og, world, G, pairs, n, res):
+def check_gathered(og, world, G, pairs, n, res_all):
     """What arrived on rank 0 is complete: every slot of every rank has the right magic and frame count, no
-    overflow flag, a size that fits the slot; rank 0's own record matches its rows."""
+    overflow flag, a size that fits the slot; rank 0's own slot holds the rows of one of its pipelines."""
     from new_bloom_filter_repo_amd.dist import RECORD_MAGIC, unpack_device_record
     sw = og.slot_words
     for ob in range(2):
@@ -341,9 +342,13 @@ def check_gathered(og, world, G, pairs, n, res):
                 h = heads[j]
                 if int(h[0]) != RECORD_MAGIC or int(h[1]) != pairs or int(h[3]) != 0 or int(h[2]) > sw * 8:
                     raise SystemExit("gathered record of rank %d (outbox %d slot %d) is damaged: %s" % (r, ob, j, h.tolist()))
-    mine = og.received(0, 0)[0].cpu().numpy().view(np.uint8)
-    for got, want in zip(unpack_device_record(mine, n), res):
-        assert got["witness_bits"] == want["witness_bits"] and np.array_equal(got["witness"], want["witness"]), "gathered record differs"
+    mine = unpack_device_record(og.received(0, 0)[0].cpu().numpy().view(np.uint8), n)
+
+    def same(rows):
+        return all(g["l"] == w["l"] and g["witness_bits"] == w["witness_bits"] and np.array_equal(g["witness"], w["witness"])
+                   and (not w["l"] or np.array_equal(g["filter"], w["filter"])) for g, w in zip(mine, rows))
+    if not any(same(rows) for rows in res_all):
+        raise SystemExit("the record rank 0 gathered from itself matches none of its pipelines' rows")
 
 
 def issue_roofline(W, H, F, bits, breakdown):
@@ -589,10 +594,11 @@ def clip_main(args):
                           "gather_to_rank0": bool(use_gather), "gather": "exact-size: all_gather of lengths, then grouped send/recv of payloads; rank 0's own records are not sent",
                           "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only)"},
                "verified_vs_oracle": verified}
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

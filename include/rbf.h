@@ -106,7 +106,8 @@ int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes); 
 int rbf_timing_enable(rbf_ctx *ctx, int on);
 /* Testing knob (bit mask): bit 0 = always use the generic (global-memory filter) kernels;
  * bit 1 = LDS fast path without double-buffering the filter; bit 2 = per-pixel threshold compare in the
- * GOP mask kernel even for threshold 0.  0 (default) = pick the fastest
+ * GOP mask kernel even for threshold 0; bit 3 = Barrett reductions only (never the FP64 h mod m of the query
+ * kernel, which is taken when every filter of a batch has 2^15 <= m < 2^23).  0 (default) = pick the fastest
  * variant that fits: the LDS-resident path needs the batch's largest filter to fit in LDS. */
 int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
 int rbf_timing_reset(rbf_ctx *ctx);

@@ -1,7 +1,7 @@
 // rbf_api.hip -- C ABI (include/rbf.h) over the gfx950 kernels.  Host side: argument checks,
 // scratch management, launches on the context's single HIP stream, optional per-kernel timing.
 #include "../../include/rbf.h"
-#include "rbf_kernels_lds.h"
+#include "rbf_kernels_q64.h"
 #include "rbf_kernels_noise.h"
 #include "rbf_kernels_pack.h"
 
@@ -49,12 +49,14 @@ struct rbf_ctx {
     uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
     uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
     uint32_t *partials = nullptr;    size_t partials_cap = 0;
+    uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
     int32_t *thr_tab = nullptr;      size_t thr_tab_cap = 0;      // per-pair thresholds of the mask kernels
     uint64_t *pack_base = nullptr;   size_t pack_base_cap = 0;    // running record size between pack chunks
     int force_generic = 0;           // tests: 1 = never use the LDS fast path
     int single_buffer = 0;           // tests: 1 = fast query path without filter double-buffering
     uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
     int force_generic_mask_bits = 0; // tests: 1 = per-pixel threshold compare even for threshold 0
+    int barrett_only = 0;            // tests/tuning: 1 = never take the FP64 reductions (mod_m_f64)
     uint32_t tile_words = 0;         // tests/tuning: cap the LDS filter tile (dwords); forces the tiled kernels
     // host staging of encode_gop: device-visible pinned block [flag | ones...] the GPU publishes into
     uint64_t *ones_pinned = nullptr; size_t host_cap = 0;
@@ -177,6 +179,7 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (ctx->seg_off) (void)hipFree(ctx->seg_off);
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->qimage) (void)hipFree(ctx->qimage);
     if (ctx->thr_tab) (void)hipFree(ctx->thr_tab);
     if (ctx->pack_base) (void)hipFree(ctx->pack_base);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -254,6 +257,7 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->force_generic = (on & 1) ? 1 : 0;
     ctx->single_buffer = (on & 2) ? 1 : 0;
     ctx->force_generic_mask_bits = (on & 4) ? 1 : 0;
+    ctx->barrett_only = (on & 8) ? 1 : 0;
     ctx->mask_chunks = (uint32_t)(on >> 8) & 0xFF;           // tuning knob, bits 8..15
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
     return RBF_OK;
@@ -379,11 +383,13 @@ struct Plan {
     bool fast_insert;            // LDS partial-filter insert (any filter size, tiled when needed)
     int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles
     bool double_buffer, small_m;
+    bool f64_mod;                // every coded frame has F64MOD_M_MIN <= m <= F64MOD_M_MAX: reductions through the FP64 pipe
     uint32_t fwords_max, S /* slices of a coded frame */, per_tile /* sum of slices */, insert_group /* coded frames per insert launch */;
     SliceTable slices;
     uint32_t insert_tile_words, insert_tiles, query_tile_words;
     size_t insert_lds_bytes, query_lds_bytes;
     uint64_t nseg; uint32_t words_per_seg;
+    uint32_t image_stride_words;  // row pitch of the probe image (dwords, multiple of 4)
 };
 
 constexpr uint32_t MAX_INSERT_TILES = 7, MAX_QUERY_TILES = 3;     // measured crossovers, see make_plan
@@ -393,10 +399,12 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     Plan p{};
     uint32_t mmax = 0, active = 0;
     p.small_m = true;
+    p.f64_mod = !ctx->barrett_only;
     for (uint32_t f = 0; f < nframes; ++f) {
         if (params[f].m > mmax) mmax = params[f].m;
         if (params[f].m) ++active;
         if (params[f].m == 1 || params[f].m > (1u << 30)) p.small_m = false;
+        if (params[f].m && (params[f].m < F64MOD_M_MIN || params[f].m > F64MOD_M_MAX)) p.f64_mod = false;
     }
     p.fwords_max = (uint32_t)(((uint64_t)mmax + 31) / 32);
     const size_t fbytes = (size_t)((p.fwords_max + 3u) & ~3u) * 4;
@@ -417,12 +425,15 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     const bool auto_tiles = ctx->tile_words == 0;
     p.fast_insert = !ctx->force_generic && mmax > 0 && !(auto_tiles && p.insert_tiles > MAX_INSERT_TILES);
     // query
-    p.double_buffer = 2 * fbytes <= LDS_LIMIT && !ctx->single_buffer;
+    // k_query_f64 (FP64 reductions, probe image) is double-buffered only; its buffers end with the SAFE dwords
+    if (2 * (fbytes + 16) > LDS_LIMIT || ctx->single_buffer) p.f64_mod = false;
+    const size_t qbytes = fbytes + (p.f64_mod ? 16 : 0);
+    p.double_buffer = 2 * qbytes <= LDS_LIMIT && !ctx->single_buffer;
     p.query_kind = 0;
     if (!ctx->force_generic && mmax > 0) {
-        if (fbytes <= LDS_LIMIT && !ctx->tile_words) {
+        if (qbytes <= LDS_LIMIT && !ctx->tile_words) {
             p.query_kind = 1;
-            p.query_lds_bytes = (p.double_buffer ? 2 : 1) * fbytes;
+            p.query_lds_bytes = (p.double_buffer ? 2 : 1) * qbytes;
         } else {
             p.query_kind = 2;
             p.query_tile_words = (uint32_t)(LDS_LIMIT / 4);
@@ -453,6 +464,8 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
         p.slices.n[f] = (uint8_t)sf;
         p.per_tile += sf;
     }
+    if (p.query_kind != 1) p.f64_mod = false;                     // only the whole-filter LDS query kernel has the FP64 form
+    p.image_stride_words = (p.fwords_max + 3u) & ~3u;
     const uint32_t segpx = p.query_kind == 1 ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
     p.nseg = (n + segpx - 1) / segpx;
     p.words_per_seg = segpx / 64;
@@ -576,10 +589,38 @@ static int check_filter_strides(const rbf_filter_params *params, uint32_t nframe
 }
 
 // query launch shared by encode and decode
-static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nframes, const FrameTable &tab, const Seeds &sd,
-                        const void *filters_dev, uint64_t filter_stride_bytes)
+static int ensure_image(rbf_ctx *ctx, const Plan &pl, uint32_t nframes)
 {
-    if (pl.query_kind == 1) {
+    return grow((void **)&ctx->qimage, &ctx->qimage_cap, (size_t)nframes * pl.image_stride_words * 4);
+}
+
+// image_ready: the probe image of this batch has already been written (k_filter_reduce does it on the encode side)
+static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nframes, const FrameTable &tab, const Seeds &sd,
+                        const void *filters_dev, uint64_t filter_stride_bytes, bool image_ready)
+{
+    if (pl.query_kind == 1 && pl.f64_mod) {
+        if (int r = ensure_image(ctx, pl, nframes)) return r;
+        if (!image_ready) {
+            uint32_t bx = (pl.image_stride_words + WG_THREADS - 1) / WG_THREADS;
+            hipLaunchKernelGGL(k_probe_image, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream, (const uint32_t *)filters_dev,
+                               filter_stride_bytes / 4, ctx->qimage, (uint64_t)pl.image_stride_words);
+        }
+        filters_dev = ctx->qimage;
+        filter_stride_bytes = (uint64_t)pl.image_stride_words * 4;
+    }
+    if (pl.query_kind == 1 && pl.f64_mod) {
+        // k_query_f64 reads -1/m (IEEE double, computed here on the host) from the table's M field instead of the Barrett constant
+        FrameTable qtab = tab;
+        for (uint32_t f = 0; f < nframes; ++f)
+            if (qtab.f[f].m) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
+        auto kern = k_query_f64<0>;
+        if (int r = allow_big_lds((const void *)kern)) return r;
+        const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
+                           n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+                           ctx->seg_cnt, pl.nseg, ctx->pass_words);
+    } else if (pl.query_kind == 1) {
         auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<true, true> : k_query_lds<true, false>)
                                      : (pl.small_m ? k_query_lds<false, true> : k_query_lds<false, false>);
         if (int r = allow_big_lds((const void *)kern)) return r;
@@ -620,6 +661,9 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
+    const bool want_image = pl.query_kind == 1 && pl.f64_mod;       // the reduce kernel also writes the FP64 query kernel's probe image
+    if (want_image) if (int r = ensure_image(ctx, pl, nframes)) return r;
+    uint32_t *image = want_image ? ctx->qimage : nullptr;
 
     if (!outputs_zeroed) {
         HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)nframes * witness_stride_bytes, ctx->stream));
@@ -653,7 +697,8 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
             uint32_t bx = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx < 1) bx = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)ctx->partials, part_stride, pl.S, pl.slices, tab, (uint32_t *)filters_dev, words, stats_dev, vec_ok);
+                               (const uint32_t *)ctx->partials, part_stride, pl.S, pl.slices, tab, (uint32_t *)filters_dev, words, stats_dev, vec_ok,
+                               image, (uint64_t)pl.image_stride_words);
         }
     } else {
         HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
@@ -674,11 +719,12 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
             uint32_t bx2 = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx2 < 1) bx2 = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx2, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                               (const uint32_t *)filters_dev, words, 1u, ones, tab, (uint32_t *)filters_dev, words, stats_dev, 0u);
+                               (const uint32_t *)filters_dev, words, 1u, ones, tab, (uint32_t *)filters_dev, words, stats_dev, 0u,
+                               image, (uint64_t)pl.image_stride_words);
         }
     }
     // ---- query: pass word of every 64 positions + per-segment pass counts
-    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes)) return r;
+    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, want_image)) return r;
     // ---- witness: pext(mask, pass) of every word lands at its bit offset (scan fused in)
     {
         const uint64_t words = pl.nseg * pl.words_per_seg;
@@ -913,7 +959,7 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * wps * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
-    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes)) return r;
+    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, false)) return r;
     {
         LaunchTimer t(ctx, RBF_K_SCAN);
         hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, pl.nseg,

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
     const SliceTable slices /* partial filters per frame */,
     const FrameTable tab,
     uint32_t *filters /* may alias partials when Smax == 1 */, uint64_t filter_stride_words32,
-    uint64_t *__restrict__ stats, uint32_t vec_ok)
+    uint64_t *__restrict__ stats, uint32_t vec_ok,
+    uint32_t *__restrict__ image /* nullable: probe image rows (~bswap of every dword) for the FP64 query kernel */, uint64_t image_stride_words32)
 {
     __shared__ uint32_t red[WG_WAVES];
     const uint32_t f = blockIdx.y;
@@ -192,6 +193,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
                 if (w + 3 >= fwords) v.w = 0;
             }
             if (m) *reinterpret_cast<uint4 *>(filt + w) = v;     // passthrough frames: filter untouched
+            if (image && w < image_stride_words32)
+                *reinterpret_cast<uint4 *>(image + (uint64_t)f * image_stride_words32 + w) =
+                    make_uint4(~__builtin_bswap32(v.x), ~__builtin_bswap32(v.y), ~__builtin_bswap32(v.z), ~__builtin_bswap32(v.w));
             pc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
         }
     } else {
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
             if (w < fwords)
                 for (uint32_t s = 0; s < S; ++s) v |= part[(uint64_t)s * part_stride_words32 + w];
             if (m) filt[w] = v;
+            if (image && w < image_stride_words32) image[(uint64_t)f * image_stride_words32 + w] = ~__builtin_bswap32(v);
             pc += __popc(v);
         }
     }
@@ -212,6 +217,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
         for (int k = 0; k < WG_WAVES; ++k) t += red[k];
         if (t) atomicAdd((unsigned long long *)&stats[(uint64_t)f * 4 + 1], (unsigned long long)t);
     }
+}
+
+// Probe image of caller-supplied packed filters (decode): image[f][w] = ~bswap(filters[f][w]).
+__global__ __launch_bounds__(WG_THREADS) void k_probe_image(const uint32_t *__restrict__ filters, uint64_t filter_stride_words32,
+                                                            uint32_t *__restrict__ image, uint64_t image_stride_words32)
+{
+    const uint32_t f = blockIdx.y;
+    for (uint64_t w = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x; w < image_stride_words32; w += (uint64_t)gridDim.x * WG_THREADS)
+        image[(uint64_t)f * image_stride_words32 + w] = w < filter_stride_words32 ? ~__builtin_bswap32(filters[(uint64_t)f * filter_stride_words32 + w]) : ~0u;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,293 @@
+// rbf_kernels_q64.h -- k_query_f64: the frames-inner query kernel for filters of 2^15 <= m < 2^23 bits that fit
+// LDS twice (1080p-class frames: BASELINE config 2).  Same outputs as k_query_lds (pass bytes in numpy.packbits
+// order + per-segment pass counts; reference semantics improved_video_compressor.py:116-138, :245-253), rebuilt
+// around what the round-2 measurements showed (profiles/r02_opbench.txt, profiles/r02_query_timeline.txt):
+//
+//  * VALU cost on gfx950 is per opcode CLASS, not per instruction: v_add / v_sub / v_and / v_or / v_xor with VGPR or
+//    inline-constant operands issue in ~1.2 cycles per wave; shifts, min, bfe, mad, cndmask, alignbit, fma (f32 and
+//    f64 alike) and ANY opcode with an SGPR source in ~3.2; compares in ~4.  32-bit multiplies are not special.
+//    => h mod m goes through ONE v_fma_f64 + ONE v_mad_u32_u24 (mod_m_f64) instead of four multiplies + fix-ups, the
+//       wave-uniform m / LDS base live in VGPRs, and probes test a PROBE IMAGE (~bswap of the packed filter) so a
+//       probe is shift / and / add + ds_read + one v_lshl_or.
+//  * Timeline stamps inside the frame loop (tools/bench_query.hip, profiles/r02_query_timeline.txt): staging a 76 KB
+//    filter costs the CU ~1 200 cycles whichever way it is issued (tools/dmabench.hip: LDS-DMA and global_load +
+//    ds_write both land 76 KB in 1 150 - 1 550 cycles, ~50 B/clk/CU; one wave alone needs 160 cycles per 1 KiB
+//    instruction), and that time ADDS to the frame passes instead of hiding under them: 86 us without the DMA,
+//    101 us with it.  Variants measured and NOT kept because they changed nothing or lost: issuing the DMA share of
+//    wave group g in front of pixel part g (PARTS = 2 / 4: 100 - 108 us vs 101), storing the verdicts one barrier
+//    late (+7 us), counting passes with popc + a wave reduction instead of ballots (+4 us).
+//  * The next frame's geometry (scalar loads; -1/m comes from the host in FrameDev::M) is fetched one frame ahead.
+#pragma once
+#include "rbf_kernels_lds.h"
+
+namespace rbf {
+
+// ---- h mod m through the FP64 pipe (2^15 <= m < 2^23) --------------------------------------------------------
+// With hd = RN(h) as a double (frame-independent, computed once per pixel next to the hash) and ninv = -1/m:
+//     t = fma(hd, ninv, 1.5 * 2^52)  ->  t = 1.5 * 2^52 - q_est,  q_est = RN(h/m + d),  |d| <= 1.5 * 2^-52 * h/m < 2^-2
+// (h/m < 2^49 because m >= 2^15; t lies in [2^52, 2^53), where doubles are integers), so q_est is floor(h/m) or
+// floor(h/m) + 1 and r_est = h - q_est * m lies in [-0.75 m, 0.75 m].  The low dword of t's mantissa is -q_est mod 2^32;
+// only r_est mod 2^24 is needed (|r_est| < 2^23 as m < 2^23), and that depends only on the low 24 bits of q_est, m
+// and h: ONE v_mad_u32_u24 computes (-q_est * m + h_lo) mod 2^24, v_bfe_i32 sign-extends it, and one add +
+// unsigned min folds a negative r_est back into [0, m).  Exactness is checked against integer arithmetic on the host
+// (tests/c/mod_f64_check.c restates these five steps in C) and by the GPU parity tests.
+// `m` arrives in a VGPR on purpose (vgpr_copy): see the opcode classes above.
+__device__ __forceinline__ uint32_t mod_m_f64(double hd, uint32_t hl, double ninv, uint32_t m)
+{
+    const double t = __builtin_fma(hd, ninv, 0x1.8p52);
+    const uint32_t nq = (uint32_t)__builtin_bit_cast(uint64_t, t);
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(nq), "v"(m), "v"(hl));     // the compiler would pick v_mad_u64_u32 (it sees only 24 demanded bits)
+    const uint32_t rs = (uint32_t)(((int32_t)(r << 8)) >> 8);                     // v_bfe_i32 r, 0, 24
+    return min(rs, rs + m);
+}
+constexpr uint32_t F64MOD_M_MIN = 1u << 15, F64MOD_M_MAX = (1u << 23) - 1u;      // eligible filter sizes (host: make_plan)
+
+__device__ __forceinline__ uint32_t vgpr_copy(uint32_t uniform)
+{
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));                    // volatile: must not be folded back into an SGPR operand
+    return v;
+}
+
+// The kernel probes a PROBE IMAGE of the filter: dword w of the image is ~bswap(packed dword w), i.e. stream bit i of
+// the dword sits at bit 31 - i, inverted.  A probe is then
+//     fail = (image[pos >> 5] << (pos & 31)) | fail          (v_lshl_or_b32: the shifter takes pos's low 5 bits itself)
+// and the sign bit of `fail` says "some probed filter bit is 0" -- no xor for the MSB-first bit order, no and-tree.
+// The image is written by k_filter_reduce next to the packed filter (encode) or by k_probe_image (decode).
+// The activated extra probe is made unconditional by steering the non-activated pixels to SAFE, a dword past the
+// filter that the kernel keeps 0 in both LDS buffers ("bit set"): one v_cndmask instead of a masked merge.
+template <int AB = 0>
+__device__ __forceinline__ uint32_t probe_image_word(uint32_t lds_base_bytes /* in a VGPR */, uint32_t pos)
+{
+    uint32_t addr;
+    if (!(AB & 8192)) {                                          // two instructions: v_lshrrev_b32 + v_lshl_add_u32
+        uint32_t w;
+        asm("v_lshrrev_b32 %0, 5, %1" : "=v"(w) : "v"(pos));     // opaque, or the compiler rewrites it as shift / and / add
+        addr = (w << 2) + lds_base_bytes;
+    } else
+        addr = ((pos >> 3) & ~3u) + lds_base_bytes;
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
+}
+
+// Pixels [IT0, IT1) of one frame's pass over a lane's QL_P pixels.  pbf accumulates the lane's FAIL bits MSB-first
+// (after all parts: bit 7-j = pixel j failed), npass the wave's number of passing positions.  CHECK_VALID: lanes may
+// own positions past the end of the frame (validmask), which must fail; the common whole-wave case skips that.
+// AB (ablation mask, tools/bench_query.hip only; 0 in the library): 1 = no reductions, 2 = no LDS probes, 4 = no ballot.
+template <int FK, int AB, bool CHECK_VALID, int IT0, int IT1>
+__device__ __forceinline__ void frame_part_f64(
+    const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
+    const uint64_t (&ha)[QL_P], uint32_t validmask, uint32_t lds_base_bytes, uint32_t safe_pos, uint32_t m, double ninv, uint64_t T,
+    uint32_t fk_rt, uint32_t &pbf, uint32_t &npass)
+{
+    const uint32_t fk = FK >= 0 ? (uint32_t)FK : fk_rt;
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        uint32_t pos, step;
+        if (AB & 1) { pos = hl1[it] & 0x7FFFFu; step = hl2[it] & 0x3FFFFu; }
+        else { pos = mod_m_f64(hd1[it], hl1[it], ninv, m); step = mod_m_f64(hd2[it], hl2[it], ninv, m); }
+        uint32_t fail = CHECK_VALID ? ~(validmask << (31 - it)) & 0x80000000u : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < fk; ++j) {
+            const uint32_t w = (AB & 2) ? (pos * 0x9E3779B1u) : probe_image_word<AB>(lds_base_bytes, pos);
+            fail = (w << (pos & 31u)) | fail;
+            const uint32_t s2 = pos + step;
+            pos = min(s2, s2 - m);
+        }
+        const uint32_t pc = (ha[it] < T) ? pos : safe_pos;
+        const uint32_t w = (AB & 2) ? (pc * 0x85EBCA77u) : probe_image_word<AB>(lds_base_bytes, pc);
+        fail = (w << (pc & 31u)) | fail;
+        pbf = __builtin_amdgcn_alignbit(pbf, fail, 31);           // (pbf << 1) | (fail >> 31)
+        if (!(AB & 4) && !(AB & 16384)) npass += __popcll(__ballot((int32_t)fail >= 0));
+    }
+}
+
+// Timeline probe (tools/bench_query.hip only, AB & 1024): wave 0 and the last wave of the first workgroups record the
+// shader clock at the phases of every frame iteration into this buffer ([wg][wave 0 / last][frame][phase]).
+__device__ uint64_t *g_query_timeline = nullptr;
+constexpr uint32_t TL_WGS = 4, TL_PHASES = 6;
+
+constexpr int Q64_PARTS = 1;                       // DMA issue points per frame = wave groups (1: every wave right after the barrier)
+
+// Per-frame scalars, prepared one frame ahead.
+struct Q64Frame {
+    uint32_t m, fk, fwords, f;
+    uint32_t Thi, Tlo, ninv_lo, ninv_hi;
+};
+
+// AB bits also understood here: 8 = no filter DMA, 32 = no barrier / DMA wait (wrong results), 64 = no output,
+// 2048 = store the verdicts one barrier late, 4096 = every wave issues its DMA right after the barrier (= PARTS 1),
+// 8192 = three-instruction probe address (shift, and, add), 16384 = pass count by popc + wave reduction.
+template <int AB = 0, int PARTS = Q64_PARTS>
+__global__ __launch_bounds__(QL_THREADS) void k_query_f64(
+    uint64_t n, uint32_t nframes, const FrameTable tab, Seeds seeds,
+    const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t fwords_max,
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // two buffers; each ends with 4 dwords that no DMA touches, the first of which stays 0 (SAFE)
+    const uint32_t bufwords = ((fwords_max + 3u) & ~3u) + 4u;
+    const uint32_t safe_pos = ((fwords_max + 3u) & ~3u) << 5;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    const bool live = seg < nseg;
+    const uint64_t base = seg * QL_SEG_PIXELS;
+    if (threadIdx.x < 8u) lds[(threadIdx.x >> 2) * bufwords + (bufwords - 4u) + (threadIdx.x & 3u)] = 0u;   // visible after the first barrier
+
+    // ---- frame-independent part: the three hashes of my 8 consecutive pixel indices, as (double, low dword) ------
+    static_assert(QL_P == 8, "a lane's verdicts fill one byte; hash3_run8 hashes runs of 8");
+    double hd1[QL_P], hd2[QL_P];
+    uint32_t hl1[QL_P], hl2[QL_P];
+    uint64_t ha[QL_P];
+    uint32_t validmask = 0;
+    const uint64_t i0 = base + (uint64_t)lane * QL_P;
+    {
+        uint64_t h1[QL_P], h2[QL_P];
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
+            if (live && i0 + it < n) validmask |= 1u << it;
+        }
+        if (AB & 16) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) { h1[it] = (i0 + it) * P1; h2[it] = (i0 + it) * P2 + seeds.h2; ha[it] = (i0 + it) * P3; }
+        } else if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) {                  // mixed key lengths in this wave: index by index
+                const bool act = (validmask >> it) & 1u;
+                const Hash3 h = hash3_index((uint32_t)(i0 + it), act, seeds);
+                h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            hd1[it] = (double)h1[it]; hl1[it] = (uint32_t)h1[it];
+            hd2[it] = (double)h2[it]; hl2[it] = (uint32_t)h2[it];
+        }
+    }
+    const bool whole_wave = __builtin_amdgcn_readfirstlane((uint32_t)__all(validmask == 0xFFu)) != 0u;   // every lane owns 8 positions inside the frame
+    uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
+
+    // passthrough frames (m == 0): nothing passes
+    for (uint32_t g = 0; g < nframes; ++g) {
+        if (tab.f[g].m == 0) {
+            if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
+            if (live) pass_bytes[((uint64_t)g * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = 0;
+        }
+    }
+    auto next_active = [&](uint32_t k) -> uint32_t { while (k < nframes && tab.f[k].m == 0) ++k; return k; };
+    // geometry of frame k (k < nframes), everything wave-uniform -> SGPRs
+    auto prepare = [&](uint32_t k) -> Q64Frame {
+        Q64Frame q;
+        const FrameDev fd = tab.f[k];
+        q.f = k;
+        q.m = __builtin_amdgcn_readfirstlane(fd.m);
+        q.fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
+        q.fwords = filter_words(q.m);
+        q.Thi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.T >> 32));
+        q.Tlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.T);
+        q.ninv_lo = __builtin_amdgcn_readfirstlane((uint32_t)fd.M);        // the host put the bits of -1.0 / m (IEEE double) into M
+        q.ninv_hi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32));
+        return q;
+    };
+
+    uint32_t k = next_active(0);
+    if (k >= nframes) return;
+    Q64Frame cf = prepare(k);
+    if (!(AB & 8)) dma_filter(lds, image + (uint64_t)cf.f * image_stride_words32, cf.fwords, wave, lane, nwaves);
+    uint32_t cur = 0;
+    const uint32_t group = __builtin_amdgcn_readfirstlane((wave >> 2) % PARTS);   // consecutive waves sit on different SIMDs: a group = one wave per SIMD
+
+    uint32_t held_pb = 0, held_np = 0, held_f = ~0u;
+    auto flush_held = [&]() {
+        if (held_f != ~0u && !(AB & 64) && live) {
+            pass_bytes[((uint64_t)held_f * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)held_pb;
+            if (lane == 0) seg_cnt[(uint64_t)held_f * nseg + seg] = held_np;
+        }
+        held_f = ~0u;
+    };
+    const bool tl_on = (AB & 1024) && blockIdx.x < TL_WGS && (wave == 0 || wave == nwaves - 1) && g_query_timeline;
+    uint64_t *tl = (AB & 1024) && g_query_timeline ? g_query_timeline + ((uint64_t)(blockIdx.x % TL_WGS) * 2 + (wave ? 1 : 0)) * MAX_BATCH * TL_PHASES : nullptr;
+    auto stamp = [&](uint32_t frame_slot, uint32_t phase) {
+        if ((AB & 1024) && tl_on && lane == 0) tl[frame_slot * TL_PHASES + phase] = __builtin_readcyclecounter();
+    };
+
+    while (true) {
+        stamp(cf.f, 0);
+        if (!(AB & 32)) {
+            dma_wait_all();           // my share of DMA(cf.f) has landed (it was issued most of a frame ago) ...
+            stamp(cf.f, 1);
+            __syncthreads();          // ... and everyone's; nobody probes buffer cur^1 any more
+        }
+        stamp(cf.f, 2);
+        const uint32_t kn = __builtin_amdgcn_readfirstlane(next_active(cf.f + 1));
+        const bool more = kn < nframes;
+        Q64Frame nf = cf;
+        if (more) nf = prepare(kn);                               // scalar loads + the division, off the critical path
+        const uint32_t fbase = vgpr_copy(__builtin_amdgcn_readfirstlane(lds_addr_of(lds + cur * bufwords)));
+        uint32_t *const next_buf = lds + (cur ^ 1u) * bufwords;
+        auto issue = [&]() {                                      // this wave's share of DMA(next frame) + last frame's verdicts
+            if (more && !(AB & 8)) dma_filter(next_buf, image + (uint64_t)nf.f * image_stride_words32, nf.fwords, wave, lane, nwaves);
+            if (AB & 2048) flush_held();                          // (ablation: verdicts stored one barrier late)
+        };
+        const uint32_t m_v = vgpr_copy(cf.m);
+        const double ninv = __builtin_bit_cast(double, ((uint64_t)cf.ninv_hi << 32) | cf.ninv_lo);
+        const uint64_t T = ((uint64_t)cf.Thi << 32) | cf.Tlo;
+        const uint32_t fk = cf.fk;
+        const uint32_t grp = (AB & 4096) ? 0u : group;
+        uint32_t pbf = 0, npass = 0;
+        stamp(cf.f, 3);
+        // floor(k*) is a small integer: straight-line code for the common values lets the compiler issue the LDS probes
+        // of a part's pixels back to back instead of one round trip at a time.
+#define RBF_Q64_ARGS hd1, hl1, hd2, hl2, ha, validmask, fbase, safe_pos, m_v, ninv, T, fk, pbf, npass
+#define RBF_Q64_PASS(FKV, CV)                                                                                                         \
+        do {                                                                                                                          \
+            if (grp == 0) issue();                                                                                                    \
+            if (PARTS == 1) frame_part_f64<FKV, AB, CV, 0, 8>(RBF_Q64_ARGS);                                                          \
+            else if (PARTS == 2) {                                                                                                    \
+                frame_part_f64<FKV, AB, CV, 0, 4>(RBF_Q64_ARGS);                                                                      \
+                if (grp == 1) issue();                                                                                                \
+                frame_part_f64<FKV, AB, CV, 4, 8>(RBF_Q64_ARGS);                                                                      \
+            } else {                                                                                                                  \
+                frame_part_f64<FKV, AB, CV, 0, 2>(RBF_Q64_ARGS);                                                                      \
+                if (grp == 1) issue();                                                                                                \
+                frame_part_f64<FKV, AB, CV, 2, 4>(RBF_Q64_ARGS);                                                                      \
+                if (grp == 2) issue();                                                                                                \
+                frame_part_f64<FKV, AB, CV, 4, 6>(RBF_Q64_ARGS);                                                                      \
+                if (grp == 3) issue();                                                                                                \
+                frame_part_f64<FKV, AB, CV, 6, 8>(RBF_Q64_ARGS);                                                                      \
+            }                                                                                                                         \
+        } while (0)
+        if (whole_wave) {
+            switch (fk) {
+            case 1: RBF_Q64_PASS(1, false); break;
+            case 2: RBF_Q64_PASS(2, false); break;
+            case 3: RBF_Q64_PASS(3, false); break;
+            case 4: RBF_Q64_PASS(4, false); break;
+            default: RBF_Q64_PASS(-1, false); break;
+            }
+        } else {                                                  // the frame's last segments: some positions lie past the end
+            RBF_Q64_PASS(-1, true);
+        }
+#undef RBF_Q64_PASS
+#undef RBF_Q64_ARGS
+        if (AB & 16384) {                                          // pass count from the verdict bytes: one popcount + a wave reduction
+            uint32_t c = __popc(~pbf & 0xFFu);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
+            npass = __builtin_amdgcn_readfirstlane(c);
+        }
+        stamp(cf.f, 4);
+        flush_held();
+        held_pb = ~pbf; held_np = npass; held_f = cf.f;
+        if (!(AB & 2048)) flush_held();
+        stamp(cf.f, 5);
+        if (!more) break;
+        cf = nf;
+        cur ^= 1u;
+    }
+    flush_held();
+}
+
+}  // namespace rbf

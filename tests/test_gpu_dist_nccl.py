@@ -79,35 +79,34 @@ dist.destroy_process_group()
 
 
 def run(cmd, timeout=600):
+    """Runs the command, returns its JSON result line (RCCL itself prints to stdout, e.g. 'Librccl path : ...')."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=REPO)
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
-    return p.stdout
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, p.stdout[-2000:]
+    return json.loads(lines[-1])
 
 
 def test_rccl_world1_gathers_records_the_gpu_packed():
     port = str(36000 + os.getpid() % 2000)
-    out = run([sys.executable, "-c", WORKER % {"repo": REPO, "port": port}])
-    res = json.loads(out.strip().splitlines()[-1])
+    res = run([sys.executable, "-c", WORKER % {"repo": REPO, "port": port}])
     assert res["sent"] == 3 and res["slots_checked"] >= 3 * 5
 
 
 def test_bench_force_dist_weak_mode():
     os.environ["MASTER_PORT"] = str(38000 + os.getpid() % 2000)
-    out = run([sys.executable, "bench.py", "--force-dist", "--steps", "12", "--warmup", "2", "--width", "640", "--height", "360", "--frames", "8",
+    res = run([sys.executable, "bench.py", "--force-dist", "--steps", "12", "--warmup", "2", "--width", "640", "--height", "360", "--frames", "8",
                "--gather-every", "4", "--no-cpu-baseline", "--exact-steps"], timeout=900)
-    res = json.loads(out.strip().splitlines()[-1])
     assert res["config"]["gather_to_rank0"] and res["verified_vs_oracle"]["frames"] == 7 * 4 and res["value"] > 0
 
 
 def test_bench_clip_mode_strong_scaling_world1():
     os.environ["MASTER_PORT"] = str(40000 + os.getpid() % 2000)
-    out = run([sys.executable, "bench.py", "--force-dist", "--clip-frames", "40", "--keyframe-interval", "10", "--steps", "2", "--warmup", "1",
+    res = run([sys.executable, "bench.py", "--force-dist", "--clip-frames", "40", "--keyframe-interval", "10", "--steps", "2", "--warmup", "1",
                "--width", "640", "--height", "360"], timeout=900)
-    res = json.loads(out.strip().splitlines()[-1])
     assert res["scaling"] == "strong" and res["verified_vs_oracle"]["frames"] == 36 == res["verified_vs_oracle"]["of"]
     assert res["verified_vs_oracle"]["records_parsed_on_rank0"] == 36
-    out = run([sys.executable, "bench.py", "--clip-frames", "21", "--keyframe-interval", "10", "--steps", "2", "--warmup", "1",
+    res = run([sys.executable, "bench.py", "--clip-frames", "21", "--keyframe-interval", "10", "--steps", "2", "--warmup", "1",
                "--width", "640", "--height", "360", "--bits", "16"], timeout=900)
-    res = json.loads(out.strip().splitlines()[-1])
     assert res["verified_vs_oracle"]["frames"] == 18

@@ -257,3 +257,16 @@ def test_wire_record_layout_against_reference_blob():
     assert parse_record("f64", wide)["k"] == k
     with pytest.raises(ValueError):
         parse_record("reference", blob[:-5])
+
+
+def test_fp64_reduction_is_exact(tmp_path):
+    """mod_m_f64 (the query / insert kernels' h mod m through one v_fma_f64 + one v_mad_u32_u24) restated step by step
+    in C against 64-bit integer arithmetic: random h, h next to multiples of m over the whole quotient range, the
+    extremes of the 64-bit range, the whole span of eligible m."""
+    import subprocess
+    exe = str(tmp_path / "mod_f64_check")
+    r = subprocess.run(["gcc", "-O2", "-std=c99", "-Wall", "-Werror", os.path.join(REPO, "tests", "c", "mod_f64_check.c"), "-lm", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe, "3000"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("OK "), out.stdout[-2000:]

@@ -3,26 +3,34 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../new_bloom_filter_repo_amd/csrc/rbf_kernels_lds.h"
+#include <cstring>
+#include "../new_bloom_filter_repo_amd/csrc/rbf_kernels_q64.h"
 using namespace rbf;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int AB, bool DB = true, int THREADS = QL_THREADS>
+static const uint32_t *g_image = nullptr;       // probe image (~bswap of every filter dword), same row pitch as the filters
+template <int AB, bool DB = true, int THREADS = QL_THREADS, int MODK = 0, int PARTS = 1>
 static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F, const FrameTable &tab, Seeds sd, const uint32_t *filters,
                  uint64_t fstride, uint32_t fwmax, uint32_t *seg_bits, uint32_t *seg_cnt, uint64_t nseg, size_t lds)
 {
-    auto kern = k_query_lds<DB, true, AB>;
+    FrameTable qtab = tab;
+    if (MODK == 1) {
+        filters = g_image; lds += 32;
+        for (uint32_t f = 0; f < F; ++f) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
+    }
+    void (*kern)(uint64_t, uint32_t, const FrameTable, Seeds, const uint32_t *, uint64_t, uint32_t, uint32_t *, uint64_t, uint64_t *);
+    if constexpr (MODK == 1) kern = k_query_f64<AB, PARTS>; else kern = k_query_lds<DB, true, AB>;
     uint64_t *pwords = (uint64_t *)seg_bits;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const uint32_t bx = (uint32_t)((nseg + THREADS / 64 - 1) / (THREADS / 64));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int w = 0; w < 2; ++w)
-        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, n, F, tab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
+        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, n, F, qtab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
     const int R = 10;
     for (int r = 0; r < R; ++r)
-        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, n, F, tab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
+        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, n, F, qtab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return ms / R * 1000.f;
@@ -31,7 +39,7 @@ static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F
 int main()
 {
     const uint64_t n = 1920 * 1080; const uint32_t F = 29; const uint32_t m = 611158;
-    const uint64_t mstride = ((n + 63) / 64), fwords = (m + 31) / 32, fstride = ((fwords + 1) & ~1ull);
+    const uint64_t mstride = ((n + 63) / 64), fwords = (m + 31) / 32, fstride = ((fwords + 3) & ~3ull);
     const uint64_t nseg = (n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS;
     std::vector<uint64_t> hm(mstride * F); std::vector<uint32_t> hf(fstride * F);
     srand(1);
@@ -41,13 +49,92 @@ int main()
     CK(hipMalloc(&dm, hm.size() * 8)); CK(hipMalloc(&df, hf.size() * 4 + 64));
     CK(hipMalloc(&sb, (size_t)F * nseg * QL_P * 8)); CK(hipMalloc(&sc, (size_t)F * nseg * 4));
     CK(hipMemcpy(dm, hm.data(), hm.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(df, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    { std::vector<uint32_t> img(hf.size()); for (size_t i = 0; i < hf.size(); ++i) img[i] = ~__builtin_bswap32(hf[i]);
+      uint32_t *di; CK(hipMalloc(&di, img.size() * 4 + 64)); CK(hipMemcpy(di, img.data(), img.size() * 4, hipMemcpyHostToDevice)); g_image = di; }
     FrameTable tab{};
     for (uint32_t f = 0; f < F; ++f) { tab.f[f].m = m - 37 * f; tab.f[f].floor_k = 2; tab.f[f].T = 0x4D00000000000000ull; tab.f[f].M = (uint64_t)((((unsigned __int128)1) << 64) / tab.f[f].m); }
     Seeds sd{0x12345678, 0x87654321, 999};
     const uint32_t fwmax = (uint32_t)fwords;
     const size_t lds = 2 * (size_t)((fwmax + 3) & ~3u) * 4;
 #define RUN(AB, what) printf("%-44s %8.1f us\n", what, run<AB>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+#define RUN1(AB, what) printf("%-44s %8.1f us\n", "[fp64 mod] " what, run<AB, true, QL_THREADS, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
     RUN(0, "full kernel");
+    {   // the FP64-reduction kernel must write the same pass bytes and segment counts
+        const size_t pwb = (size_t)F * nseg * QL_P * 8, scb = (size_t)F * nseg * 4;
+        std::vector<uint8_t> a(pwb), b(pwb); std::vector<uint32_t> ca(F * nseg), cb(F * nseg);
+        CK(hipMemcpy(a.data(), sb, pwb, hipMemcpyDeviceToHost)); CK(hipMemcpy(ca.data(), sc, scb, hipMemcpyDeviceToHost));
+        CK(hipMemset(sb, 0xEE, pwb)); CK(hipMemset(sc, 0xEE, scb));
+        RUN1(0, "full kernel");
+        CK(hipMemcpy(b.data(), sb, pwb, hipMemcpyDeviceToHost)); CK(hipMemcpy(cb.data(), sc, scb, hipMemcpyDeviceToHost));
+        size_t diff = 0; for (size_t i = 0; i < pwb; ++i) diff += a[i] != b[i];
+        size_t dc = 0; for (size_t i = 0; i < ca.size(); ++i) dc += ca[i] != cb[i];
+        uint64_t passes = 0; for (auto c : ca) passes += c;
+        printf("fp64-mod kernel vs Barrett kernel: %zu differing pass bytes, %zu differing segment counts (%llu passes)\n", diff, dc, (unsigned long long)passes);
+    }
+#define RUNP(AB, TH, PARTS, what) printf("%-60s %8.1f us\n", "[fp64 mod] " what, run<AB, true, TH, 1, PARTS>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+    RUNP(8 | 32 | 2048, 1024, 1, "pure passes (A): and/add addressing, ballots");
+    RUNP(8 | 32 | 2048 | 8192, 1024, 1, "pure passes (B): lshr + lshl_add addressing");
+    RUNP(8 | 32 | 2048 | 16384, 1024, 1, "pure passes (C): count by popc + wave reduction");
+    RUNP(8 | 32 | 2048 | 8192 | 16384, 1024, 1, "pure passes (B+C)");
+    RUNP(2048, 1024, 1, "full (A)");
+    RUNP(2048 | 8192, 1024, 1, "full (B)");
+    RUNP(2048 | 16384, 1024, 1, "full (C)");
+    RUNP(2048 | 8192 | 16384, 1024, 1, "full (B+C)");
+    RUNP(0, 1024, 1, "full kernel, 1 part (all DMA after the barrier)");
+    RUNP(0, 1024, 2, "full kernel, 2 parts");
+    RUNP(8 | 32, 1024, 1, "pure passes, 1 part, 4 waves/SIMD");
+    RUNP(8 | 32, 512, 1, "pure passes, 1 part, 2 waves/SIMD");
+    RUNP(8 | 32, 256, 1, "pure passes, 1 part, 1 wave/SIMD");
+    RUNP(8 | 32, 1024, 2, "pure passes, 2 parts, 4 waves/SIMD");
+    RUNP(8 | 32, 256, 2, "pure passes, 2 parts, 1 wave/SIMD");
+    RUNP(8 | 32 | 4, 1024, 1, "pure passes, 1 part, no ballots");
+    RUNP(8, 1024, 1, "1 part, no DMA (barrier kept)");
+    RUNP(2048, 1024, 1, "1 part, stores at the end of the iteration");
+    RUN1(8 | 32, "no DMA, no barrier: pure frame passes + stores");
+    printf("%-44s %8.1f us\n", "[fp64 mod] same, 512-thread WGs (2 waves/SIMD)", run<8 | 32, true, 512, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+    printf("%-44s %8.1f us\n", "[fp64 mod] same, 256-thread WGs (1 wave/SIMD)", run<8 | 32, true, 256, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+    printf("%-44s %8.1f us\n", "[fp64 mod] same, 128-thread WGs (2 SIMDs busy)", run<8 | 32, true, 128, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+    printf("%-44s %8.1f us\n", "[fp64 mod] full kernel, 512-thread WGs", run<0, true, 512, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+    RUN1(8 | 32 | 2, "no DMA, no barrier, no LDS probes");
+    RUN1(8 | 32 | 1, "no DMA, no barrier, no reductions");
+    RUN1(8 | 32 | 4, "no DMA, no barrier, no pass counting (ballots)");
+    RUN1(8 | 32 | 16, "no DMA, no barrier, no hashing");
+    RUN1(8 | 32 | 1 | 2 | 4, "no DMA, no barrier, no reductions/probes/ballots");
+    RUN1(8, "no DMA (barrier kept)");
+    RUN1(32, "no barrier (DMA kept; wrong results)");
+    RUN1(2048, "verdict store at the end of its own iteration");
+    RUN1(4096, "every wave issues its DMA right after the barrier");
+    RUN1(4096 | 2048, "... and stores at the end (the r01 frame loop)");
+    RUN1(2 | 8, "no LDS probes, no filter DMA");
+    RUN1(512, "frame order rotated per workgroup");
+    {   // timeline of the frame loop: shader-clock stamps of wave 0 and wave 15 of the first workgroups
+        uint64_t *dtl; const size_t tlw = (size_t)TL_WGS * 2 * MAX_BATCH * TL_PHASES;
+        CK(hipMalloc(&dtl, tlw * 8)); CK(hipMemset(dtl, 0, tlw * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_query_timeline), &dtl, sizeof dtl));
+        RUN1(1024, "with timeline stamps");
+        std::vector<uint64_t> tl(tlw); CK(hipMemcpy(tl.data(), dtl, tlw * 8, hipMemcpyDeviceToHost));
+        const char *names[6] = {"vmcnt(0) wait", "barrier", "next-frame geometry", "frame pass + DMA issue + store", "hold", "loop overhead to next frame"};
+        for (uint32_t wg = 0; wg < TL_WGS; ++wg) for (int w = 0; w < 2; ++w) {
+            const uint64_t *t = tl.data() + ((size_t)wg * 2 + w) * MAX_BATCH * TL_PHASES;
+            double sum[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t f = 1; f + 1 < F; ++f) {
+                for (int ph = 0; ph < 5; ++ph) sum[ph] += (double)(t[f * TL_PHASES + ph + 1] - t[f * TL_PHASES + ph]);
+                sum[5] += (double)(t[(f + 1) * TL_PHASES] - t[f * TL_PHASES + 5]);
+            }
+            printf("timeline wg %u wave %s: ", wg, w ? "15" : " 0");
+            double tot = 0; for (int ph = 0; ph < 6; ++ph) tot += sum[ph];
+            for (int ph = 0; ph < 6; ++ph) printf("%s %.0f (%.0f%%) | ", names[ph], sum[ph] / (F - 2), 100.0 * sum[ph] / tot);
+            printf("cycles per frame %.0f\n", tot / (F - 2));
+        }
+    }
+    RUN1(32 | 64 | 8, "no barrier, no flush, no DMA");
+    RUN1(16, "no hashing");
+    RUN1(1, "no reductions (mod m)");
+    RUN1(2, "no LDS probes");
+    RUN1(4, "no ballot/compaction");
+    RUN1(8, "no filter DMA");
+    RUN1(2 | 4 | 8 | 16, "only reductions");
+    RUN1(1 | 4 | 8 | 16, "only probes");
     { const size_t lds1 = (size_t)((fwmax + 3) & ~3u) * 4;
       printf("%-44s %8.1f us\n", "single buffer, 1024 thr (1 WG/CU)", run<0, false, 1024>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds1));
       printf("%-44s %8.1f us\n", "single buffer, 512 thr (2 WG/CU)", run<0, false, 512>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds1));

@@ -21,6 +21,8 @@ enum Op {
     FMA_F32, FMA_F64, MUL_F64, ADD_F64, CVT_F64_U32, CVT_U32_F64, LSHLREV_B64, LSHRREV_B64,
     CMP_LT_U32, CMP_LT_U64, CNDMASK, ADD_CO_ADDC, MOV_DPP, READLANE, PK_ADD_U16, PK_MIN_U16,
     MAD_U32_U16, MOV_B32, NOP_SALU,
+    ADD_VV, ADD_VK, MIN_VV, AND_VV, XOR_VV, LSHLREV_VV, SUBREV_VS, ADD3_VVV, BITOP3_VVV, MAD24_VVV, FMA64_VVV, LSHL_ADD_VVV, ALIGNBIT_VVV,
+    CNDMASK_SGPR, CMP_SGPR_DST, ADD_LIT, BFE_I32, MIN_VS_E64,
     NOPS
 };
 
@@ -31,10 +33,13 @@ static const char *op_name[] = {
     "v_fma_f32", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_cvt_f64_u32", "v_cvt_u32_f64", "v_lshlrev_b64", "v_lshrrev_b64",
     "v_cmp_lt_u32 (vcc)", "v_cmp_lt_u64 (vcc)", "v_cndmask_b32", "v_add_co+v_addc_co (pair)", "v_mov_b32 dpp row_shr:1", "v_readlane_b32", "v_pk_add_u16", "v_pk_min_u16",
     "v_mad_u32_u16", "v_mov_b32", "s_add_u32 (SALU)",
+    "v_add_u32 v,v,v", "v_add_u32 v,7,v", "v_min_u32 v,v,v", "v_and_b32 v,v,v", "v_xor_b32 v,v,v", "v_lshlrev_b32 v,v,v", "v_subrev_u32 v,s,v", "v_add3_u32 v,v,v,v",
+    "v_bitop3_b32 v,v,v,v", "v_mad_u32_u24 v,v,v,v", "v_fma_f64 v,v,v,v", "v_lshl_add_u32 v,v,2,v", "v_alignbit_b32 v,v,v,v",
+    "v_cndmask_b32 v,v,v,s[]", "v_cmp_lt_u32 s[],v,v", "v_add_u32 v,literal,v", "v_bfe_i32 v,v,0,24", "v_min_u32_e64 v,v,s",
 };
 
 template <int OP>
-__device__ __forceinline__ void one(uint32_t &a, uint32_t &b, uint64_t &d, uint32_t s0, uint32_t s1)
+__device__ __forceinline__ void one(uint32_t &a, uint32_t &b, uint64_t &d, uint32_t s0, uint32_t s1, uint32_t &c, uint64_t &e, uint64_t scond)
 {
     // a, b: 32-bit chain registers; d: 64-bit chain register; s0, s1: SGPR operands
     if (OP == ADD_U32) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a) : "s"(s0));
@@ -76,6 +81,24 @@ __device__ __forceinline__ void one(uint32_t &a, uint32_t &b, uint64_t &d, uint3
     else if (OP == MAD_U32_U16) asm volatile("v_mad_u32_u16 %0, %0, %1, %2" : "+v"(a) : "s"(s0), "v"(b));
     else if (OP == MOV_B32) asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(b));
     else if (OP == NOP_SALU) { uint32_t t = s0; asm volatile("s_add_u32 %0, %0, %1" : "+s"(t) : "s"(s1) : "scc"); }
+    else if (OP == ADD_VV) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a) : "v"(b));
+    else if (OP == ADD_VK) asm volatile("v_add_u32 %0, 7, %0" : "+v"(a));
+    else if (OP == MIN_VV) asm volatile("v_min_u32 %0, %1, %0" : "+v"(a) : "v"(b));
+    else if (OP == AND_VV) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a) : "v"(b));
+    else if (OP == XOR_VV) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a) : "v"(b));
+    else if (OP == LSHLREV_VV) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(a) : "v"(b));
+    else if (OP == SUBREV_VS) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(a) : "s"(s0));
+    else if (OP == ADD3_VVV) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    else if (OP == BITOP3_VVV) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a) : "v"(b), "v"(c));
+    else if (OP == MAD24_VVV) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    else if (OP == FMA64_VVV) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d) : "v"(e));
+    else if (OP == LSHL_ADD_VVV) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a) : "v"(b));
+    else if (OP == ALIGNBIT_VVV) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    else if (OP == CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(scond));
+    else if (OP == CMP_SGPR_DST) { uint64_t t; asm volatile("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(t) : "v"(a), "v"(b)); }
+    else if (OP == ADD_LIT) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(a));
+    else if (OP == BFE_I32) asm volatile("v_bfe_i32 %0, %0, 0, 24" : "+v"(a));
+    else if (OP == MIN_VS_E64) asm volatile("v_min_u32_e64 %0, %0, %1" : "+v"(a) : "s"(s0));
 }
 
 constexpr int UNROLL = 8;
@@ -84,10 +107,11 @@ template <int OP, int CH>
 __global__ __launch_bounds__(256) void k_op(uint64_t *out, uint32_t s0, uint32_t s1, int reps)
 {
     extern __shared__ uint32_t lds_pad[];
-    uint32_t a[CH], b[CH];
-    uint64_t d[CH];
+    uint32_t a[CH], b[CH], cc[CH];
+    uint64_t d[CH], e[CH];
+    const uint64_t scond = __ballot((threadIdx.x & 1u) != 0);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { a[c] = threadIdx.x * 2654435761u + c; b[c] = threadIdx.x + 17 * c + 1; d[c] = 0x3FF0000000000000ull + threadIdx.x + c; }
+    for (int c = 0; c < CH; ++c) { a[c] = threadIdx.x * 2654435761u + c; b[c] = threadIdx.x + 17 * c + 1; cc[c] = threadIdx.x * 3 + c; d[c] = 0x3FF0000000000000ull + threadIdx.x + c; e[c] = 0x3FF0000000000001ull + c; }
     __syncthreads();
     const uint64_t w0 = wall_clock64();
     const uint64_t t0 = __builtin_readcyclecounter();
@@ -96,12 +120,12 @@ __global__ __launch_bounds__(256) void k_op(uint64_t *out, uint32_t s0, uint32_t
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-            for (int c = 0; c < CH; ++c) one<OP>(a[c], b[c], d[c], s0, s1);
+            for (int c = 0; c < CH; ++c) one<OP>(a[c], b[c], d[c], s0, s1, cc[c], e[c], scond);
     }
     const uint64_t t1 = __builtin_readcyclecounter();
     uint32_t x = 0;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) x ^= a[c] ^ b[c] ^ (uint32_t)d[c] ^ (uint32_t)(d[c] >> 32);
+    for (int c = 0; c < CH; ++c) x ^= a[c] ^ b[c] ^ cc[c] ^ (uint32_t)e[c] ^ (uint32_t)d[c] ^ (uint32_t)(d[c] >> 32);
     if (x == 0x12345u && reps < 0) lds_pad[threadIdx.x] = x;
     const uint64_t w1 = wall_clock64();
     if ((threadIdx.x & 63u) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
@@ -199,6 +223,10 @@ int main()
     bench<FMA_F32>(); bench<FMA_F64>(); bench<MUL_F64>(); bench<ADD_F64>(); bench<CVT_F64_U32>(); bench<CVT_U32_F64>(); bench<LSHLREV_B64>(); bench<LSHRREV_B64>();
     bench<CMP_LT_U32>(); bench<CMP_LT_U64>(); bench<CNDMASK>(); bench<ADD_CO_ADDC>(); bench<MOV_DPP>(); bench<READLANE>(); bench<PK_ADD_U16>(); bench<PK_MIN_U16>();
     bench<MAD_U32_U16>(); bench<MOV_B32>(); bench<NOP_SALU>();
+    printf("# operand kinds: the same opcodes with VGPR-only / inline-constant / literal / SGPR operands\n");
+    bench<ADD_VV>(); bench<ADD_VK>(); bench<ADD_LIT>(); bench<MIN_VV>(); bench<MIN_VS_E64>(); bench<AND_VV>(); bench<XOR_VV>(); bench<LSHLREV_VV>(); bench<SUBREV_VS>();
+    bench<ADD3_VVV>(); bench<BITOP3_VVV>(); bench<MAD24_VVV>(); bench<FMA64_VVV>(); bench<LSHL_ADD_VVV>(); bench<ALIGNBIT_VVV>(); bench<BFE_I32>();
+    bench<CNDMASK_SGPR>(); bench<CMP_SGPR_DST>();
     printf("# LDS probes, 1024-thread workgroup per CU, 76 KB table\n");
     const double base = run_lds<4>("address generation only");
     const double r32 = run_lds<0>("ds_read_b32 random dword");
