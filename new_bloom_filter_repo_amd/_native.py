@@ -15,8 +15,8 @@ RBF_ENOMEM = -12
 RBF_EIO = -5
 RBF_ERANGE = -34
 
-K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE, K_PACK = range(12)
-KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack"]
+K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE, K_PACK, K_HASHTAB = range(13)
+KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack", "hashtab"]
 STATS_PER_FRAME = 4
 
 

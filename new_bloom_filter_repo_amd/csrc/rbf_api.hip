@@ -1,7 +1,7 @@
 // rbf_api.hip -- C ABI (include/rbf.h) over the gfx950 kernels.  Host side: argument checks,
 // scratch management, launches on the context's single HIP stream, optional per-kernel timing.
 #include "../../include/rbf.h"
-#include "rbf_kernels_q64.h"
+#include "rbf_kernels_i64.h"
 #include "rbf_kernels_noise.h"
 #include "rbf_kernels_pack.h"
 
@@ -57,6 +57,10 @@ struct rbf_ctx {
     uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
     int force_generic_mask_bits = 0; // tests: 1 = per-pixel threshold compare even for threshold 0
     int barrett_only = 0;            // tests/tuning: 1 = never take the FP64 reductions (mod_m_f64)
+    int hash_cache = 0;              // 1 = keep the hash table between batches of the same (n, seeds)
+    int no_hash_table = 0;           // 1 = the insert kernel hashes the set positions itself
+    uint4 *hash_tab = nullptr;       size_t hash_tab_cap = 0;     // k_hash_table output, 32 bytes per pixel
+    uint64_t hash_tab_n = 0; rbf_seeds hash_tab_seeds{0, 0, 0}; bool hash_tab_valid = false;
     uint32_t tile_words = 0;         // tests/tuning: cap the LDS filter tile (dwords); forces the tiled kernels
     // host staging of encode_gop: device-visible pinned block [flag | ones...] the GPU publishes into
     uint64_t *ones_pinned = nullptr; size_t host_cap = 0;
@@ -180,6 +184,7 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->qimage) (void)hipFree(ctx->qimage);
+    if (ctx->hash_tab) (void)hipFree(ctx->hash_tab);
     if (ctx->thr_tab) (void)hipFree(ctx->thr_tab);
     if (ctx->pack_base) (void)hipFree(ctx->pack_base);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -258,6 +263,9 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->single_buffer = (on & 2) ? 1 : 0;
     ctx->force_generic_mask_bits = (on & 4) ? 1 : 0;
     ctx->barrett_only = (on & 8) ? 1 : 0;
+    ctx->hash_cache = (on & 16) ? 1 : 0;
+    ctx->no_hash_table = (on & 32) ? 1 : 0;
+    if (!ctx->hash_cache) ctx->hash_tab_valid = false;
     ctx->mask_chunks = (uint32_t)(on >> 8) & 0xFF;           // tuning knob, bits 8..15
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
     return RBF_OK;
@@ -383,6 +391,7 @@ struct Plan {
     bool fast_insert;            // LDS partial-filter insert (any filter size, tiled when needed)
     int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles
     bool double_buffer, small_m;
+    bool insert_tab;             // insert through the hash table + FP64 reductions (same size condition, any LDS fit)
     bool f64_mod;                // every coded frame has F64MOD_M_MIN <= m <= F64MOD_M_MAX: reductions through the FP64 pipe
     uint32_t fwords_max, S /* slices of a coded frame */, per_tile /* sum of slices */, insert_group /* coded frames per insert launch */;
     SliceTable slices;
@@ -400,7 +409,9 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     uint32_t mmax = 0, active = 0;
     p.small_m = true;
     p.f64_mod = !ctx->barrett_only;
+    bool sizes_f64 = true;
     for (uint32_t f = 0; f < nframes; ++f) {
+        if (params[f].m && (params[f].m < F64MOD_M_MIN || params[f].m > F64MOD_M_MAX)) sizes_f64 = false;
         if (params[f].m > mmax) mmax = params[f].m;
         if (params[f].m) ++active;
         if (params[f].m == 1 || params[f].m > (1u << 30)) p.small_m = false;
@@ -409,7 +420,8 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     p.fwords_max = (uint32_t)(((uint64_t)mmax + 31) / 32);
     const size_t fbytes = (size_t)((p.fwords_max + 3u) & ~3u) * 4;
     // insert: whole partial filter in LDS next to the per-wave queues, else tiles of the largest size that fits
-    const size_t queue_bytes = (size_t)IL_WAVES * IL_QUEUE * 4;
+    // the table-driven insert kernel has the larger per-wave queue; size the tiles for whichever may run
+    const size_t queue_bytes = (size_t)IL_WAVES * (IT_QUEUE > IL_QUEUE ? IT_QUEUE : IL_QUEUE) * 4;
     const uint32_t max_tile_words = (uint32_t)((LDS_LIMIT - queue_bytes) / 4) & ~3u;
     p.insert_tile_words = ((p.fwords_max + 3u) & ~3u) <= max_tile_words ? ((p.fwords_max + 3u) & ~3u) : max_tile_words;
     if (ctx->tile_words && ctx->tile_words < p.insert_tile_words) p.insert_tile_words = ctx->tile_words & ~3u;
@@ -465,6 +477,7 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
         p.per_tile += sf;
     }
     if (p.query_kind != 1) p.f64_mod = false;                     // only the whole-filter LDS query kernel has the FP64 form
+    p.insert_tab = p.fast_insert && sizes_f64 && !ctx->no_hash_table && !ctx->barrett_only;
     p.image_stride_words = (p.fwords_max + 3u) & ~3u;
     const uint32_t segpx = p.query_kind == 1 ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
     p.nseg = (n + segpx - 1) / segpx;
@@ -673,8 +686,36 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     if (pl.fast_insert) {
         const uint64_t part_stride = (pl.fwords_max + 3u) & ~3ull;      // 16-byte rows for the reduce kernel
         if (int r = grow((void **)&ctx->partials, &ctx->partials_cap, (size_t)nframes * pl.S * part_stride * 4)) return r;
+        // hash table of the pixel indices (k_hash_table): built for this batch, or kept from the last one when the
+        // context was told to cache it; without device memory for it the insert kernel hashes for itself
+        bool use_tab = pl.insert_tab;
+        if (use_tab) {
+            const size_t need = ((size_t)n + QL_SEG_PIXELS) * 32;
+            if (ctx->hash_tab_cap < need) {
+                if (ctx->hash_tab) { HIP_TRY(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->hash_tab); }
+                ctx->hash_tab = nullptr; ctx->hash_tab_cap = 0; ctx->hash_tab_valid = false;
+                if (hipMalloc((void **)&ctx->hash_tab, need) != hipSuccess) { (void)hipGetLastError(); ctx->hash_tab = nullptr; use_tab = false; }
+                else ctx->hash_tab_cap = need;
+            }
+        }
+        if (use_tab) {
+            const bool same = ctx->hash_tab_valid && ctx->hash_tab_n == n && ctx->hash_tab_seeds.h1 == seeds->h1 &&
+                              ctx->hash_tab_seeds.h2 == seeds->h2 && ctx->hash_tab_seeds.act == seeds->act;
+            if (!(ctx->hash_cache && same)) {
+                const uint64_t segs = (n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS;
+                LaunchTimer t(ctx, RBF_K_HASHTAB);
+                hipLaunchKernelGGL(k_hash_table, dim3((uint32_t)((segs + HT_THREADS / WAVE - 1) / (HT_THREADS / WAVE))), dim3(HT_THREADS), 0, ctx->stream,
+                                   n, sd, ctx->hash_tab);
+                ctx->hash_tab_n = n; ctx->hash_tab_seeds = *seeds; ctx->hash_tab_valid = true;
+            }
+        }
+        FrameTable itab = tab;                                     // k_insert_tab reads -1/m from the M field
+        if (use_tab)
+            for (uint32_t f = 0; f < nframes; ++f)
+                if (itab.f[f].m) { const double ninv = -1.0 / (double)itab.f[f].m; memcpy(&itab.f[f].M, &ninv, 8); }
         auto ikern = pl.small_m ? k_insert_lds<true> : k_insert_lds<false>;
         if (int r = allow_big_lds((const void *)ikern)) return r;
+        if (int r = allow_big_lds((const void *)k_insert_tab<0>)) return r;
         for (uint32_t f0 = 0; f0 < nframes;) {                    // groups of pl.insert_group coded frames
             SliceTable grp{};
             uint32_t per_tile = 0, coded = 0, f = f0;
@@ -686,9 +727,14 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
             f0 = f;
             if (!per_tile) continue;
             LaunchTimer t(ctx, RBF_K_INSERT);
-            hipLaunchKernelGGL(ikern, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
-                               (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.insert_tile_words,
-                               grp, per_tile, pl.S);
+            if (use_tab)
+                hipLaunchKernelGGL(k_insert_tab<0>, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, ctx->partials, part_stride,
+                                   pl.insert_tile_words, grp, per_tile, pl.S);
+            else
+                hipLaunchKernelGGL(ikern, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.insert_tile_words,
+                                   grp, per_tile, pl.S);
         }
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);

@@ -1,0 +1,196 @@
+// rbf_kernels_i64.h -- the insert path for filters of 2^15 <= m < 2^23 bits (1080p / 2160p frames):
+//
+//   k_hash_table   the three XXH64 of EVERY pixel index of the frame geometry, once per batch (they depend on the index
+//                  and the seeds only, not on the frame: improved_video_compressor.py:77-78,94), stored in the form the
+//                  FP64 reduction wants -- 32 bytes per pixel: RN(h1), RN(h2) as doubles, the low dwords of h1 and
+//                  h2, and h_act.  A lane owns 8 consecutive indices, so the decade-prefix sharing of hash3_run8
+//                  applies (~120 instead of ~600 instructions per index), and over a 29-frame batch 93 % of all
+//                  indices are set in at least one frame, so nothing is hashed in vain.
+//   k_insert_tab   k_insert_lds with the hashing replaced by a 32-byte gather from that table: workgroup (slice, frame
+//                  [, tile]) builds a partial filter in LDS from its slice of the mask; set positions are compacted
+//                  through a per-wave LDS queue so that the gather, the two reductions (mod_m_f64) and the LDS atomics
+//                  always run on full waves; the gather of one batch of 64 keys flies while the next mask bytes are
+//                  compacted.  All workgroups of a slice run on the same XCD (slice = blockIdx % 8 when a frame has 8
+//                  slices), so the table lines of a slice are fetched from HBM once and then hit that XCD's L2 for the
+//                  other frames.
+//
+// In k_insert_lds the three hashes of the p*n set positions cost ~33 of its ~70 us per 1080p x 29 batch (64-bit
+// multiplies: tools/bench_insert.hip ablation); the table costs one ~66 MB write per batch.
+#pragma once
+#include "rbf_kernels_q64.h"
+
+namespace rbf {
+
+constexpr int HT_THREADS = 256;
+
+__global__ __launch_bounds__(HT_THREADS) void k_hash_table(uint64_t n, Seeds seeds, uint4 *__restrict__ table)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * (HT_THREADS / WAVE) + wave;
+    const uint64_t i0 = seg * QL_SEG_PIXELS + (uint64_t)lane * QL_P;
+    uint64_t h1[QL_P], h2[QL_P], ha[QL_P];
+    uint32_t validmask = 0;
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) {
+        h1[it] = 0; h2[it] = 0; ha[it] = 0;
+        if (i0 + it < n) validmask |= 1u << it;
+    }
+    if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {                      // mixed key lengths in this wave: index by index
+            const bool act = (validmask >> it) & 1u;
+            const Hash3 h = hash3_index((uint32_t)(i0 + it), act, seeds);
+            h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
+        }
+    }
+    // A lane's 8 entries are 256 contiguous bytes of the table, so a plain store instruction would scatter 64 sixteen-byte
+    // pieces over 64 cache lines (measured: 37 us for the 66 MB of a 1080p table).  The wave's entries go through LDS in
+    // two halves of 4 pixels (lane pitch 144 bytes: conflict-free 16-byte writes) and leave as whole 128-byte lines, 8
+    // lines per store instruction.  Entries past the end of the frame are written too (the table is padded to whole
+    // segments): they are never read.
+    __shared__ __attribute__((aligned(16))) uint32_t stage[(HT_THREADS / WAVE) * 64 * 36];
+    uint32_t *mine = stage + wave * (64 * 36);
+    uint8_t *out = reinterpret_cast<uint8_t *>(table) + seg * (uint64_t)QL_SEG_PIXELS * 32;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int it = half * 4 + e;
+            const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h1[it]), d2 = __builtin_bit_cast(uint64_t, (double)h2[it]);
+            uint4 *dst = reinterpret_cast<uint4 *>(mine + lane * 36 + e * 8);
+            dst[0] = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));
+            dst[1] = make_uint4((uint32_t)h1[it], (uint32_t)h2[it], (uint32_t)ha[it], (uint32_t)(ha[it] >> 32));
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t L = r * 8 + (lane >> 3), piece = lane & 7u;            // 8 lanes move the 128 bytes of lane L's half
+            const uint4 v = *reinterpret_cast<const uint4 *>(mine + L * 36 + piece * 4);
+            *reinterpret_cast<uint4 *>(out + (uint64_t)(L * 8 + half * 4) * 32 + piece * 16) = v;
+        }
+        wave_lds_fence();
+    }
+}
+
+constexpr int IT_STEP_BYTES = 128;                 // mask bytes per wave step: a lane owns 16 pixels (two bytes)
+constexpr int IT_QUEUE = 64 + IT_STEP_BYTES * 8;   // carry (< 64) + one wave step
+
+// IAB (ablation mask, tools/bench_insert.hip only; 0 in the library): 1 = no table gather (fake entries), 2 = no LDS
+// atomics, 4 = no LDS zeroing / partial store, 8 = no queueing (mask bytes read, nothing queued).
+// `tab`: M carries the bits of -1.0 / m (IEEE double, computed on the host) instead of the Barrett constant.
+template <int IAB = 0>
+__global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
+    const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
+    const FrameTable tab, const uint4 *__restrict__ table,
+    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t tile_words /* even */,
+    const SliceTable slices, uint32_t per_tile /* sum of slices.n */, uint32_t Smax /* max of slices.n: row pitch of the partials */)
+{
+    // workgroup -> (tile, frame, slice) exactly as in k_insert_lds (one-dimensional grid, slice fastest)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *filt = lds;                                         // [tile_words]
+    uint32_t *queues = lds + tile_words;                          // [IL_WAVES][IT_QUEUE]
+    const uint32_t tile = blockIdx.x / per_tile;
+    uint32_t s = blockIdx.x - tile * per_tile, f = 0;
+    while (s >= slices.n[f]) { s -= slices.n[f]; ++f; }
+    const uint32_t S = slices.n[f];
+    const FrameDev fd = tab.f[f];
+    if (fd.m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t fwords = filter_words(fd.m);
+    const uint32_t tile0 = tile * tile_words;
+    if (tile0 >= fwords) return;
+    const uint32_t tile_bit0 = tile0 << 5, tile_bits = tile_words << 5;
+    if (!(IAB & 4)) for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
+    __syncthreads();
+
+    const uint8_t *mask = masks + (uint64_t)f * mask_stride_bytes;
+    const uint64_t nbytes = (n + 7) >> 3;
+    const uint64_t groups = (nbytes + IT_STEP_BYTES - 1) / IT_STEP_BYTES;   // wave steps of 128 mask bytes = 1024 pixels
+    const uint64_t gper = (groups + S - 1) / S;
+    const uint64_t g0 = (uint64_t)s * gper;
+    const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
+    uint32_t *q = queues + wave * IT_QUEUE;
+    uint32_t qn = 0;                                               // wave-uniform queue length
+
+    const uint32_t m = vgpr_copy(__builtin_amdgcn_readfirstlane(fd.m));
+    const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
+    const double ninv = __builtin_bit_cast(double, fd.M);
+    const uint64_t T = fd.T;
+
+    // one batch of <= 64 keys in flight: its table entries are requested (`fetch`) when the batch leaves the queue and
+    // consumed (`finish`) when the next batch is ready -- or at the end -- so the gather latency hides under compaction
+    uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+    uint32_t pending = 0;                                          // keys of the batch in flight (wave-uniform)
+    auto fetch = [&](uint32_t first, uint32_t count) {
+        const uint32_t idx = lane < count ? q[first + lane] : 0u;  // idle lanes read entry 0 (always there)
+        if (IAB & 1) { e0 = make_uint4(idx * 0x9E3779B1u, 0x41D00000u + (idx & 0xFFFFFu), idx * 0x85EBCA77u, 0x41E00000u + (idx & 0xFFFFu)); e1 = make_uint4(idx * 3u, idx * 7u, idx * 11u, idx * 13u); }
+        else { e0 = table[2 * (uint64_t)idx]; e1 = table[2 * (uint64_t)idx + 1]; }
+        pending = count;
+    };
+    auto finish = [&]() {
+        if (!pending) return;
+        if (lane < pending) {
+            const double hd1 = __builtin_bit_cast(double, ((uint64_t)e0.y << 32) | e0.x), hd2 = __builtin_bit_cast(double, ((uint64_t)e0.w << 32) | e0.z);
+            const uint64_t ha = ((uint64_t)e1.w << 32) | e1.z;
+            uint32_t pos = mod_m_f64(hd1, e1.x, ninv, m);
+            const uint32_t step = mod_m_f64(hd2, e1.y, ninv, m);
+            for (uint32_t j = 0; j < fk; ++j) {
+                const uint32_t rel = pos - tile_bit0;              // unsigned: out-of-tile positions wrap high
+                if (rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
+                const uint32_t s2 = pos + step;
+                pos = min(s2, s2 - m);
+            }
+            const uint32_t rel = pos - tile_bit0;
+            if (ha < T && rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
+        }
+        pending = 0;
+    };
+
+    // my two bytes of wave step g as 16 bits in natural order (bit j = pixel 16 * lane + j of the step); rows are padded to
+    // 8 bytes, so the 2-byte load never leaves the row
+    auto load_bits = [&](uint64_t g) -> uint32_t {
+        const uint64_t byte = g * IT_STEP_BYTES + lane * 2;
+        if (g >= g1 || byte >= nbytes) return 0u;
+        const uint32_t v = *reinterpret_cast<const uint16_t *>(mask + byte);      // byte 0 = pixels 0..7 MSB-first, byte 1 = pixels 8..15
+        const uint32_t x = __builtin_bitreverse32(v) >> 16;                       // bits 8..15 = byte 0 reversed, bits 0..7 = byte 1 reversed
+        uint32_t b = ((x & 0xFFu) << 8) | (x >> 8);
+        const uint64_t rem = n - byte * 8;
+        if (rem < 16) b &= (1u << rem) - 1u;                      // ignore pad bits
+        return b;
+    };
+    uint32_t nxt = load_bits(g0 + wave);
+    for (uint64_t g = g0 + wave; g < g1; g += IL_WAVES) {
+        uint32_t bits = (IAB & 8) ? (nxt & 0u) : nxt;
+        nxt = load_bits(g + IL_WAVES);                             // prefetch
+        // exclusive prefix of the per-lane counts (0..16) without a cross-lane scan: one ballot per bit of the count
+        const uint32_t c = __popc(bits);
+        const uint64_t b0 = __ballot((c & 1u) != 0), b1 = __ballot((c & 2u) != 0), b2 = __ballot((c & 4u) != 0);
+        const uint64_t b3 = __ballot((c & 8u) != 0), b4 = __ballot((c & 16u) != 0);
+        const uint32_t excl = rank_below(b0) + 2u * rank_below(b1) + 4u * rank_below(b2) + 8u * rank_below(b3) + 16u * rank_below(b4);
+        const uint32_t total = __popcll(b0) + 2u * __popcll(b1) + 4u * __popcll(b2) + 8u * __popcll(b3) + 16u * __popcll(b4);
+        uint32_t off = qn + excl;
+        const uint32_t base = (uint32_t)((g * IT_STEP_BYTES + lane * 2) << 3);
+        while (bits) {
+            q[off++] = base + __builtin_ctz(bits);
+            bits &= bits - 1u;
+        }
+        qn += total;
+        wave_lds_fence();
+        while (qn >= WAVE) {                                       // full waves only; order is irrelevant (OR)
+            qn -= WAVE;
+            finish();
+            fetch(qn, WAVE);
+        }
+        wave_lds_fence();                                          // queue reads done before it is refilled
+    }
+    finish();
+    if (qn) { fetch(0, qn); finish(); }
+    __syncthreads();
+    uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;
+    const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
+    const uint32_t pairs = (IAB & 4) ? 1u : (mine + 1) >> 1;      // tile0 is even: 8-byte aligned
+    for (uint32_t i = threadIdx.x; i < pairs; i += IL_THREADS)
+        reinterpret_cast<uint2 *>(part)[i] = reinterpret_cast<const uint2 *>(filt)[i];
+}
+
+}  // namespace rbf

@@ -70,9 +70,15 @@ __device__ __forceinline__ uint32_t probe_image_word(uint32_t lds_base_bytes /* 
     return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
 }
 
-// Pixels [IT0, IT1) of one frame's pass over a lane's QL_P pixels.  pbf accumulates the lane's FAIL bits MSB-first
-// (after all parts: bit 7-j = pixel j failed), npass the wave's number of passing positions.  CHECK_VALID: lanes may
-// own positions past the end of the frame (validmask), which must fail; the common whole-wave case skips that.
+// One frame's pass over pixels [IT0, IT1) of a lane's QL_P pixels, software-pipelined by hand in groups of G pixels:
+//     positions(g) -> issue the group's LDS reads -> positions(g+1) -> combine(g) -> reads(g+1) ...
+// Left to itself hipcc emitted the pass pixel by pixel -- 13 VALU, three ds_reads, s_waitcnt, combine -- i.e. eight
+// exposed LDS round trips per frame and wave (profiles/r02_query_schedule.txt), which is what kept the VALU at ~25 % of
+// its issue rate with four waves per SIMD.  Here the reads of a group are in flight while the positions of the next
+// group are computed; __builtin_amdgcn_sched_barrier pins the phase order.
+// pbf accumulates the lane's FAIL bits MSB-first (after all parts: bit 7-j = pixel j failed), npass the wave's number
+// of passing positions.  CHECK_VALID: lanes may own positions past the end of the frame (validmask), which must fail;
+// the common whole-wave case skips that.
 // AB (ablation mask, tools/bench_query.hip only; 0 in the library): 1 = no reductions, 2 = no LDS probes, 4 = no ballot.
 template <int FK, int AB, bool CHECK_VALID, int IT0, int IT1>
 __device__ __forceinline__ void frame_part_f64(
@@ -80,25 +86,75 @@ __device__ __forceinline__ void frame_part_f64(
     const uint64_t (&ha)[QL_P], uint32_t validmask, uint32_t lds_base_bytes, uint32_t safe_pos, uint32_t m, double ninv, uint64_t T,
     uint32_t fk_rt, uint32_t &pbf, uint32_t &npass)
 {
-    const uint32_t fk = FK >= 0 ? (uint32_t)FK : fk_rt;
+    if constexpr (FK < 0) {                                       // runtime floor(k*): rare geometries, plain loop
 #pragma unroll
-    for (int it = IT0; it < IT1; ++it) {
-        uint32_t pos, step;
-        if (AB & 1) { pos = hl1[it] & 0x7FFFFu; step = hl2[it] & 0x3FFFFu; }
-        else { pos = mod_m_f64(hd1[it], hl1[it], ninv, m); step = mod_m_f64(hd2[it], hl2[it], ninv, m); }
-        uint32_t fail = CHECK_VALID ? ~(validmask << (31 - it)) & 0x80000000u : 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < fk; ++j) {
-            const uint32_t w = (AB & 2) ? (pos * 0x9E3779B1u) : probe_image_word<AB>(lds_base_bytes, pos);
-            fail = (w << (pos & 31u)) | fail;
-            const uint32_t s2 = pos + step;
-            pos = min(s2, s2 - m);
+        for (int it = IT0; it < IT1; ++it) {
+            uint32_t pos = mod_m_f64(hd1[it], hl1[it], ninv, m);
+            const uint32_t step = mod_m_f64(hd2[it], hl2[it], ninv, m);
+            uint32_t fail = CHECK_VALID ? ~(validmask << (31 - it)) & 0x80000000u : 0u;
+            for (uint32_t j = 0; j < fk_rt; ++j) {
+                fail = (probe_image_word<AB>(lds_base_bytes, pos) << (pos & 31u)) | fail;
+                const uint32_t s2 = pos + step;
+                pos = min(s2, s2 - m);
+            }
+            const uint32_t pc = (ha[it] < T) ? pos : safe_pos;
+            fail = (probe_image_word<AB>(lds_base_bytes, pc) << (pc & 31u)) | fail;
+            pbf = __builtin_amdgcn_alignbit(pbf, fail, 31);
+            if (!(AB & 4)) npass += __popcll(__ballot((int32_t)fail >= 0));
         }
-        const uint32_t pc = (ha[it] < T) ? pos : safe_pos;
-        const uint32_t w = (AB & 2) ? (pc * 0x85EBCA77u) : probe_image_word<AB>(lds_base_bytes, pc);
-        fail = (w << (pc & 31u)) | fail;
-        pbf = __builtin_amdgcn_alignbit(pbf, fail, 31);           // (pbf << 1) | (fail >> 31)
-        if (!(AB & 4) && !(AB & 16384)) npass += __popcll(__ballot((int32_t)fail >= 0));
+    } else {
+        constexpr int G = 2, NG = (IT1 - IT0) / G, NP = FK + 1;
+        static_assert((IT1 - IT0) % G == 0, "whole groups");
+        uint32_t pos[NG][G][NP], wrd[NG][G][NP];
+        auto positions = [&](int g) {
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const int it = IT0 + g * G + e;
+                uint32_t p, step;
+                if (AB & 1) { p = hl1[it] & 0x7FFFFu; step = hl2[it] & 0x3FFFFu; }
+                else { p = mod_m_f64(hd1[it], hl1[it], ninv, m); step = mod_m_f64(hd2[it], hl2[it], ninv, m); }
+#pragma unroll
+                for (int j = 0; j < FK; ++j) {
+                    pos[g][e][j] = p;
+                    const uint32_t s2 = p + step;
+                    p = min(s2, s2 - m);
+                }
+                pos[g][e][FK] = (ha[it] < T) ? p : safe_pos;      // the activated extra probe, or SAFE
+            }
+        };
+        auto loads = [&](int g) {
+#pragma unroll
+            for (int e = 0; e < G; ++e)
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    wrd[g][e][j] = (AB & 2) ? (pos[g][e][j] * 0x9E3779B1u) : probe_image_word<AB>(lds_base_bytes, pos[g][e][j]);
+        };
+        auto combine = [&](int g) {
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const int it = IT0 + g * G + e;
+                uint32_t fail = CHECK_VALID ? ~(validmask << (31 - it)) & 0x80000000u : 0u;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) fail = (wrd[g][e][j] << (pos[g][e][j] & 31u)) | fail;
+                pbf = __builtin_amdgcn_alignbit(pbf, fail, 31);   // (pbf << 1) | (fail >> 31)
+                if (!(AB & 4)) npass += __popcll(__ballot((int32_t)fail >= 0));
+            }
+        };
+        // P0 L0 | P1 C0 L1 | P2 C1 L2 | ... | C(last): the reads of group g fly while the positions of group g+1 are computed
+        positions(0);
+        __builtin_amdgcn_sched_barrier(0);
+        loads(0);
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            positions(g);
+            __builtin_amdgcn_sched_barrier(0);
+            combine(g - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            loads(g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        combine(NG - 1);
     }
 }
 
