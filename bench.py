@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--shared-gop", action="store_true", help="diagnostic: all pipelines read the SAME resident GOP (the round-1 setup; inputs then fit the Infinity Cache)")
     ap.add_argument("--lds-tile-kib", type=int, default=0, help="cap the LDS filter tile (KiB) -> tiled kernels; 0 = auto (BASELINE config 4 sweep)")
     ap.add_argument("--gather-every", type=int, default=16, help="N>1: steps whose records travel in one RCCL gather")
-    ap.add_argument("--hash-cache", action="store_true", help="keep the pixel-index hash table (k_hash_table) resident between steps instead of rebuilding it in every step")
+    ap.add_argument("--rebuild-hash-table", action="store_true", help="diagnostic: run k_hash_table in every step instead of taking the table the previous step's query kernel wrote")
     ap.add_argument("--generic-kernels", action="store_true", help="diagnostic: global-memory insert / query kernels instead of the LDS ones")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and gather) even with one rank (smoke-tests the N>1 path)")
@@ -115,9 +115,9 @@ def main():
     # neighbours, and (N > 1) the async RCCL gather of step s overlaps the kernels of step s+1.  Every step
     # still does all of its work inside the timed region.
     ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
-    if args.lds_tile_kib or args.generic_kernels or args.hash_cache:
+    if args.lds_tile_kib or args.generic_kernels or args.rebuild_hash_table:
         for c in ctxs:
-            c.force_generic(((args.lds_tile_kib * 1024 // 256) << 16) | (1 if args.generic_kernels else 0) | (16 if args.hash_cache else 0))      # tile unit: 64 dwords
+            c.force_generic(((args.lds_tile_kib * 1024 // 256) << 16) | (1 if args.generic_kernels else 0) | (16 if args.rebuild_hash_table else 0))      # tile unit: 64 dwords
     ctx = ctxs[0]
     arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
     coders = []
@@ -281,7 +281,8 @@ def main():
                    "distinct_gop_per_pipeline": not args.shared_gop, "resident_input_mb_per_gpu": round(resident_mb, 1),
                    "gather_bytes_per_rank_per_step": og.slot_words * 8 if gather else 0, "steps_per_gather": G if gather else 0,
                    "lds_tile_kib": args.lds_tile_kib or "auto", "generic_kernels": bool(args.generic_kernels),
-                   "hash_table": "kept resident between steps (--hash-cache)" if args.hash_cache else "rebuilt inside every step (k_hash_table is part of the timed work)",
+                   "hash_table": "k_hash_table runs in every step (--rebuild-hash-table)" if args.rebuild_hash_table else
+                                 "written in every step by that step's query kernel (which hashes every pixel index anyway) for the next step's insert kernel",
                    "stages": "residual mask -> host params -> insert -> query+witness",
                    "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by gloo world-2 tests and an nccl world-1 test"},
     }

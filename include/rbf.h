@@ -108,9 +108,9 @@ int rbf_timing_enable(rbf_ctx *ctx, int on);
 /* Testing knob (bit mask): bit 0 = always use the generic (global-memory filter) kernels;
  * bit 1 = LDS fast path without double-buffering the filter; bit 2 = per-pixel threshold compare in the
  * GOP mask kernel even for threshold 0; bit 3 = Barrett reductions only (never the FP64 h mod m of the query
- * kernel, which is taken when every filter of a batch has 2^15 <= m < 2^23); bit 4 = keep the pixel-index hash
- * table (k_hash_table, 32 bytes per pixel) resident between batches of the same frame size and seeds instead of
- * rebuilding it for every batch (it depends on neither the frames nor the filters); bit 5 = never use that table
+ * kernel, which is taken when every filter of a batch has 2^15 <= m < 2^23); bit 4 = run k_hash_table (the pixel-index
+ * hash table the insert kernel gathers from, 32 bytes per pixel) for every batch instead of taking the copy the previous
+ * batch's query kernel wrote while hashing the same indices for its own probes; bit 5 = never use that table
  * (the insert kernel hashes the set positions itself, as in ABI build 1).  0 (default) = pick the fastest
  * variant that fits: the LDS-resident path needs the batch's largest filter to fit in LDS. */
 int rbf_ctx_force_generic(rbf_ctx *ctx, int on);

@@ -57,7 +57,7 @@ struct rbf_ctx {
     uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
     int force_generic_mask_bits = 0; // tests: 1 = per-pixel threshold compare even for threshold 0
     int barrett_only = 0;            // tests/tuning: 1 = never take the FP64 reductions (mod_m_f64)
-    int hash_cache = 0;              // 1 = keep the hash table between batches of the same (n, seeds)
+    int hash_rebuild = 0;            // 1 = run k_hash_table for every batch instead of taking the table the last query kernel wrote
     int no_hash_table = 0;           // 1 = the insert kernel hashes the set positions itself
     uint4 *hash_tab = nullptr;       size_t hash_tab_cap = 0;     // k_hash_table output, 32 bytes per pixel
     uint64_t hash_tab_n = 0; rbf_seeds hash_tab_seeds{0, 0, 0}; bool hash_tab_valid = false;
@@ -263,9 +263,8 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->single_buffer = (on & 2) ? 1 : 0;
     ctx->force_generic_mask_bits = (on & 4) ? 1 : 0;
     ctx->barrett_only = (on & 8) ? 1 : 0;
-    ctx->hash_cache = (on & 16) ? 1 : 0;
+    ctx->hash_rebuild = (on & 16) ? 1 : 0;
     ctx->no_hash_table = (on & 32) ? 1 : 0;
-    if (!ctx->hash_cache) ctx->hash_tab_valid = false;
     ctx->mask_chunks = (uint32_t)(on >> 8) & 0xFF;           // tuning knob, bits 8..15
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
     return RBF_OK;
@@ -389,7 +388,7 @@ static inline uint64_t nseg_of(uint64_t n) { return (n + SEG_PIXELS - 1) / SEG_P
 constexpr size_t LDS_LIMIT = 160 * 1024;
 struct Plan {
     bool fast_insert;            // LDS partial-filter insert (any filter size, tiled when needed)
-    int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles
+    int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles (Barrett), 3 LDS tiles, FP64 (k_query_f64t)
     bool double_buffer, small_m;
     bool insert_tab;             // insert through the hash table + FP64 reductions (same size condition, any LDS fit)
     bool f64_mod;                // every coded frame has F64MOD_M_MIN <= m <= F64MOD_M_MAX: reductions through the FP64 pipe
@@ -476,10 +475,22 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
         p.slices.n[f] = (uint8_t)sf;
         p.per_tile += sf;
     }
-    if (p.query_kind != 1) p.f64_mod = false;                     // only the whole-filter LDS query kernel has the FP64 form
+    // FP64 geometries that do not fit LDS twice (or whose tile size a test caps): k_query_f64t, double-buffered tiles
+    if (!ctx->force_generic && mmax > 0 && sizes_f64 && !ctx->barrett_only && !ctx->single_buffer && !(p.query_kind == 1 && p.f64_mod)) {
+        const uint32_t cap = (uint32_t)(LDS_LIMIT / 4 - 4) & ~3u;            // one buffer of tile_words + 4 dwords
+        uint32_t tw = (p.fwords_max + 3u) & ~3u;
+        if (tw > cap) { const uint32_t nt = (p.fwords_max + cap - 1) / cap; tw = (((p.fwords_max + nt - 1) / nt) + 3u) & ~3u; }
+        if (ctx->tile_words && (ctx->tile_words & ~3u) < tw) tw = ctx->tile_words & ~3u;
+        if (tw < 4) tw = 4;
+        p.query_kind = 3;
+        p.query_tile_words = tw;
+        p.query_lds_bytes = (size_t)(tw + 4) * 4;
+        p.f64_mod = true;                                         // the probe image is needed
+    }
+    if (p.query_kind != 1 && p.query_kind != 3) p.f64_mod = false;
     p.insert_tab = p.fast_insert && sizes_f64 && !ctx->no_hash_table && !ctx->barrett_only;
     p.image_stride_words = (p.fwords_max + 3u) & ~3u;
-    const uint32_t segpx = p.query_kind == 1 ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
+    const uint32_t segpx = (p.query_kind == 1 || p.query_kind == 3) ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
     p.nseg = (n + segpx - 1) / segpx;
     p.words_per_seg = segpx / 64;
     return p;
@@ -609,9 +620,9 @@ static int ensure_image(rbf_ctx *ctx, const Plan &pl, uint32_t nframes)
 
 // image_ready: the probe image of this batch has already been written (k_filter_reduce does it on the encode side)
 static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nframes, const FrameTable &tab, const Seeds &sd,
-                        const void *filters_dev, uint64_t filter_stride_bytes, bool image_ready)
+                        const void *filters_dev, uint64_t filter_stride_bytes, bool image_ready, bool table_for_next = false)
 {
-    if (pl.query_kind == 1 && pl.f64_mod) {
+    if ((pl.query_kind == 1 || pl.query_kind == 3) && pl.f64_mod) {
         if (int r = ensure_image(ctx, pl, nframes)) return r;
         if (!image_ready) {
             uint32_t bx = (pl.image_stride_words + WG_THREADS - 1) / WG_THREADS;
@@ -621,7 +632,18 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         filters_dev = ctx->qimage;
         filter_stride_bytes = (uint64_t)pl.image_stride_words * 4;
     }
-    if (pl.query_kind == 1 && pl.f64_mod) {
+    if (pl.query_kind == 3) {
+        FrameTable qtab = tab;
+        for (uint32_t f = 0; f < nframes; ++f)
+            if (qtab.f[f].m) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
+        auto kern = k_query_f64t<0>;
+        if (int r = allow_big_lds((const void *)kern)) return r;
+        const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
+        LaunchTimer t(ctx, RBF_K_QUERY);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
+                           n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
+                           ctx->seg_cnt, pl.nseg, ctx->pass_words);
+    } else if (pl.query_kind == 1 && pl.f64_mod) {
         // k_query_f64 reads -1/m (IEEE double, computed here on the host) from the table's M field instead of the Barrett constant
         FrameTable qtab = tab;
         for (uint32_t f = 0; f < nframes; ++f)
@@ -630,9 +652,15 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         if (int r = allow_big_lds((const void *)kern)) return r;
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
+        // the kernel hashes every index anyway: it leaves the hash table of this geometry for the next batch's insert
+        uint4 *table_out = nullptr;
+        if (table_for_next && ctx->hash_tab && ctx->hash_tab_cap >= ((size_t)n + QL_SEG_PIXELS) * 32 && !ctx->no_hash_table) {
+            table_out = ctx->hash_tab;
+            ctx->hash_tab_n = n; ctx->hash_tab_seeds = rbf_seeds{sd.h1, sd.h2, sd.act}; ctx->hash_tab_valid = true;
+        }
         hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                            n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
-                           ctx->seg_cnt, pl.nseg, ctx->pass_words);
+                           ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
     } else if (pl.query_kind == 1) {
         auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<true, true> : k_query_lds<true, false>)
                                      : (pl.small_m ? k_query_lds<false, true> : k_query_lds<false, false>);
@@ -674,7 +702,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
-    const bool want_image = pl.query_kind == 1 && pl.f64_mod;       // the reduce kernel also writes the FP64 query kernel's probe image
+    const bool want_image = (pl.query_kind == 1 || pl.query_kind == 3) && pl.f64_mod;       // the reduce kernel also writes the FP64 query kernel's probe image
     if (want_image) if (int r = ensure_image(ctx, pl, nframes)) return r;
     uint32_t *image = want_image ? ctx->qimage : nullptr;
 
@@ -701,7 +729,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         if (use_tab) {
             const bool same = ctx->hash_tab_valid && ctx->hash_tab_n == n && ctx->hash_tab_seeds.h1 == seeds->h1 &&
                               ctx->hash_tab_seeds.h2 == seeds->h2 && ctx->hash_tab_seeds.act == seeds->act;
-            if (!(ctx->hash_cache && same)) {
+            if (ctx->hash_rebuild || !same) {
                 const uint64_t segs = (n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS;
                 LaunchTimer t(ctx, RBF_K_HASHTAB);
                 hipLaunchKernelGGL(k_hash_table, dim3((uint32_t)((segs + HT_THREADS / WAVE - 1) / (HT_THREADS / WAVE))), dim3(HT_THREADS), 0, ctx->stream,
@@ -770,7 +798,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         }
     }
     // ---- query: pass word of every 64 positions + per-segment pass counts
-    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, want_image)) return r;
+    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, want_image, pl.insert_tab)) return r;
     // ---- witness: pext(mask, pass) of every word lands at its bit offset (scan fused in)
     {
         const uint64_t words = pl.nseg * pl.words_per_seg;

@@ -1,7 +1,9 @@
 // rbf_kernels_i64.h -- the insert path for filters of 2^15 <= m < 2^23 bits (1080p / 2160p frames):
 //
-//   k_hash_table   the three XXH64 of EVERY pixel index of the frame geometry, once per batch (they depend on the index
-//                  and the seeds only, not on the frame: improved_video_compressor.py:77-78,94), stored in the form the
+//   k_hash_table   the three XXH64 of EVERY pixel index of the frame geometry (they depend on the index and the seeds
+//                  only, not on the frame: improved_video_compressor.py:77-78,94).  Runs for the FIRST batch of a
+//                  geometry; afterwards k_query_f64, which computes the same hashes for its own probes in every batch,
+//                  writes the table for the following batch's insert.  Stored in the form the
 //                  FP64 reduction wants -- 32 bytes per pixel: RN(h1), RN(h2) as doubles, the low dwords of h1 and
 //                  h2, and h_act.  A lane owns 8 consecutive indices, so the decade-prefix sharing of hash3_run8
 //                  applies (~120 instead of ~600 instructions per index), and over a 29-frame batch 93 % of all
@@ -43,33 +45,10 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash_table(uint64_t n, Seeds see
             h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
         }
     }
-    // A lane's 8 entries are 256 contiguous bytes of the table, so a plain store instruction would scatter 64 sixteen-byte
-    // pieces over 64 cache lines (measured: 37 us for the 66 MB of a 1080p table).  The wave's entries go through LDS in
-    // two halves of 4 pixels (lane pitch 144 bytes: conflict-free 16-byte writes) and leave as whole 128-byte lines, 8
-    // lines per store instruction.  Entries past the end of the frame are written too (the table is padded to whole
-    // segments): they are never read.
-    __shared__ __attribute__((aligned(16))) uint32_t stage[(HT_THREADS / WAVE) * 64 * 36];
-    uint32_t *mine = stage + wave * (64 * 36);
-    uint8_t *out = reinterpret_cast<uint8_t *>(table) + seg * (uint64_t)QL_SEG_PIXELS * 32;
+    // slot-major inside the segment (hash_table_slot): every store pair of the wave covers 2 KiB contiguously.  Entries past
+    // the end of the frame are written too (the table is padded to whole segments): they are never read.
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int it = half * 4 + e;
-            const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h1[it]), d2 = __builtin_bit_cast(uint64_t, (double)h2[it]);
-            uint4 *dst = reinterpret_cast<uint4 *>(mine + lane * 36 + e * 8);
-            dst[0] = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));
-            dst[1] = make_uint4((uint32_t)h1[it], (uint32_t)h2[it], (uint32_t)ha[it], (uint32_t)(ha[it] >> 32));
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const uint32_t L = r * 8 + (lane >> 3), piece = lane & 7u;            // 8 lanes move the 128 bytes of lane L's half
-            const uint4 v = *reinterpret_cast<const uint4 *>(mine + L * 36 + piece * 4);
-            *reinterpret_cast<uint4 *>(out + (uint64_t)(L * 8 + half * 4) * 32 + piece * 16) = v;
-        }
-        wave_lds_fence();
-    }
+    for (int it = 0; it < QL_P; ++it) hash_table_store(table, seg, lane, it, h1[it], h2[it], ha[it]);
 }
 
 constexpr int IT_STEP_BYTES = 128;                 // mask bytes per wave step: a lane owns 16 pixels (two bytes)
@@ -124,7 +103,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     auto fetch = [&](uint32_t first, uint32_t count) {
         const uint32_t idx = lane < count ? q[first + lane] : 0u;  // idle lanes read entry 0 (always there)
         if (IAB & 1) { e0 = make_uint4(idx * 0x9E3779B1u, 0x41D00000u + (idx & 0xFFFFFu), idx * 0x85EBCA77u, 0x41E00000u + (idx & 0xFFFFu)); e1 = make_uint4(idx * 3u, idx * 7u, idx * 11u, idx * 13u); }
-        else { e0 = table[2 * (uint64_t)idx]; e1 = table[2 * (uint64_t)idx + 1]; }
+        else { const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = table[2 * slot + 1]; }
         pending = count;
     };
     auto finish = [&]() {

@@ -158,6 +158,22 @@ __device__ __forceinline__ void frame_part_f64(
     }
 }
 
+// The pixel-index hash table (32 bytes per index: RN(h1), RN(h2) as doubles | low dwords of h1, h2 | h_act) that
+// k_insert_tab gathers from (rbf_kernels_i64.h).  Inside a 512-index segment the entries are stored SLOT-MAJOR -- the
+// entry of index seg * 512 + lane * 8 + it sits at seg * 512 + it * 64 + lane -- because that is the order in which the
+// kernels that produce it (a lane owns 8 consecutive indices) can store it with fully coalesced 2 KiB wave stores.
+__device__ __forceinline__ uint32_t hash_table_slot(uint32_t index)
+{
+    return (index & ~511u) | ((index & 7u) << 6) | ((index >> 3) & 63u);
+}
+__device__ __forceinline__ void hash_table_store(uint4 *__restrict__ table, uint64_t seg, uint32_t lane, int it, uint64_t h1, uint64_t h2, uint64_t ha)
+{
+    const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h1), d2 = __builtin_bit_cast(uint64_t, (double)h2);
+    uint4 *e = table + 2 * (seg * QL_SEG_PIXELS + (uint32_t)it * 64u + lane);
+    e[0] = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));
+    e[1] = make_uint4((uint32_t)h1, (uint32_t)h2, (uint32_t)ha, (uint32_t)(ha >> 32));
+}
+
 // Timeline probe (tools/bench_query.hip only, AB & 1024): wave 0 and the last wave of the first workgroups record the
 // shader clock at the phases of every frame iteration into this buffer ([wg][wave 0 / last][frame][phase]).
 __device__ uint64_t *g_query_timeline = nullptr;
@@ -178,7 +194,8 @@ template <int AB = 0, int PARTS = Q64_PARTS>
 __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
     uint64_t n, uint32_t nframes, const FrameTable tab, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t fwords_max,
-    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words)
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words,
+    uint4 *__restrict__ table_out /* nullable: write the hash table of the frame geometry for the NEXT batch's insert kernel */)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // two buffers; each ends with 4 dwords that no DMA touches, the first of which stays 0 (SAFE)
@@ -220,6 +237,13 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
         for (int it = 0; it < QL_P; ++it) {
             hd1[it] = (double)h1[it]; hl1[it] = (uint32_t)h1[it];
             hd2[it] = (double)h2[it]; hl2[it] = (uint32_t)h2[it];
+        }
+        // The hashes depend on the index and the seeds only, and this kernel has just computed them for every index of
+        // the frame: they are handed to the next batch's insert kernel (same geometry, same values) instead of being
+        // computed a second time by k_hash_table.  64 lanes x 32 bytes per store pair: whole 2 KiB runs.
+        if (table_out && live) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) hash_table_store(table_out, seg, lane, it, h1[it], h2[it], ha[it]);
         }
     }
     const bool whole_wave = __builtin_amdgcn_readfirstlane((uint32_t)__all(validmask == 0xFFu)) != 0u;   // every lane owns 8 positions inside the frame
@@ -344,6 +368,204 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
         cur ^= 1u;
     }
     flush_held();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_query_f64t -- the same kernel for filters that do not fit LDS twice (2160p: 306 KB; up to m < 2^23 bits = 1 MiB):
+// the probe image is walked in TILES of `tile_words` dwords.  Per frame the two reductions of a pixel are done once (pos0, step stay in
+// registers); per tile every probe position is rebuilt by stepping (3 cheap instructions) and redirected to the tile's
+// SAFE dword unless it falls into the tile: word index relative to the tile, unsigned min against tile_words -- one
+// instruction for "in this tile?" and the redirect.  A pixel whose extra probe is not activated gets position 2^32 - 1
+// for it, which is in no tile.  Replaces k_query_tiled's scheme (single buffer: stage, wait, probe; per-pixel hashing;
+// Barrett reductions; two compares + two selects per probe and tile) for every geometry the FP64 reduction covers.
+// ------------------------------------------------------------------------------------------------------------------
+template <int FK, int AB>
+__device__ __forceinline__ void tile_part_f64(const uint32_t (&pos0)[QL_P], const uint32_t (&step)[QL_P], uint32_t notact /* bit it: no extra probe */,
+                                              uint32_t lds_base_bytes, uint32_t tile_word0, uint32_t tile_words, uint32_t m, uint32_t fk_rt,
+                                              uint32_t (&fail)[QL_P])
+{
+    const uint32_t fk = FK >= 0 ? (uint32_t)FK : fk_rt;
+    auto probe = [&](uint32_t p) -> uint32_t {                    // image word of position p if it lies in this tile, else the SAFE dword (0)
+        const uint32_t idx = min((p >> 5) - tile_word0, tile_words);
+        const uint32_t w = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)((idx << 2) + lds_base_bytes));
+        return w << (p & 31u);
+    };
+    if constexpr (FK < 0) {
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            uint32_t p = pos0[it];
+            for (uint32_t j = 0; j < fk; ++j) {
+                fail[it] |= probe(p);
+                const uint32_t s2 = p + step[it];
+                p = min(s2, s2 - m);
+            }
+            fail[it] |= probe(p | (uint32_t)(((int32_t)(notact << (31 - it))) >> 31));
+        }
+    } else {
+        constexpr int G = 2, NG = QL_P / G, NP = FK + 1;
+        uint32_t pp[NG][G][NP], wrd[NG][G][NP];
+        auto positions = [&](int g) {
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const int it = g * G + e;
+                uint32_t p = pos0[it];
+                // opaque per tile: otherwise the compiler hoists all (FK + 1) * 8 positions and shifts out of the tile loop
+                // (48 registers that are live across it, and the kernel spills); stepping again per tile costs 3 instructions
+                asm volatile("" : "+v"(p));
+#pragma unroll
+                for (int j = 0; j < FK; ++j) {
+                    pp[g][e][j] = p;
+                    const uint32_t s2 = p + step[it];
+                    p = min(s2, s2 - m);
+                }
+                pp[g][e][FK] = p | (uint32_t)(((int32_t)(notact << (31 - it))) >> 31);
+            }
+        };
+        auto loads = [&](int g) {
+#pragma unroll
+            for (int e = 0; e < G; ++e)
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const uint32_t idx = min((pp[g][e][j] >> 5) - tile_word0, tile_words);
+                    wrd[g][e][j] = (AB & 2) ? idx : *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)((idx << 2) + lds_base_bytes));
+                }
+        };
+        auto combine = [&](int g) {
+#pragma unroll
+            for (int e = 0; e < G; ++e)
+#pragma unroll
+                for (int j = 0; j < NP; ++j) fail[g * G + e] = (wrd[g][e][j] << (pp[g][e][j] & 31u)) | fail[g * G + e];
+        };
+        positions(0);
+        __builtin_amdgcn_sched_barrier(0);
+        loads(0);
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            positions(g);
+            __builtin_amdgcn_sched_barrier(0);
+            combine(g - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            loads(g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        combine(NG - 1);
+    }
+}
+
+template <int AB = 0>
+__global__ __launch_bounds__(QL_THREADS) void k_query_f64t(
+    uint64_t n, uint32_t nframes, const FrameTable tab /* M = bits of -1/m */, Seeds seeds,
+    const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t tile_words /* multiple of 4; tile_words + 4 dwords of LDS */,
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // ONE buffer of tile_words dwords + the SAFE dword (kept 0): measured, the LDS-DMA of a tile does not hide under the
+    // probes of another one (it adds, see k_query_f64), while every (frame, tile) stage costs ~3 500 cycles of barriers and
+    // DMA issue on top of its probes -- so the tiles are as large as LDS allows and there are as few stages as possible
+    // (2160p: 2 per frame; double-buffered 76 KB tiles, 4 per frame, were 2.4x slower).
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    const bool live = seg < nseg;
+    if (threadIdx.x < 4u) lds[tile_words + threadIdx.x] = 0u;
+
+    // the hashes stay 64-bit integers here (6 registers per pixel instead of 8: this kernel also keeps pos0, step and fail
+    // per pixel) and are converted to the FP64 reduction's (double, low dword) form once per frame, not per tile
+    uint64_t h1[QL_P], h2[QL_P], ha[QL_P];
+    uint32_t validmask = 0;
+    const uint64_t i0 = seg * QL_SEG_PIXELS + (uint64_t)lane * QL_P;
+    {
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
+            if (live && i0 + it < n) validmask |= 1u << it;
+        }
+        if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) {
+                const bool act = (validmask >> it) & 1u;
+                const Hash3 h = hash3_index((uint32_t)(i0 + it), act, seeds);
+                h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
+            }
+        }
+    }
+    // invalid positions (past the end of the frame, or a dead wave) must fail: their verdict bits are forced afterwards
+    uint32_t invalid_byte = 0;                                    // bit 7-j: pixel j is not a position of the frame
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) invalid_byte |= ((validmask >> it) & 1u) ? 0u : (0x80u >> it);
+    uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
+
+    for (uint32_t g = 0; g < nframes; ++g) {
+        if (tab.f[g].m == 0) {
+            if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
+            if (live) pass_bytes[((uint64_t)g * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = 0;
+        }
+    }
+    auto next_active = [&](uint32_t k) -> uint32_t { while (k < nframes && tab.f[k].m == 0) ++k; return k; };
+    auto stage_dma = [&](uint32_t f, uint32_t fwords, uint32_t t) {                     // tile t of frame f -> LDS
+        const uint32_t w0 = t * tile_words;
+        const uint32_t words = fwords - w0 < tile_words ? fwords - w0 : tile_words;
+        if (!(AB & 8)) dma_filter(lds, image + (uint64_t)f * image_stride_words32 + w0, words, wave, lane, nwaves);
+    };
+    uint32_t f = __builtin_amdgcn_readfirstlane(next_active(0));
+    if (f >= nframes) return;
+    uint32_t fwords = __builtin_amdgcn_readfirstlane(filter_words(tab.f[f].m));
+    uint32_t ntiles = (fwords + tile_words - 1) / tile_words;
+    const uint32_t fbase = vgpr_copy(__builtin_amdgcn_readfirstlane(lds_addr_of(lds)));
+
+    while (f < nframes) {
+        // ---- per frame: the two reductions of every pixel, once
+        const FrameDev fd = tab.f[f];
+        const uint32_t m_s = __builtin_amdgcn_readfirstlane(fd.m);
+        const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
+        const uint32_t m_v = vgpr_copy(m_s);
+        // (__builtin_amdgcn_readfirstlane returns int: every half goes through uint32_t, or the low one sign-extends into the high one)
+        const uint32_t nhi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32)), nlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.M);
+        const uint32_t thi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.T >> 32)), tlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.T);
+        const double ninv = __builtin_bit_cast(double, ((uint64_t)nhi << 32) | nlo);
+        const uint64_t T = ((uint64_t)thi << 32) | tlo;
+        uint32_t pos0[QL_P], step[QL_P], fail[QL_P];
+        uint32_t notact = 0;
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            pos0[it] = mod_m_f64((double)h1[it], (uint32_t)h1[it], ninv, m_v);
+            step[it] = mod_m_f64((double)h2[it], (uint32_t)h2[it], ninv, m_v);
+            notact |= (ha[it] < T) ? 0u : (1u << it);
+            fail[it] = 0;
+        }
+        const uint32_t fnext = __builtin_amdgcn_readfirstlane(next_active(f + 1));
+        const uint32_t fwords_next = fnext < nframes ? __builtin_amdgcn_readfirstlane(filter_words(tab.f[fnext].m)) : 0u;
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            if (!(AB & 32)) __syncthreads();      // the previous stage's probes are done
+            stage_dma(f, fwords, t);
+            if (!(AB & 32)) {
+                dma_wait_all();                   // my share has landed ...
+                __syncthreads();                  // ... and everyone's
+            }
+            const uint32_t w0 = t * tile_words;
+            switch (fk) {
+            case 1: tile_part_f64<1, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
+            case 2: tile_part_f64<2, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
+            case 3: tile_part_f64<3, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
+            default: tile_part_f64<-1, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
+            }
+        }
+        // ---- verdicts of the frame
+        uint32_t pbf = 0, npass = 0;
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) pbf = __builtin_amdgcn_alignbit(pbf, fail[it], 31);
+        const uint32_t pb = ~(pbf | invalid_byte) & 0xFFu;
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) npass += __popcll(__ballot(((pb >> (7 - it)) & 1u) != 0));
+        if (!(AB & 64) && live) {
+            pass_bytes[((uint64_t)f * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)pb;
+            if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
+        }
+        f = fnext;
+        fwords = fwords_next;
+        ntiles = (fwords + tile_words - 1) / tile_words;
+    }
 }
 
 }  // namespace rbf

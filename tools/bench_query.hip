@@ -8,6 +8,7 @@
 using namespace rbf;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
+static uint4 *g_table_out = nullptr;            // k_query_f64: also write the hash table (nullptr = do not)
 static const uint32_t *g_image = nullptr;       // probe image (~bswap of every filter dword), same row pitch as the filters
 template <int AB, bool DB = true, int THREADS = QL_THREADS, int MODK = 0, int PARTS = 1>
 static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F, const FrameTable &tab, Seeds sd, const uint32_t *filters,
@@ -18,19 +19,22 @@ static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F
         filters = g_image; lds += 32;
         for (uint32_t f = 0; f < F; ++f) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
     }
-    void (*kern)(uint64_t, uint32_t, const FrameTable, Seeds, const uint32_t *, uint64_t, uint32_t, uint32_t *, uint64_t, uint64_t *);
-    if constexpr (MODK == 1) kern = k_query_f64<AB, PARTS>; else kern = k_query_lds<DB, true, AB>;
+    auto launch = [&](dim3 g, dim3 b, size_t sh, hipStream_t st, uint64_t n_, uint32_t F_, const FrameTable &t_, Seeds s_, const uint32_t *f_, uint64_t fs_, uint32_t fw_, uint32_t *sc_, uint64_t ns_, uint64_t *pw_) {
+        if constexpr (MODK == 1) k_query_f64<AB, PARTS><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out);
+        else k_query_lds<DB, true, AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_);
+    };
+    const void *kern = MODK == 1 ? (const void *)k_query_f64<AB, PARTS> : (const void *)k_query_lds<DB, true, AB>;
     uint64_t *pwords = (uint64_t *)seg_bits;
-    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const uint32_t bx = (uint32_t)((nseg + THREADS / 64 - 1) / (THREADS / 64));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int w = 0; w < 2; ++w)
-        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, n, F, qtab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
+        launch(dim3(bx), dim3(THREADS), lds, 0, n, F, qtab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
     const int R = 10;
     for (int r = 0; r < R; ++r)
-        hipLaunchKernelGGL(kern, dim3(bx), dim3(THREADS), lds, 0, n, F, qtab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
+        launch(dim3(bx), dim3(THREADS), lds, 0, n, F, qtab, sd, filters, fstride, fwmax, seg_cnt, nseg, pwords);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return ms / R * 1000.f;
@@ -72,6 +76,8 @@ int main()
         printf("fp64-mod kernel vs Barrett kernel: %zu differing pass bytes, %zu differing segment counts (%llu passes)\n", diff, dc, (unsigned long long)passes);
     }
 #define RUNP(AB, TH, PARTS, what) printf("%-60s %8.1f us\n", "[fp64 mod] " what, run<AB, true, TH, 1, PARTS>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+    { uint4 *t; CK(hipMalloc(&t, (n + 512) * 32)); g_table_out = t; RUNP(0, 1024, 1, "full kernel + hash table written for the next batch"); g_table_out = nullptr; CK(hipFree(t)); }
+    RUNP(0, 1024, 1, "full kernel (again, no table)");
     RUNP(8 | 32 | 2048, 1024, 1, "pure passes (A): and/add addressing, ballots");
     RUNP(8 | 32 | 2048 | 8192, 1024, 1, "pure passes (B): lshr + lshl_add addressing");
     RUNP(8 | 32 | 2048 | 16384, 1024, 1, "pure passes (C): count by popc + wave reduction");
