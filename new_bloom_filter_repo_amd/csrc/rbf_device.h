@@ -248,6 +248,39 @@ __device__ __forceinline__ bool hash3_run8(uint32_t v0, uint32_t valid, const Se
     return false;
 }
 
+// Hashes of v0 + j, j = 0..3 (a lane of k_query_p4 owns 4 consecutive indices): the same decade-prefix sharing as
+// hash3_run8 -- a run of 4 touches at most two decades.  Returns false (nothing written) when the wave cannot take the
+// shared-prefix path; the caller then hashes index by index.
+template <int LEN>
+__device__ __forceinline__ void hash3_run4_fixed(uint32_t v0, const Seeds &s, uint64_t (&h1)[4], uint64_t (&h2)[4], uint64_t (&ha)[4])
+{
+    const uint32_t decade = v0 / 10u, r0 = v0 - decade * 10u;
+    const Prefix3 a = hash3_decade_prefix<LEN>(decade, s);
+    const Prefix3 b = hash3_decade_prefix<LEN>(decade + 1u, s);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t t = r0 + (uint32_t)j;
+        const bool in_b = t >= 10u;
+        const uint64_t term = (uint64_t)(0x30u + (in_b ? t - 10u : t)) * P5;
+        h1[j] = xxh64_last_byte(in_b ? b.h1 : a.h1, term);
+        h2[j] = xxh64_last_byte(in_b ? b.h2 : a.h2, term);
+        ha[j] = xxh64_last_byte(in_b ? b.ha : a.ha, term);
+    }
+}
+
+__device__ __forceinline__ bool hash3_run4(uint32_t v0, uint32_t valid, const Seeds &s, uint64_t (&h1)[4], uint64_t (&h2)[4], uint64_t (&ha)[4])
+{
+    const bool active = valid != 0u;
+    const uint32_t v3 = v0 + 3u;
+    const bool in7 = v0 >= 1000000u && v3 < 10000000u;
+    const bool in6 = v0 >= 100000u && v3 < 1000000u;
+    const bool in5 = v0 >= 10000u && v3 < 100000u;
+    if (__all(!active || in7)) { hash3_run4_fixed<7>(active ? v0 : 1000000u, s, h1, h2, ha); return true; }
+    if (__all(!active || in6)) { hash3_run4_fixed<6>(active ? v0 : 100000u, s, h1, h2, ha); return true; }
+    if (__all(!active || in5)) { hash3_run4_fixed<5>(active ? v0 : 10000u, s, h1, h2, ha); return true; }
+    return false;
+}
+
 // h mod m, exact, via Barrett with M = floor(2^64/m): q in {floor(h/m)-1, floor(h/m)}.
 __device__ __forceinline__ uint32_t mod_m(uint64_t h, uint32_t m, uint64_t M)
 {

@@ -569,3 +569,199 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64t(
 }
 
 }  // namespace rbf
+
+namespace rbf {
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_query_p4 -- k_query_f64 re-cut for OCCUPANCY: a lane owns 4 consecutive pixels instead of 8, which halves the
+// per-lane hash state (32 registers), lets the kernel live in 64 VGPRs = 8 waves per SIMD, and lets TWO 1024-thread
+// workgroups share a CU, each with its own single LDS buffer (76 KB + SAFE for a 1080p filter).
+// Why: the frame pass is latency-bound -- measured on k_query_f64, pure frame passes take 144 / 95 / 74 us at 1 / 2 / 4
+// waves per SIMD (T ~ 52 + 114 / waves us), and 4 is all that 8 pixels per lane (117 VGPRs) allow -- and the staging of a
+// filter (~1 200 cycles of the CU's vector-memory front end) does not hide under the same workgroup's probes.  With two
+// independent workgroups per CU one stages while the other probes, and within a workgroup the reductions of the NEXT
+// frame (which need no filter) run between the DMA issue and its completion.
+// Outputs: pass bytes in the same packed order; the segment (the unit of seg_cnt) is a wave's 256 pixels.
+// MEASURED (tools/bench_query.hip, 1080p x 29): 112 us against k_query_f64's 104 us -- pure frame passes 79 us in both.
+// Eight waves per SIMD buy nothing: per pixel the kernel issues ~30 % more instructions (loop, barrier, DMA issue, stores
+// and ballots are per wave and frame, and a wave now carries half the pixels), and that cancels what the occupancy
+// gains.  Kept selectable (rbf_ctx_force_generic bit 6) and parity-tested; k_query_f64 stays the default.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int P4_P = 4;                            // pixels per lane
+constexpr int P4_SEG_PIXELS = P4_P * WAVE;         // 256
+
+template <int FK, int AB>
+__device__ __forceinline__ void p4_positions(const double (&hd1)[P4_P], const uint32_t (&hl1)[P4_P], const double (&hd2)[P4_P], const uint32_t (&hl2)[P4_P],
+                                             const uint64_t (&ha)[P4_P], uint32_t safe_pos, uint32_t m, double ninv, uint64_t T, uint32_t (&pos)[P4_P][FK + 1])
+{
+#pragma unroll
+    for (int it = 0; it < P4_P; ++it) {
+        uint32_t p, step;
+        if (AB & 1) { p = hl1[it] & 0x7FFFFu; step = hl2[it] & 0x3FFFFu; }
+        else { p = mod_m_f64(hd1[it], hl1[it], ninv, m); step = mod_m_f64(hd2[it], hl2[it], ninv, m); }
+#pragma unroll
+        for (int j = 0; j < FK; ++j) {
+            pos[it][j] = p;
+            const uint32_t s2 = p + step;
+            p = min(s2, s2 - m);
+        }
+        pos[it][FK] = (ha[it] < T) ? p : safe_pos;
+    }
+}
+
+template <int FK, int AB>
+__device__ __forceinline__ uint32_t p4_probe(const uint32_t (&pos)[P4_P][FK + 1], uint32_t lds_base_bytes, uint32_t invalid_nibble, uint32_t &npass)
+{
+    uint32_t w[P4_P][FK + 1];
+#pragma unroll
+    for (int it = 0; it < P4_P; ++it)
+#pragma unroll
+        for (int j = 0; j <= FK; ++j) w[it][j] = (AB & 2) ? pos[it][j] * 0x9E3779B1u : probe_image_word<AB>(lds_base_bytes, pos[it][j]);
+    uint32_t nib = 0;                                             // bit 3-it: pixel `it` FAILED
+#pragma unroll
+    for (int it = 0; it < P4_P; ++it) {
+        uint32_t fail = 0;
+#pragma unroll
+        for (int j = 0; j <= FK; ++j) fail = (w[it][j] << (pos[it][j] & 31u)) | fail;
+        nib = __builtin_amdgcn_alignbit(nib, fail, 31);
+    }
+    nib |= invalid_nibble;
+    const uint32_t pass = ~nib & 0xFu;
+    if (!(AB & 4)) {
+#pragma unroll
+        for (int it = 0; it < P4_P; ++it) npass += __popcll(__ballot(((pass >> (3 - it)) & 1u) != 0));
+    }
+    return pass;
+}
+
+template <int AB = 0>
+__global__ __launch_bounds__(QL_THREADS, 8) void k_query_p4(
+    uint64_t n, uint32_t nframes, const FrameTable tab /* M = bits of -1/m */, Seeds seeds,
+    const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t fwords_max,
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg /* of 256 pixels */, uint64_t *__restrict__ pass_words,
+    uint4 *__restrict__ table_out /* nullable, see k_query_f64 */)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t safe_word = (fwords_max + 3u) & ~3u;           // one buffer; the dword after it stays 0 (SAFE)
+    const uint32_t safe_pos = safe_word << 5;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    const bool live = seg < nseg;
+    if (threadIdx.x < 4u) lds[safe_word + threadIdx.x] = 0u;
+
+    double hd1[P4_P], hd2[P4_P];
+    uint32_t hl1[P4_P], hl2[P4_P];
+    uint64_t ha[P4_P];
+    uint32_t validmask = 0;
+    const uint64_t i0 = seg * P4_SEG_PIXELS + (uint64_t)lane * P4_P;
+    {
+        uint64_t h1[P4_P], h2[P4_P];
+#pragma unroll
+        for (int it = 0; it < P4_P; ++it) {
+            h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
+            if (live && i0 + it < n) validmask |= 1u << it;
+        }
+        if (AB & 16) {
+#pragma unroll
+            for (int it = 0; it < P4_P; ++it) { h1[it] = (i0 + it) * P1; h2[it] = (i0 + it) * P2 + seeds.h2; ha[it] = (i0 + it) * P3; }
+        } else if (!hash3_run4((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+#pragma unroll
+            for (int it = 0; it < P4_P; ++it) {
+                const bool act = (validmask >> it) & 1u;
+                const Hash3 h = hash3_index((uint32_t)(i0 + it), act, seeds);
+                h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < P4_P; ++it) {
+            hd1[it] = (double)h1[it]; hl1[it] = (uint32_t)h1[it];
+            hd2[it] = (double)h2[it]; hl2[it] = (uint32_t)h2[it];
+        }
+        if (table_out && live) {                                  // slot-major inside the 512-index segment (hash_table_slot)
+#pragma unroll
+            for (int it = 0; it < P4_P; ++it) {
+                const uint32_t idx = (uint32_t)(i0 + it);
+                const uint64_t d1 = __builtin_bit_cast(uint64_t, hd1[it]), d2 = __builtin_bit_cast(uint64_t, hd2[it]);
+                uint4 *e = table_out + 2 * (uint64_t)hash_table_slot(idx);
+                e[0] = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));
+                e[1] = make_uint4(hl1[it], hl2[it], (uint32_t)ha[it], (uint32_t)(ha[it] >> 32));
+            }
+        }
+    }
+    uint32_t invalid_nibble = 0;
+#pragma unroll
+    for (int it = 0; it < P4_P; ++it) invalid_nibble |= ((validmask >> it) & 1u) ? 0u : (8u >> it);
+    uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
+    const uint64_t seg_bytes = P4_SEG_PIXELS / 8;                 // 32 bytes of verdicts per wave and frame
+
+    for (uint32_t g = 0; g < nframes; ++g) {
+        if (tab.f[g].m == 0) {
+            if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
+            if (live && lane < seg_bytes) pass_bytes[((uint64_t)g * nseg + seg) * seg_bytes + lane] = 0;
+        }
+    }
+    auto next_active = [&](uint32_t k) -> uint32_t { while (k < nframes && tab.f[k].m == 0) ++k; return k; };
+    const uint32_t fbase = vgpr_copy(__builtin_amdgcn_readfirstlane(lds_addr_of(lds)));
+    uint32_t f = __builtin_amdgcn_readfirstlane(next_active(0));
+    while (f < nframes) {
+        const FrameDev fd = tab.f[f];
+        const uint32_t m_s = __builtin_amdgcn_readfirstlane(fd.m);
+        const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
+        const uint32_t nhi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32)), nlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.M);
+        const uint32_t thi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.T >> 32)), tlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.T);
+        const double ninv = __builtin_bit_cast(double, ((uint64_t)nhi << 32) | nlo);
+        const uint64_t T = ((uint64_t)thi << 32) | tlo;
+        const uint32_t m_v = vgpr_copy(m_s);
+        if (!(AB & 32)) __syncthreads();                          // everyone is done probing the previous filter
+        if (!(AB & 8)) dma_filter(lds, image + (uint64_t)f * image_stride_words32, filter_words(m_s), wave, lane, nwaves);
+        // the reductions need no filter: they run while the DMA flies (and while the CU's other workgroup probes)
+        uint32_t npass = 0, pass;
+#define RBF_P4_FRAME(FKV)                                                                                          \
+        do {                                                                                                       \
+            uint32_t pos[P4_P][FKV + 1];                                                                           \
+            p4_positions<FKV, AB>(hd1, hl1, hd2, hl2, ha, safe_pos, m_v, ninv, T, pos);                            \
+            if (!(AB & 32)) { dma_wait_all(); __syncthreads(); }                                                   \
+            pass = p4_probe<FKV, AB>(pos, fbase, invalid_nibble, npass);                                           \
+        } while (0)
+        switch (fk) {
+        case 0: RBF_P4_FRAME(0); break;
+        case 1: RBF_P4_FRAME(1); break;
+        case 2: RBF_P4_FRAME(2); break;
+        case 3: RBF_P4_FRAME(3); break;
+        case 4: RBF_P4_FRAME(4); break;
+        case 5: RBF_P4_FRAME(5); break;
+        default: {                                                // floor(k*) > 5 (p < 1.2 %): stepping inside the probe loop
+            if (!(AB & 32)) { dma_wait_all(); __syncthreads(); }
+            uint32_t nib = 0;
+#pragma unroll
+            for (int it = 0; it < P4_P; ++it) {
+                uint32_t p = mod_m_f64(hd1[it], hl1[it], ninv, m_v);
+                const uint32_t step = mod_m_f64(hd2[it], hl2[it], ninv, m_v);
+                uint32_t fail = 0;
+                for (uint32_t j = 0; j < fk; ++j) {
+                    fail = (probe_image_word<AB>(fbase, p) << (p & 31u)) | fail;
+                    const uint32_t s2 = p + step;
+                    p = min(s2, s2 - m_v);
+                }
+                const uint32_t pc = (ha[it] < T) ? p : safe_pos;
+                fail = (probe_image_word<AB>(fbase, pc) << (pc & 31u)) | fail;
+                nib = __builtin_amdgcn_alignbit(nib, fail, 31);
+            }
+            pass = ~(nib | invalid_nibble) & 0xFu;
+#pragma unroll
+            for (int it = 0; it < P4_P; ++it) npass += __popcll(__ballot(((pass >> (3 - it)) & 1u) != 0));
+        } break;
+        }
+#undef RBF_P4_FRAME
+        // a byte of the packed pass vector = the nibbles of an even lane (pixels 8j .. 8j+3) and its odd neighbour
+        const uint32_t other = (uint32_t)__shfl_xor((int)pass, 1);
+        if (!(AB & 64) && live) {
+            if (!(lane & 1u)) pass_bytes[((uint64_t)f * nseg + seg) * seg_bytes + (lane >> 1)] = (uint8_t)((pass << 4) | other);
+            if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
+        }
+        f = __builtin_amdgcn_readfirstlane(next_active(f + 1));
+    }
+}
+
+}  // namespace rbf

@@ -40,6 +40,27 @@ static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F
     return ms / R * 1000.f;
 }
 
+template <int AB, int THREADS = 1024>
+static float run_p4(uint64_t n, uint32_t F, const FrameTable &tab, Seeds sd, uint64_t fstride, uint32_t fwmax, uint32_t *seg_cnt, uint64_t *pwords)
+{
+    auto kern = k_query_p4<AB>;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FrameTable qtab = tab;
+    for (uint32_t f = 0; f < F; ++f) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
+    const uint64_t nseg = (n + P4_SEG_PIXELS - 1) / P4_SEG_PIXELS;
+    const uint32_t bx = (uint32_t)((nseg + THREADS / 64 - 1) / (THREADS / 64));
+    const size_t lds = (size_t)(((fwmax + 3) & ~3u) + 4) * 4;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int w = 0; w < 2; ++w) kern<<<bx, THREADS, lds, 0>>>(n, F, qtab, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, g_table_out);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    const int R = 10;
+    for (int r = 0; r < R; ++r) kern<<<bx, THREADS, lds, 0>>>(n, F, qtab, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, g_table_out);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / R * 1000.f;
+}
+
 int main()
 {
     const uint64_t n = 1920 * 1080; const uint32_t F = 29; const uint32_t m = 611158;
@@ -76,6 +97,25 @@ int main()
         printf("fp64-mod kernel vs Barrett kernel: %zu differing pass bytes, %zu differing segment counts (%llu passes)\n", diff, dc, (unsigned long long)passes);
     }
 #define RUNP(AB, TH, PARTS, what) printf("%-60s %8.1f us\n", "[fp64 mod] " what, run<AB, true, TH, 1, PARTS>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+    {   // k_query_p4: 4 pixels per lane, two workgroups per CU; same pass bytes (its segments are 256 pixels, so the counts are compared as sums)
+        const size_t pwb = (size_t)F * nseg * QL_P * 8;
+        std::vector<uint8_t> a(pwb), b(pwb);
+        run<0, true, QL_THREADS, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds);
+        CK(hipMemcpy(a.data(), sb, pwb, hipMemcpyDeviceToHost));
+        CK(hipMemset(sb, 0xEE, pwb));
+        uint32_t *sc4; CK(hipMalloc(&sc4, (size_t)F * nseg * 2 * 4));
+        printf("%-60s %8.1f us\n", "[p4] k_query_p4 full kernel", run_p4<0>(n, F, tab, sd, fstride, fwmax, sc4, (uint64_t *)sb));
+        CK(hipMemcpy(b.data(), sb, pwb, hipMemcpyDeviceToHost));
+        size_t diff = 0; for (size_t i = 0; i < pwb; ++i) diff += a[i] != b[i];
+        printf("k_query_p4 vs k_query_f64: %zu differing pass bytes\n", diff);
+        printf("%-60s %8.1f us\n", "[p4] no DMA, no barrier (pure passes)", run_p4<8 | 32>(n, F, tab, sd, fstride, fwmax, sc4, (uint64_t *)sb));
+        printf("%-60s %8.1f us\n", "[p4] no DMA (barriers kept)", run_p4<8>(n, F, tab, sd, fstride, fwmax, sc4, (uint64_t *)sb));
+        printf("%-60s %8.1f us\n", "[p4] no hashing", run_p4<16>(n, F, tab, sd, fstride, fwmax, sc4, (uint64_t *)sb));
+        printf("%-60s %8.1f us\n", "[p4] no LDS probes", run_p4<2>(n, F, tab, sd, fstride, fwmax, sc4, (uint64_t *)sb));
+        printf("%-60s %8.1f us\n", "[p4] no reductions", run_p4<1>(n, F, tab, sd, fstride, fwmax, sc4, (uint64_t *)sb));
+        printf("%-60s %8.1f us\n", "[p4] no ballots", run_p4<4>(n, F, tab, sd, fstride, fwmax, sc4, (uint64_t *)sb));
+        printf("%-60s %8.1f us\n", "[p4] 512-thread workgroups (4 per CU)", run_p4<0, 512>(n, F, tab, sd, fstride, fwmax, sc4, (uint64_t *)sb));
+    }
     { uint4 *t; CK(hipMalloc(&t, (n + 512) * 32)); g_table_out = t; RUNP(0, 1024, 1, "full kernel + hash table written for the next batch"); g_table_out = nullptr; CK(hipFree(t)); }
     RUNP(0, 1024, 1, "full kernel (again, no table)");
     RUNP(8 | 32 | 2048, 1024, 1, "pure passes (A): and/add addressing, ballots");
