@@ -49,6 +49,8 @@ struct rbf_ctx {
     uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
     uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
     uint32_t *partials = nullptr;    size_t partials_cap = 0;
+    uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
+    bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
     int32_t *thr_tab = nullptr;      size_t thr_tab_cap = 0;      // per-pair thresholds of the mask kernels
     uint64_t *pack_base = nullptr;   size_t pack_base_cap = 0;    // running record size between pack chunks
@@ -185,6 +187,7 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->qimage) (void)hipFree(ctx->qimage);
+    if (ctx->ones_acc) (void)hipFree(ctx->ones_acc);
     if (ctx->hash_tab) (void)hipFree(ctx->hash_tab);
     if (ctx->thr_tab) (void)hipFree(ctx->thr_tab);
     if (ctx->pack_base) (void)hipFree(ctx->pack_base);
@@ -520,11 +523,55 @@ __global__ void k_store_thresholds(const ThrChunk c, int32_t *__restrict__ dst, 
     if (threadIdx.x < count) dst[threadIdx.x] = c.v[threadIdx.x];
 }
 
-int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
-                            uint32_t nframes, uint32_t width, uint32_t height,
-                            uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
-                            uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
-                            void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev)
+// The tail of a residual-mask pass, ONE launch instead of a memset in front of the mask kernels, a copy kernel behind
+// them and two more memsets (rocprofv3: the four small launches were ~25 us of a ~215 us step).  The mask kernels count
+// into a context-owned accumulator that is zero whenever they start; block 0 hands the counts to the caller's array (and,
+// for rbf_encode_gop, into the device-visible pinned block whose flag word the host spins on) and zeroes the accumulator
+// again; every block clears its share of up to two output regions (the witness rows and the stats of the batch).
+__global__ __launch_bounds__(256) void k_finish_ones(uint64_t *__restrict__ acc, uint64_t *__restrict__ ones, uint32_t count,
+                                                     uint64_t *host_block /* nullable */, uint64_t token,
+                                                     uint4 *__restrict__ clear_a, uint64_t quads_a, uint4 *__restrict__ clear_b, uint64_t quads_b)
+{
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+            const uint64_t v = acc[i];
+            ones[i] = v;
+            acc[i] = 0;
+            if (host_block) __hip_atomic_store(&host_block[1 + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (host_block) {
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(&host_block[0], token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads_a; i += (uint64_t)gridDim.x * blockDim.x) clear_a[i] = z;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads_b; i += (uint64_t)gridDim.x * blockDim.x) clear_b[i] = z;
+}
+
+static int launch_finish_ones(rbf_ctx *ctx, uint64_t *ones_dev, uint32_t pairs, uint64_t *host_block, uint64_t token,
+                              void *clear_a, size_t bytes_a, void *clear_b, size_t bytes_b)
+{
+    // regions that are not 16-byte shaped fall back to a memset (never the case for the library's own buffers)
+    if (clear_a && (((uintptr_t)clear_a | bytes_a) & 15)) { HIP_TRY(hipMemsetAsync(clear_a, 0, bytes_a, ctx->stream)); clear_a = nullptr; bytes_a = 0; }
+    if (clear_b && (((uintptr_t)clear_b | bytes_b) & 15)) { HIP_TRY(hipMemsetAsync(clear_b, 0, bytes_b, ctx->stream)); clear_b = nullptr; bytes_b = 0; }
+    const uint64_t quads = bytes_a / 16 + bytes_b / 16;
+    uint32_t blocks = (uint32_t)((quads + 256 * 4 - 1) / (256 * 4));       // ~4 stores per thread
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_finish_ones, dim3(blocks), dim3(256), 0, ctx->stream, ctx->ones_acc, ones_dev, pairs, host_block, token,
+                       (uint4 *)clear_a, (uint64_t)(bytes_a / 16), (uint4 *)clear_b, (uint64_t)(bytes_b / 16));
+    HIP_TRY(hipGetLastError());
+    ctx->ones_acc_dirty = false;
+    return RBF_OK;
+}
+
+static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                              uint32_t nframes, uint32_t width, uint32_t height,
+                              uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                              uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                              void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev, bool finish)
 {
     if (int r = set_device(ctx)) return r;
     if (!frames_dev || !masks_dev || !ones_dev) return fail(RBF_EINVAL, "null device pointer");
@@ -537,7 +584,16 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
     const uint64_t n = (uint64_t)width * height;
     if (int r = check_frame_geometry(n, nframes - 1, mask_stride_bytes)) return r;
     const uint32_t pairs = nframes - 1;
-    HIP_TRY(hipMemsetAsync(ones_dev, 0, (size_t)pairs * sizeof(uint64_t), ctx->stream));
+    if (ctx->ones_acc_cap < (size_t)pairs * 8) {
+        if (ctx->ones_acc) { HIP_TRY(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ones_acc); ctx->ones_acc = nullptr; ctx->ones_acc_cap = 0; }
+        const size_t want = ((size_t)pairs + 64) * 8;
+        HIP_TRY(hipMalloc((void **)&ctx->ones_acc, want));
+        ctx->ones_acc_cap = want;
+        ctx->ones_acc_dirty = true;
+    }
+    if (ctx->ones_acc_dirty) HIP_TRY(hipMemsetAsync(ctx->ones_acc, 0, ctx->ones_acc_cap, ctx->stream));
+    ctx->ones_acc_dirty = true;                                   // until k_finish_ones has been enqueued
+    uint64_t *const acc = ctx->ones_acc;
     const int32_t *thr_tab = nullptr;
     if (thr_floors) {
         // Kernel arguments are captured at launch, so the caller's array is free as soon as we return.
@@ -575,7 +631,7 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
         LaunchTimer t(ctx, RBF_K_MASK);
 #define RBF_MASK_GOP(S, PB, Z) hipLaunchKernelGGL((k_residual_mask_gop<S, PB, false, Z>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
                                (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, thr_tab, (uint16_t *)masks_dev, \
-                               mask_stride_bytes / 2, ones_dev, ppc)
+                               mask_stride_bytes / 2, acc, ppc)
 #define RBF_MASK_GOP2(S, PB) do { if (thr0) RBF_MASK_GOP(S, PB, true); else RBF_MASK_GOP(S, PB, false); } while (0)
         const bool thr0 = !thr_tab && thr_floor == 0 && !(ctx->force_generic_mask_bits);     // "luma changed": no per-pixel extraction
         if (sample_bytes == 1 && pixel_stride_bytes == 1) RBF_MASK_GOP2(uint8_t, 1);
@@ -595,13 +651,24 @@ int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
         LaunchTimer t(ctx, RBF_K_MASK);
         if (sample_bytes == 1)
             hipLaunchKernelGGL(k_residual_mask<uint8_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
-                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, thr_tab, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev, first_word);
+                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, thr_tab, (uint64_t *)masks_dev, mask_stride_bytes / 8, acc, first_word);
         else
             hipLaunchKernelGGL(k_residual_mask<uint16_t>, grid, block, 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
-                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, thr_tab, (uint64_t *)masks_dev, mask_stride_bytes / 8, ones_dev, first_word);
+                               width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, thr_tab, (uint64_t *)masks_dev, mask_stride_bytes / 8, acc, first_word);
     }
     HIP_TRY(hipGetLastError());
+    if (finish) return launch_finish_ones(ctx, ones_dev, pairs, nullptr, 0, nullptr, 0, nullptr, 0);
     return RBF_OK;
+}
+
+int rbf_residual_mask_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                            uint32_t nframes, uint32_t width, uint32_t height,
+                            uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                            uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                            void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev)
+{
+    return residual_mask_impl(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
+                              thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -917,16 +984,6 @@ int rbf_bgr_to_gray_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
     return RBF_OK;
 }
 
-// copies the ones counts into the device-visible pinned block and raises its flag word
-__global__ void k_publish_ones(const uint64_t *__restrict__ ones, uint64_t *host_block, uint32_t count, uint64_t token)
-{
-    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x)
-        __hip_atomic_store(&host_block[1 + i], ones[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&host_block[0], token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
                    uint32_t nframes, uint32_t width, uint32_t height,
                    uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
@@ -938,8 +995,8 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
                    rbf_filter_params *params_out, double *k_out)
 {
     if (!filters_dev || !witnesses_dev || !stats_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
-    if (int r = rbf_residual_mask_batch(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
-                                        pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev))
+    if (int r = residual_mask_impl(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
+                                   pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, false))
         return r;
     const uint32_t pairs = nframes - 1;
     const uint64_t n = (uint64_t)width * height;
@@ -963,10 +1020,9 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
     // cleared, so the only thing between the mask kernel and the Bloom kernels is the host's
     // float64 parameter math.
     const uint64_t token = ++ctx->publish_token;
-    hipLaunchKernelGGL(k_publish_ones, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)ones_dev, ctx->ones_mapped_dev, pairs, token);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)pairs * witness_stride_bytes, ctx->stream));
-    HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)pairs * RBF_STATS_PER_FRAME * 8, ctx->stream));
+    if (int r = launch_finish_ones(ctx, ones_dev, pairs, ctx->ones_mapped_dev, token, witnesses_dev, (size_t)pairs * witness_stride_bytes,
+                                   stats_dev, (size_t)pairs * RBF_STATS_PER_FRAME * 8))
+        return r;
     volatile uint64_t *flag = ctx->ones_pinned;
     for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != token; ++spins) {
         if ((spins & 0xFFFF) == 0xFFFF) {                    // every ~65k polls make sure the stream is still alive

@@ -614,13 +614,23 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
         const uint64_t obase = start & ~31ull;                     // dword-aligned start of my LDS image
         const uint64_t o = start + before + incl - c;
         if (pw) {
-            uint64_t tp = pw & flip_bytes64(masks[(uint64_t)f * mask_stride_words64 + w]);   // passes whose mask bit is 1
-            uint64_t out = 0;                                      // pext(mask, pw), LSB = first passing position
-            while (tp) {
-                const uint64_t below = (tp & (0 - tp)) - 1;        // bits under the lowest set bit
-                out |= 1ull << __popcll(pw & below);
-                tp &= tp - 1;
+            const uint64_t tp = pw & flip_bytes64(masks[(uint64_t)f * mask_stride_words64 + w]);   // passes whose mask bit is 1
+            // pext(mask, pw), LSB = first passing position, as two 32-bit halves: a pass at bit b of a half lands at
+            // popc(the half's passes below b); the high half's result is then shifted up by the low half's pass count.
+            // (One 64-bit loop cost ~18 instructions per set bit, a 32-bit one 7; the wave runs as long as its busiest lane.)
+            const uint32_t pw_lo = (uint32_t)pw, pw_hi = (uint32_t)(pw >> 32);
+            uint32_t t_lo = (uint32_t)tp, t_hi = (uint32_t)(tp >> 32), o_lo = 0, o_hi = 0;
+            while (t_lo) {
+                const uint32_t lsb = t_lo & (0u - t_lo);
+                o_lo |= 1u << __popc(pw_lo & (lsb - 1u));
+                t_lo ^= lsb;
             }
+            while (t_hi) {
+                const uint32_t lsb = t_hi & (0u - t_hi);
+                o_hi |= 1u << __popc(pw_hi & (lsb - 1u));
+                t_hi ^= lsb;
+            }
+            const uint64_t out = (uint64_t)o_lo | ((uint64_t)o_hi << __popc(pw_lo));
             if (out) {
                 const uint32_t rel = (uint32_t)(o - obase);
                 const uint32_t sh = rel & 31u, word = rel >> 5;

@@ -174,6 +174,29 @@ __device__ __forceinline__ void hash_table_store(uint4 *__restrict__ table, uint
     e[1] = make_uint4((uint32_t)h1, (uint32_t)h2, (uint32_t)ha, (uint32_t)(ha >> 32));
 }
 
+// dma_filter (rbf_kernels_lds.h) costs ~30 instructions per 1 KiB piece -- M0 saved and restored, a 64-bit address per lane,
+// the bounds test -- and a wave issues five pieces per frame: ~150 of the ~520 instructions it executes per frame went into
+// ISSUING the staging (ISA count, profiles/r02_query_isa.txt).  This form keeps the row pointer in an SGPR pair (saddr
+// addressing: the VGPR holds a 32-bit byte offset), writes M0 without restoring it (declared clobbered: nothing else in
+// these kernels uses M0) and tests bounds only on the row's last piece: 4 instructions per piece.
+__device__ __forceinline__ void dma_row(uint32_t lds_byte_addr /* uniform */, const uint32_t *row /* uniform */, uint32_t words, uint32_t wave, uint32_t lane, uint32_t nwaves)
+{
+    const uint32_t npieces = words >> 2;                          // whole 16-byte pieces
+    const uint32_t lane_off = lane << 4;
+    for (uint32_t c = wave; (c << 6) < npieces; c += nwaves) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr + (c << 10));
+        const uint32_t off = lane_off + (c << 10);
+        if ((c << 6) + 64u <= npieces || (c << 6) + lane < npieces)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(off), "s"(row) : "memory", "m0");
+    }
+    const uint32_t tail = words & 3u;                             // 0..3 dwords left: 4-byte DMA by wave 0
+    if (wave == 0 && lane < tail) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr + (npieces << 4));
+        const uint32_t off = (npieces << 4) + (lane << 2);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(dst), "v"(off), "s"(row) : "memory", "m0");
+    }
+}
+
 // Timeline probe (tools/bench_query.hip only, AB & 1024): wave 0 and the last wave of the first workgroups record the
 // shader clock at the phases of every frame iteration into this buffer ([wg][wave 0 / last][frame][phase]).
 __device__ uint64_t *g_query_timeline = nullptr;
@@ -275,7 +298,8 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
     uint32_t k = next_active(0);
     if (k >= nframes) return;
     Q64Frame cf = prepare(k);
-    if (!(AB & 8)) dma_filter(lds, image + (uint64_t)cf.f * image_stride_words32, cf.fwords, wave, lane, nwaves);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    if (!(AB & 8)) dma_row(lds0, image + (uint64_t)cf.f * image_stride_words32, cf.fwords, wave, lane, nwaves);
     uint32_t cur = 0;
     const uint32_t group = __builtin_amdgcn_readfirstlane((wave >> 2) % PARTS);   // consecutive waves sit on different SIMDs: a group = one wave per SIMD
 
@@ -305,10 +329,9 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
         const bool more = kn < nframes;
         Q64Frame nf = cf;
         if (more) nf = prepare(kn);                               // scalar loads + the division, off the critical path
-        const uint32_t fbase = vgpr_copy(__builtin_amdgcn_readfirstlane(lds_addr_of(lds + cur * bufwords)));
-        uint32_t *const next_buf = lds + (cur ^ 1u) * bufwords;
+        const uint32_t fbase = vgpr_copy(lds0 + cur * bufwords * 4u);
         auto issue = [&]() {                                      // this wave's share of DMA(next frame) + last frame's verdicts
-            if (more && !(AB & 8)) dma_filter(next_buf, image + (uint64_t)nf.f * image_stride_words32, nf.fwords, wave, lane, nwaves);
+            if (more && !(AB & 8)) dma_row(lds0 + (cur ^ 1u) * bufwords * 4u, image + (uint64_t)nf.f * image_stride_words32, nf.fwords, wave, lane, nwaves);
             if (AB & 2048) flush_held();                          // (ablation: verdicts stored one barrier late)
         };
         const uint32_t m_v = vgpr_copy(cf.m);
@@ -503,10 +526,11 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64t(
         }
     }
     auto next_active = [&](uint32_t k) -> uint32_t { while (k < nframes && tab.f[k].m == 0) ++k; return k; };
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     auto stage_dma = [&](uint32_t f, uint32_t fwords, uint32_t t) {                     // tile t of frame f -> LDS
         const uint32_t w0 = t * tile_words;
         const uint32_t words = fwords - w0 < tile_words ? fwords - w0 : tile_words;
-        if (!(AB & 8)) dma_filter(lds, image + (uint64_t)f * image_stride_words32 + w0, words, wave, lane, nwaves);
+        if (!(AB & 8)) dma_row(lds_base, image + (uint64_t)f * image_stride_words32 + w0, words, wave, lane, nwaves);
     };
     uint32_t f = __builtin_amdgcn_readfirstlane(next_active(0));
     if (f >= nframes) return;
@@ -714,7 +738,7 @@ __global__ __launch_bounds__(QL_THREADS, 8) void k_query_p4(
         const uint64_t T = ((uint64_t)thi << 32) | tlo;
         const uint32_t m_v = vgpr_copy(m_s);
         if (!(AB & 32)) __syncthreads();                          // everyone is done probing the previous filter
-        if (!(AB & 8)) dma_filter(lds, image + (uint64_t)f * image_stride_words32, filter_words(m_s), wave, lane, nwaves);
+        if (!(AB & 8)) dma_row(__builtin_amdgcn_readfirstlane(lds_addr_of(lds)), image + (uint64_t)f * image_stride_words32, filter_words(m_s), wave, lane, nwaves);
         // the reductions need no filter: they run while the DMA flies (and while the CU's other workgroup probes)
         uint32_t npass = 0, pass;
 #define RBF_P4_FRAME(FKV)                                                                                          \

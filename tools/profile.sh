@@ -9,10 +9,10 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the default command (four GOP pipelines: kernels of neighbouring steps overlap, so per-kernel durations
 # include the co-runner) ...
-BENCH2="python $ROOT/bench.py --no-cpu-baseline $*"      # exactly the default command, minus the CPU leg
+BENCH2="python $ROOT/bench.py --no-cpu-baseline --no-verify $*"      # exactly the default command, minus the CPU leg
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_default" -o stats -- $BENCH2 > "$OUT/stats_default.log" 2>&1
 # ... and one pipeline alone: every kernel has the chip to itself (this is what the counters describe)
-BENCH="python $ROOT/bench.py --streams 1 --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing $*"
+BENCH="python $ROOT/bench.py --streams 1 --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-verify $*"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 PMC1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_ANY"
 PMC2="SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
