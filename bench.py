@@ -184,15 +184,8 @@ def main():
     torch.cuda.synchronize(device)
     if gather:
         from new_bloom_filter_repo_amd.dist import OutboxGather
-        heads = []
-        for k in range(ncoders):
-            buf = np.zeros(4, dtype=np.uint64)
-            nat.check(nat.lib().rbf_memcpy_d2h(ctxs[k].handle, buf.ctypes.data, probe[k].ptr, 32))
-            heads.append(int(buf[2]))
-        agreed = torch.tensor([max(heads)], dtype=torch.int64, device=device)
-        dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
-        slot_bytes = min(record_max, (int(agreed.item()) * 102 // 100 + 4096 + 255) // 256 * 256)
-        og = OutboxGather(slot_bytes // 8, G, device, streams=streams)
+        # worst-case slots (a record can never overflow one); only the used bytes of a slot travel
+        og = OutboxGather(record_max // 8, G, device, streams=streams)
         probe = None
         for _ in range(2 * G):                    # untimed: the first RCCL transfer of both outboxes (connection setup)
             step()
@@ -279,7 +272,8 @@ def main():
                                % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3"),
                    "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
                    "distinct_gop_per_pipeline": not args.shared_gop, "resident_input_mb_per_gpu": round(resident_mb, 1),
-                   "gather_bytes_per_rank_per_step": og.slot_words * 8 if gather else 0, "steps_per_gather": G if gather else 0,
+                   "gather": "exact-size: all_gather of the used sizes, then one grouped point-to-point message per peer; rank 0's own records are not sent" if gather else None,
+                   "steps_per_gather": G if gather else 0,
                    "lds_tile_kib": args.lds_tile_kib or "auto", "generic_kernels": bool(args.generic_kernels),
                    "hash_table": "k_hash_table runs in every step (--rebuild-hash-table)" if args.rebuild_hash_table else
                                  "written in every step by that step's query kernel (which hashes every pixel index anyway) for the next step's insert kernel",
@@ -289,7 +283,7 @@ def main():
     if short:
         out["requested_region"] = short           # the exactly---steps region, too short to be the headline
     if rank == 0 and gather:
-        check_gathered(og, world, G, pairs, n, res_all)
+        out["config"]["gathered_records_parsed_on_rank0"] = check_gathered(og, world, G, pairs, n, res_all)
     if rank == 0:
         l_sum = sum(r["l"] for r in res)
         w_sum = sum(r["witness_bits"] for r in res)
@@ -334,24 +328,23 @@ def main():
 
 
 def check_gathered(og, world, G, pairs, n, res_all):
-    """What arrived on rank 0 is complete: every slot of every rank has the right magic and frame count, no
-    overflow flag, a size that fits the slot; rank 0's own slot holds the rows of one of its pipelines."""
-    from new_bloom_filter_repo_amd.dist import RECORD_MAGIC, unpack_device_record
-    sw = og.slot_words
+    """What rank 0 holds after the last exchanges is complete and parses: every record of every rank has the frame
+    count of a GOP and exactly its used size; rank 0's own records are the rows of one of its pipelines."""
+    from new_bloom_filter_repo_amd.dist import unpack_device_record
+    parsed = 0
     for ob in range(2):
+        if og.sizes[ob] is None:
+            continue
         for r in range(world):
-            heads = og.received(ob, r)[:, :4].cpu().numpy().view(np.uint64)
-            for j in range(G):
-                h = heads[j]
-                if int(h[0]) != RECORD_MAGIC or int(h[1]) != pairs or int(h[3]) != 0 or int(h[2]) > sw * 8:
-                    raise SystemExit("gathered record of rank %d (outbox %d slot %d) is damaged: %s" % (r, ob, j, h.tolist()))
-    mine = unpack_device_record(og.received(0, 0)[0].cpu().numpy().view(np.uint8), n)
-
-    def same(rows):
-        return all(g["l"] == w["l"] and g["witness_bits"] == w["witness_bits"] and np.array_equal(g["witness"], w["witness"])
-                   and (not w["l"] or np.array_equal(g["filter"], w["filter"])) for g, w in zip(mine, rows))
-    if not any(same(rows) for rows in res_all):
-        raise SystemExit("the record rank 0 gathered from itself matches none of its pipelines' rows")
+            for rec in og.received(ob, r):
+                rows = unpack_device_record(rec, n)
+                if len(rows) != pairs:
+                    raise SystemExit("gathered record of rank %d (outbox %d) holds %d frames, expected %d" % (r, ob, len(rows), pairs))
+                parsed += 1
+                if r == 0 and not any(all(g["l"] == w["l"] and g["witness_bits"] == w["witness_bits"] and np.array_equal(g["witness"], w["witness"])
+                                          and (not w["l"] or np.array_equal(g["filter"], w["filter"])) for g, w in zip(rows, res)) for res in res_all):
+                    raise SystemExit("a record rank 0 kept from itself matches none of its pipelines' rows")
+    return parsed
 
 
 def issue_roofline(W, H, F, bits, breakdown):

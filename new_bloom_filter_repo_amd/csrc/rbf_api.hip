@@ -42,6 +42,7 @@ struct Timed { int id; hipEvent_t a, b; };
 
 struct rbf_ctx {
     int device = 0;
+    uint32_t cus = 256;              // compute units of the device (hipDeviceAttributeMultiprocessorCount; MI355X: 256)
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     // scratch (grown on demand, never shrunk)
@@ -164,6 +165,10 @@ int rbf_ctx_create(int device, void *hip_stream, rbf_ctx **out)
     rbf_ctx *c = new (std::nothrow) rbf_ctx();
     if (!c) return fail(RBF_ENOMEM, "out of host memory");
     c->device = device;
+    {
+        int cus = 0;                                               // workgroup counts are sized for THIS device
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = (uint32_t)cus;
+    }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -460,13 +465,13 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
             if (auto_tiles && (p.fwords_max + p.query_tile_words - 1) / p.query_tile_words > MAX_QUERY_TILES) p.query_kind = 0;
         }
     }
-    // Slices per frame so that one launch has about one workgroup per CU (256).  With many frames or several
+    // Slices per frame so that one launch has about one workgroup per CU (ctx->cus; 256 on MI355X).  With many frames or several
     // tiles the quotient gets small (4K, 29 frames, 3 tiles: 2 slices -> 174 long workgroups), so the frames are
     // inserted in groups of `insert_group` coded frames, each group one launch with >= INSERT_SLICES slices per frame
     // (4K: 10 frames x 8 slices x 3 tiles = 240 workgroups).  Handing out uneven slices to use all 256 CUs was
     // measured and buys nothing: a launch lasts as long as its largest slice.
     constexpr uint32_t INSERT_SLICES = 8;
-    const uint32_t units = 256u / p.insert_tiles;                           // workgroups per tile layer
+    const uint32_t units = ctx->cus / p.insert_tiles ? ctx->cus / p.insert_tiles : 1u;     // workgroups per tile layer
     uint32_t group = units / INSERT_SLICES;                                  // coded frames per launch
     if (group < 1) group = 1;
     if (group > active) group = active ? active : 1;

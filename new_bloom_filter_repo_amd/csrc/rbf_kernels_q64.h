@@ -13,9 +13,12 @@
 //    filter costs the CU ~1 200 cycles whichever way it is issued (tools/dmabench.hip: LDS-DMA and global_load +
 //    ds_write both land 76 KB in 1 150 - 1 550 cycles, ~50 B/clk/CU; one wave alone needs 160 cycles per 1 KiB
 //    instruction), and that time ADDS to the frame passes instead of hiding under them: 86 us without the DMA,
-//    101 us with it.  Variants measured and NOT kept because they changed nothing or lost: issuing the DMA share of
-//    wave group g in front of pixel part g (PARTS = 2 / 4: 100 - 108 us vs 101), storing the verdicts one barrier
-//    late (+7 us), counting passes with popc + a wave reduction instead of ballots (+4 us).
+//    101 us with it.  Variants measured and NOT kept because they changed nothing or lost (profiles/r02_query_ablation.txt
+//    and the round-2 git history have them): issuing the DMA share of wave group g in front of pixel part g of the frame
+//    pass (2 / 4 parts: 100 - 108 us vs 101), storing the verdicts one barrier late (+7 us), counting passes with popc +
+//    a wave reduction instead of ballots (+4 us), staging through registers -- one plain 16-byte load per pipeline slot,
+//    the ds_write_b128 a slot later -- instead of LDS-DMA (125 us: it needs four more VGPRs than there are), and a
+//    4-pixels-per-lane re-cut at 8 waves per SIMD (k_query_p4 below, 112 us).
 //  * The next frame's geometry (scalar loads; -1/m comes from the host in FrameDev::M) is fetched one frame ahead.
 #pragma once
 #include "rbf_kernels_lds.h"
@@ -202,7 +205,6 @@ __device__ __forceinline__ void dma_row(uint32_t lds_byte_addr /* uniform */, co
 __device__ uint64_t *g_query_timeline = nullptr;
 constexpr uint32_t TL_WGS = 4, TL_PHASES = 6;
 
-constexpr int Q64_PARTS = 1;                       // DMA issue points per frame = wave groups (1: every wave right after the barrier)
 
 // Per-frame scalars, prepared one frame ahead.
 struct Q64Frame {
@@ -210,10 +212,9 @@ struct Q64Frame {
     uint32_t Thi, Tlo, ninv_lo, ninv_hi;
 };
 
-// AB bits also understood here: 8 = no filter DMA, 32 = no barrier / DMA wait (wrong results), 64 = no output,
-// 2048 = store the verdicts one barrier late, 4096 = every wave issues its DMA right after the barrier (= PARTS 1),
-// 8192 = three-instruction probe address (shift, and, add), 16384 = pass count by popc + wave reduction.
-template <int AB = 0, int PARTS = Q64_PARTS>
+// AB bits also understood here: 8 = no filter DMA, 16 = no hashing, 32 = no barrier / DMA wait (wrong results), 64 = no output,
+// 1024 = timeline stamps, 8192 = three-instruction probe address (shift, and, add).
+template <int AB = 0>
 __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
     uint64_t n, uint32_t nframes, const FrameTable tab, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t fwords_max,
@@ -301,16 +302,6 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     if (!(AB & 8)) dma_row(lds0, image + (uint64_t)cf.f * image_stride_words32, cf.fwords, wave, lane, nwaves);
     uint32_t cur = 0;
-    const uint32_t group = __builtin_amdgcn_readfirstlane((wave >> 2) % PARTS);   // consecutive waves sit on different SIMDs: a group = one wave per SIMD
-
-    uint32_t held_pb = 0, held_np = 0, held_f = ~0u;
-    auto flush_held = [&]() {
-        if (held_f != ~0u && !(AB & 64) && live) {
-            pass_bytes[((uint64_t)held_f * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)held_pb;
-            if (lane == 0) seg_cnt[(uint64_t)held_f * nseg + seg] = held_np;
-        }
-        held_f = ~0u;
-    };
     const bool tl_on = (AB & 1024) && blockIdx.x < TL_WGS && (wave == 0 || wave == nwaves - 1) && g_query_timeline;
     uint64_t *tl = (AB & 1024) && g_query_timeline ? g_query_timeline + ((uint64_t)(blockIdx.x % TL_WGS) * 2 + (wave ? 1 : 0)) * MAX_BATCH * TL_PHASES : nullptr;
     auto stamp = [&](uint32_t frame_slot, uint32_t phase) {
@@ -320,7 +311,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
     while (true) {
         stamp(cf.f, 0);
         if (!(AB & 32)) {
-            dma_wait_all();           // my share of DMA(cf.f) has landed (it was issued most of a frame ago) ...
+            dma_wait_all();           // my share of DMA(cf.f) has landed (it was issued a frame ago) ...
             stamp(cf.f, 1);
             __syncthreads();          // ... and everyone's; nobody probes buffer cur^1 any more
         }
@@ -328,40 +319,17 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
         const uint32_t kn = __builtin_amdgcn_readfirstlane(next_active(cf.f + 1));
         const bool more = kn < nframes;
         Q64Frame nf = cf;
-        if (more) nf = prepare(kn);                               // scalar loads + the division, off the critical path
+        if (more) nf = prepare(kn);                               // scalar loads, off the critical path
+        if (more && !(AB & 8)) dma_row(lds0 + (cur ^ 1u) * bufwords * 4u, image + (uint64_t)nf.f * image_stride_words32, nf.fwords, wave, lane, nwaves);
         const uint32_t fbase = vgpr_copy(lds0 + cur * bufwords * 4u);
-        auto issue = [&]() {                                      // this wave's share of DMA(next frame) + last frame's verdicts
-            if (more && !(AB & 8)) dma_row(lds0 + (cur ^ 1u) * bufwords * 4u, image + (uint64_t)nf.f * image_stride_words32, nf.fwords, wave, lane, nwaves);
-            if (AB & 2048) flush_held();                          // (ablation: verdicts stored one barrier late)
-        };
         const uint32_t m_v = vgpr_copy(cf.m);
         const double ninv = __builtin_bit_cast(double, ((uint64_t)cf.ninv_hi << 32) | cf.ninv_lo);
         const uint64_t T = ((uint64_t)cf.Thi << 32) | cf.Tlo;
         const uint32_t fk = cf.fk;
-        const uint32_t grp = (AB & 4096) ? 0u : group;
         uint32_t pbf = 0, npass = 0;
         stamp(cf.f, 3);
-        // floor(k*) is a small integer: straight-line code for the common values lets the compiler issue the LDS probes
-        // of a part's pixels back to back instead of one round trip at a time.
-#define RBF_Q64_ARGS hd1, hl1, hd2, hl2, ha, validmask, fbase, safe_pos, m_v, ninv, T, fk, pbf, npass
-#define RBF_Q64_PASS(FKV, CV)                                                                                                         \
-        do {                                                                                                                          \
-            if (grp == 0) issue();                                                                                                    \
-            if (PARTS == 1) frame_part_f64<FKV, AB, CV, 0, 8>(RBF_Q64_ARGS);                                                          \
-            else if (PARTS == 2) {                                                                                                    \
-                frame_part_f64<FKV, AB, CV, 0, 4>(RBF_Q64_ARGS);                                                                      \
-                if (grp == 1) issue();                                                                                                \
-                frame_part_f64<FKV, AB, CV, 4, 8>(RBF_Q64_ARGS);                                                                      \
-            } else {                                                                                                                  \
-                frame_part_f64<FKV, AB, CV, 0, 2>(RBF_Q64_ARGS);                                                                      \
-                if (grp == 1) issue();                                                                                                \
-                frame_part_f64<FKV, AB, CV, 2, 4>(RBF_Q64_ARGS);                                                                      \
-                if (grp == 2) issue();                                                                                                \
-                frame_part_f64<FKV, AB, CV, 4, 6>(RBF_Q64_ARGS);                                                                      \
-                if (grp == 3) issue();                                                                                                \
-                frame_part_f64<FKV, AB, CV, 6, 8>(RBF_Q64_ARGS);                                                                      \
-            }                                                                                                                         \
-        } while (0)
+        // floor(k*) is a small integer: straight-line, hand-pipelined code for the common values; a plain loop otherwise
+#define RBF_Q64_PASS(FKV, CV) frame_part_f64<FKV, AB, CV, 0, QL_P>(hd1, hl1, hd2, hl2, ha, validmask, fbase, safe_pos, m_v, ninv, T, fk, pbf, npass)
         if (whole_wave) {
             switch (fk) {
             case 1: RBF_Q64_PASS(1, false); break;
@@ -374,23 +342,16 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64(
             RBF_Q64_PASS(-1, true);
         }
 #undef RBF_Q64_PASS
-#undef RBF_Q64_ARGS
-        if (AB & 16384) {                                          // pass count from the verdict bytes: one popcount + a wave reduction
-            uint32_t c = __popc(~pbf & 0xFFu);
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
-            npass = __builtin_amdgcn_readfirstlane(c);
-        }
         stamp(cf.f, 4);
-        flush_held();
-        held_pb = ~pbf; held_np = npass; held_f = cf.f;
-        if (!(AB & 2048)) flush_held();
+        if (!(AB & 64) && live) {
+            pass_bytes[((uint64_t)cf.f * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)~pbf;
+            if (lane == 0) seg_cnt[(uint64_t)cf.f * nseg + seg] = npass;
+        }
         stamp(cf.f, 5);
         if (!more) break;
         cf = nf;
         cur ^= 1u;
     }
-    flush_held();
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -4,8 +4,9 @@
 Frames are independent units on the encoder side (inter-frame t needs only ORIGINAL frames t-1 and
 t), so a video shards by contiguous frame ranges with one halo frame and there is no data-path
 collective: the only exchange is the gather of the variable-length per-frame records to rank 0,
-which writes the container.  RCCL has no gatherv, so lengths are all-gathered first and the padded
-payloads are gathered to the root (xGMI gives every peer its own link into rank 0).
+which writes the container.  RCCL has no gatherv, so lengths are all-gathered first and the payloads then
+travel as grouped point-to-point messages of exactly their used size (xGMI gives every peer its own link into
+rank 0); rank 0's own records never enter a collective.
 """
 import struct
 
@@ -84,18 +85,22 @@ def unpack_device_record(buf, n):
 
 
 class OutboxGather:
-    """Batched asynchronous gather of fixed-size record slots to rank 0 (bench.py's N > 1 path).
+    """Batched asynchronous EXACT-SIZE gather of packed records to rank 0 (bench.py's N > 1 path).
 
-    Every step writes one record into the next slot of an outbox of `steps_per_gather` slots; a full
-    outbox travels in ONE dist.gather (fewer, larger collectives), and two outboxes alternate so that
-    writing never waits for a transfer.  RCCL's gather needs equal sizes on all ranks, hence fixed slots.
-    On CUDA the gather is issued from its own stream, ordered after the writers' streams by events, so no
-    writer stream waits for a send; on CPU (gloo, tests) the same bookkeeping runs without streams.
+    Every step packs one record into the next slot of an outbox of `steps_per_gather` worst-case-size slots; a full
+    outbox travels in one exchange on a dedicated communication stream: the used sizes are read from the slots'
+    headers (one small device-to-host copy on that stream), all-gathered, and every rank but `dst` sends the used
+    bytes of its slots as ONE point-to-point message while `dst` posts one receive per peer (batch_isend_irecv =
+    ncclGroupStart/End on RCCL; over xGMI every peer has its own link into `dst`).  Nothing is padded to a common
+    size, so a record cannot overflow a slot, and the records of `dst` itself never enter a collective.  Two
+    outboxes alternate so that packing never waits for a transfer; on CPU (gloo, tests) the same bookkeeping runs
+    without streams.
 
         slot = og.begin(k)      # on pipeline k's stream: where this step's record goes (int64 tensor)
         ... enqueue the writes into `slot` on pipeline k's stream ...
         og.end(k)               # record written; sends the outbox when this was its last slot
         og.flush()              # send a partly filled outbox, wait for everything in flight
+        og.received(ob, rank)   # on dst: the records last received from `rank` in outbox `ob` (list of uint8 tensors)
     """
 
     def __init__(self, slot_words, steps_per_gather, device, streams=None, group=None, dst=0):
@@ -105,12 +110,16 @@ class OutboxGather:
         self.G, self.slot_words = max(1, int(steps_per_gather)), int(slot_words)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.cuda = device.type == "cuda"
+        self.device = device
         self.out = [torch.zeros(self.G, self.slot_words, dtype=torch.int64, device=device) for _ in range(2)]
-        self.inbox = [[torch.empty(self.G * self.slot_words, dtype=torch.int64, device=device) for _ in range(self.world)]
-                      if self.rank == dst else None for _ in range(2)]
-        self.pend = [None, None]
+        self.inbox = [[torch.empty(self.G * self.slot_words * 8, dtype=torch.uint8, device=device) if r != dst else None
+                       for r in range(self.world)] if self.rank == dst else None for _ in range(2)]
+        self.sizes = [None, None]       # per outbox on dst: [rank][slot] used bytes of the last exchange
+        self.filled = [0, 0]
+        self.pend = [None, None]        # per outbox: (works, keep-alive tensors, event)
         self.s = 0                      # steps begun so far (position in the slot sequence)
         self.sent = 0
+        self.bytes_sent = 0
         self.streams = list(streams) if streams else []
         self.comm = torch.cuda.Stream(device) if self.cuda else None
         self.events = [torch.cuda.Event() for _ in self.streams] if self.cuda else []
@@ -118,44 +127,107 @@ class OutboxGather:
     def _where(self):
         return self.s % self.G, (self.s // self.G) % 2
 
+    def _wait(self, ob):
+        if self.pend[ob] is not None:
+            works, _keep, ev = self.pend[ob]
+            for w in works:
+                w.wait()
+            if ev is not None:
+                self._torch.cuda.current_stream(self.device).wait_event(ev)
+            self.pend[ob] = None
+
     def begin(self, k=0):
         j, ob = self._where()
         # the first write of every writer stream into this outbox waits for the outbox's previous transfer
-        if j < max(1, len(self.streams)) and self.pend[ob] is not None:
-            self.pend[ob].wait()
+        if j < max(1, len(self.streams)):
+            if self.cuda and self.streams:
+                with self._torch.cuda.stream(self.streams[k]):
+                    self._wait_stream(ob, self.streams[k])
+            else:
+                self._wait(ob)
         return self.out[ob][j]
+
+    def _wait_stream(self, ob, stream):
+        if self.pend[ob] is not None:
+            works, _keep, ev = self.pend[ob]
+            for w in works:
+                w.wait()                                   # NCCL work: makes the current stream wait, does not block the host
+            if ev is not None:
+                stream.wait_event(ev)
 
     def end(self, k=0):
         if self.cuda and self.streams:
             self.events[k].record(self.streams[k])
         j, ob = self._where()
         self.s += 1
+        self.filled[ob] = j + 1
         if j == self.G - 1:
             self._send(ob)
 
+    def _exchange(self, ob, count):
+        torch, dist = self._torch, self._dist
+        heads = self.out[ob][:count, :4].cpu().numpy().view(np.uint64)          # (the only host synchronisation: this stream)
+        used = []
+        for h in heads:
+            if int(h[0]) != RECORD_MAGIC or int(h[3]) != 0 or int(h[2]) > self.slot_words * 8:
+                raise ValueError("a packed record in the outbox is damaged: %s" % h.tolist())
+            used.append((int(h[2]) + 7) // 8 * 8)
+        mine = torch.zeros(self.G, dtype=torch.int64, device=self.device)
+        mine[:count] = torch.tensor(used, dtype=torch.int64, device=self.device)
+        sizes = [torch.zeros(self.G, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(sizes, mine, group=self.group)
+        sizes = [[int(x) for x in t.cpu().tolist()] for t in sizes]
+        ops, keep = [], []
+        if self.rank == self.dst:
+            self.sizes[ob] = sizes
+            for r in range(self.world):
+                if r != self.dst and sum(sizes[r]):
+                    ops.append(dist.P2POp(dist.irecv, self.inbox[ob][r][:sum(sizes[r])], r, self.group))
+        elif sum(used):
+            payload = torch.cat([self.out[ob][j, :u // 8].view(torch.uint8) for j, u in enumerate(used)])
+            keep.append(payload)
+            ops.append(dist.P2POp(dist.isend, payload, self.dst, self.group))
+            self.bytes_sent += int(payload.numel())
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, keep
+
     def _send(self, ob):
+        count = self.filled[ob]
         if self.cuda:
             with self._torch.cuda.stream(self.comm):
                 for ev in self.events:
                     self.comm.wait_event(ev)
-                self.pend[ob] = self._dist.gather(self.out[ob].view(-1), self.inbox[ob], dst=self.dst, group=self.group, async_op=True)
+                works, keep = self._exchange(ob, count)
+                ev = self._torch.cuda.Event()
+                ev.record(self.comm)
+                self.pend[ob] = (works, keep, ev)
         else:
-            self.pend[ob] = self._dist.gather(self.out[ob].view(-1), self.inbox[ob], dst=self.dst, group=self.group, async_op=True)
+            works, keep = self._exchange(ob, count)
+            self.pend[ob] = (works, keep, None)
         self.sent += 1
 
     def flush(self):
         j, ob = self._where()
-        if j:                           # a partly filled outbox: send it whole (stale slots ride along)
+        if j:                           # a partly filled outbox: only its filled slots travel
             self._send(ob)
             self.s += self.G - j
         for ob in range(2):
-            if self.pend[ob] is not None:
-                self.pend[ob].wait()
-                self.pend[ob] = None
+            self._wait(ob)
+        if self.cuda:
+            self.comm.synchronize()
 
     def received(self, ob, rank):
-        """On dst: the G slots last received from `rank` in outbox `ob`, as a (G, slot_words) view."""
-        return self.inbox[ob][rank].view(self.G, self.slot_words)
+        """On dst: the records of the last exchange of outbox `ob` that came from `rank`, as a list of uint8 tensors of
+        exactly the used size (dst's own records are views of its outbox: they never travelled)."""
+        sizes = self.sizes[ob][rank]
+        if rank == self.dst:
+            return [self.out[ob][j, :u // 8].view(self._torch.uint8) for j, u in enumerate(sizes) if u]
+        out, off = [], 0
+        for u in sizes:
+            if u:
+                out.append(self.inbox[ob][rank][off:off + u])
+                off += u
+        return out
 
 
 def gather_records(records, dst=0, group=None, device=None):

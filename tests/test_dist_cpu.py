@@ -109,27 +109,35 @@ def _outbox_worker(rank, world, port, q, G, steps, sw):
         og = DD.OutboxGather(sw, G, torch.device("cpu"))
         for s in range(steps):
             slot = og.begin(0)
-            slot.copy_(torch.arange(sw, dtype=torch.int64) + 1000 * s + 100000 * rank)     # this step's "record"
+            rec = torch.from_numpy(_fake_record(1 + s % 3, 2 + (5 * s + 3 * rank) % 17, 1000 * s + 100000 * rank))   # this step's "record"
+            slot.zero_()
+            slot[:rec.numel()] = rec
             og.end(0)
         og.flush()
         if rank == 0:
-            got = {(ob, r): og.received(ob, r)[:, 0].tolist() for ob in range(2) for r in range(world)}
-            q.put((og.sent, og.s, got))
+            got = {}
+            for ob in range(2):
+                if og.sizes[ob] is None:
+                    continue
+                for r in range(world):
+                    got[(ob, r)] = [(int(t.numel()), t.numpy().view(np.uint64)[[1, 2]].tolist(), int(t.numpy().view(np.uint64)[-1])) for t in og.received(ob, r)]
+            q.put((og.sent, og.s, got, og.bytes_sent))
         else:
-            q.put((og.sent, og.s, None))
+            q.put((og.sent, og.s, None, og.bytes_sent))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("G,steps", [(4, 11), (1, 3), (3, 6), (16, 5)])
 def test_outbox_gather_gloo_world2(G, steps):
-    """bench.py's N > 1 bookkeeping on CPU: slot sequence, alternating outboxes, one gather per full outbox,
-    a partly filled outbox flushed at the end, every rank's slots arriving on rank 0 in step order."""
+    """bench.py's N > 1 bookkeeping on CPU: slot sequence, alternating outboxes, one exact-size exchange per full outbox,
+    a partly filled outbox flushed at the end (only its filled slots travel), every rank's records arriving on rank 0 in
+    step order with exactly their used size; rank 0 sends nothing."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() * 7 + G * 13 + steps) % 2000
-    procs = [ctx.Process(target=_outbox_worker, args=(r, 2, port, q, G, steps, 6)) for r in range(2)]
+    procs = [ctx.Process(target=_outbox_worker, args=(r, 2, port, q, G, steps, 400)) for r in range(2)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=120) for _ in range(2)]
@@ -137,18 +145,23 @@ def test_outbox_gather_gloo_world2(G, steps):
         p.join(timeout=60)
         assert p.exitcode == 0
     gathers = -(-steps // G)
-    for sent, s, got in outs:
-        assert sent == gathers and s == gathers * G            # every rank issued the same collectives
+
+    def want(step, r):
+        nf, pw, tag = 1 + step % 3, 2 + (5 * step + 3 * r) % 17, 1000 * step + 100000 * r
+        used = 32 + 64 * nf + 8 * pw
+        return (used, [nf, used], tag + pw - 1)
+    for sent, s, got, bytes_sent in outs:
+        assert sent == gathers and s == gathers * G            # every rank issued the same exchanges
         if got is None:
+            assert bytes_sent == sum(want(st, 1)[0] for st in range(steps))      # rank 1 sent exactly its used bytes
             continue
+        assert bytes_sent == 0                                  # rank 0's records never travel
         # the last two rounds live in the two outboxes; round r used outbox r % 2 and holds steps r*G .. r*G+G-1
         for rnd in range(max(0, gathers - 2), gathers):
             for r in range(2):
-                firsts = got[(rnd % 2, r)]
-                for j in range(G):
-                    step = rnd * G + j
-                    if step < steps:
-                        assert firsts[j] == 1000 * step + 100000 * r, (rnd, r, j, firsts)
+                recs = got[(rnd % 2, r)]
+                steps_in = [st for st in range(rnd * G, rnd * G + G) if st < steps]
+                assert recs == [want(st, r) for st in steps_in], (rnd, r, recs)
 
 
 def _fake_record(nframes, payload_words, tag):

@@ -1,4 +1,5 @@
-// bench_query.hip -- ablation timing of k_query_lds on a synthetic 1080p x 29-frame batch (profiling aid).
+// bench_query.hip -- ablation timing of the query kernels (k_query_lds, k_query_f64, k_query_p4) on a synthetic 1080p x 29-frame batch:
+// kernel variants against each other (outputs compared), ablations, occupancy scaling and the frame-loop timeline (profiling aid).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -10,7 +11,7 @@ using namespace rbf;
 
 static uint4 *g_table_out = nullptr;            // k_query_f64: also write the hash table (nullptr = do not)
 static const uint32_t *g_image = nullptr;       // probe image (~bswap of every filter dword), same row pitch as the filters
-template <int AB, bool DB = true, int THREADS = QL_THREADS, int MODK = 0, int PARTS = 1>
+template <int AB, bool DB = true, int THREADS = QL_THREADS, int MODK = 0>
 static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F, const FrameTable &tab, Seeds sd, const uint32_t *filters,
                  uint64_t fstride, uint32_t fwmax, uint32_t *seg_bits, uint32_t *seg_cnt, uint64_t nseg, size_t lds)
 {
@@ -20,10 +21,10 @@ static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F
         for (uint32_t f = 0; f < F; ++f) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
     }
     auto launch = [&](dim3 g, dim3 b, size_t sh, hipStream_t st, uint64_t n_, uint32_t F_, const FrameTable &t_, Seeds s_, const uint32_t *f_, uint64_t fs_, uint32_t fw_, uint32_t *sc_, uint64_t ns_, uint64_t *pw_) {
-        if constexpr (MODK == 1) k_query_f64<AB, PARTS><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out);
+        if constexpr (MODK == 1) k_query_f64<AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out);
         else k_query_lds<DB, true, AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_);
     };
-    const void *kern = MODK == 1 ? (const void *)k_query_f64<AB, PARTS> : (const void *)k_query_lds<DB, true, AB>;
+    const void *kern = MODK == 1 ? (const void *)k_query_f64<AB> : (const void *)k_query_lds<DB, true, AB>;
     uint64_t *pwords = (uint64_t *)seg_bits;
     CK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const uint32_t bx = (uint32_t)((nseg + THREADS / 64 - 1) / (THREADS / 64));
@@ -96,7 +97,7 @@ int main()
         uint64_t passes = 0; for (auto c : ca) passes += c;
         printf("fp64-mod kernel vs Barrett kernel: %zu differing pass bytes, %zu differing segment counts (%llu passes)\n", diff, dc, (unsigned long long)passes);
     }
-#define RUNP(AB, TH, PARTS, what) printf("%-60s %8.1f us\n", "[fp64 mod] " what, run<AB, true, TH, 1, PARTS>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+#define RUNP(AB, TH, PARTS, what) printf("%-60s %8.1f us\n", "[fp64 mod] " what, run<AB, true, TH, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
     {   // k_query_p4: 4 pixels per lane, two workgroups per CU; same pass bytes (its segments are 256 pixels, so the counts are compared as sums)
         const size_t pwb = (size_t)F * nseg * QL_P * 8;
         std::vector<uint8_t> a(pwb), b(pwb);
@@ -118,24 +119,15 @@ int main()
     }
     { uint4 *t; CK(hipMalloc(&t, (n + 512) * 32)); g_table_out = t; RUNP(0, 1024, 1, "full kernel + hash table written for the next batch"); g_table_out = nullptr; CK(hipFree(t)); }
     RUNP(0, 1024, 1, "full kernel (again, no table)");
-    RUNP(8 | 32 | 2048, 1024, 1, "pure passes (A): and/add addressing, ballots");
-    RUNP(8 | 32 | 2048 | 8192, 1024, 1, "pure passes (B): lshr + lshl_add addressing");
-    RUNP(8 | 32 | 2048 | 16384, 1024, 1, "pure passes (C): count by popc + wave reduction");
-    RUNP(8 | 32 | 2048 | 8192 | 16384, 1024, 1, "pure passes (B+C)");
-    RUNP(2048, 1024, 1, "full (A)");
-    RUNP(2048 | 8192, 1024, 1, "full (B)");
-    RUNP(2048 | 16384, 1024, 1, "full (C)");
-    RUNP(2048 | 8192 | 16384, 1024, 1, "full (B+C)");
-    RUNP(0, 1024, 1, "full kernel, 1 part (all DMA after the barrier)");
-    RUNP(0, 1024, 2, "full kernel, 2 parts");
-    RUNP(8 | 32, 1024, 1, "pure passes, 1 part, 4 waves/SIMD");
-    RUNP(8 | 32, 512, 1, "pure passes, 1 part, 2 waves/SIMD");
-    RUNP(8 | 32, 256, 1, "pure passes, 1 part, 1 wave/SIMD");
-    RUNP(8 | 32, 1024, 2, "pure passes, 2 parts, 4 waves/SIMD");
-    RUNP(8 | 32, 256, 2, "pure passes, 2 parts, 1 wave/SIMD");
-    RUNP(8 | 32 | 4, 1024, 1, "pure passes, 1 part, no ballots");
-    RUNP(8, 1024, 1, "1 part, no DMA (barrier kept)");
-    RUNP(2048, 1024, 1, "1 part, stores at the end of the iteration");
+    RUNP(8 | 32 | 8192, 1024, 1, "pure passes, three-instruction probe address (shift, and, add)");
+    RUNP(8 | 32, 1024, 1, "pure passes, two-instruction probe address (lshr + lshl_add)");
+    RUNP(8192, 1024, 1, "full, three-instruction probe address");
+    
+    RUNP(8 | 32, 1024, 1, "pure passes, 4 waves/SIMD (1024-thread workgroups)");
+    RUNP(8 | 32, 512, 1, "pure passes, 2 waves/SIMD (512-thread workgroups)");
+    RUNP(8 | 32, 256, 1, "pure passes, 1 wave/SIMD (256-thread workgroups)");
+    RUNP(8 | 32 | 4, 1024, 1, "pure passes, no ballots");
+    RUNP(8, 1024, 1, "no DMA (barrier kept)");
     RUN1(8 | 32, "no DMA, no barrier: pure frame passes + stores");
     printf("%-44s %8.1f us\n", "[fp64 mod] same, 512-thread WGs (2 waves/SIMD)", run<8 | 32, true, 512, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
     printf("%-44s %8.1f us\n", "[fp64 mod] same, 256-thread WGs (1 wave/SIMD)", run<8 | 32, true, 256, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
@@ -148,11 +140,7 @@ int main()
     RUN1(8 | 32 | 1 | 2 | 4, "no DMA, no barrier, no reductions/probes/ballots");
     RUN1(8, "no DMA (barrier kept)");
     RUN1(32, "no barrier (DMA kept; wrong results)");
-    RUN1(2048, "verdict store at the end of its own iteration");
-    RUN1(4096, "every wave issues its DMA right after the barrier");
-    RUN1(4096 | 2048, "... and stores at the end (the r01 frame loop)");
     RUN1(2 | 8, "no LDS probes, no filter DMA");
-    RUN1(512, "frame order rotated per workgroup");
     {   // timeline of the frame loop: shader-clock stamps of wave 0 and wave 15 of the first workgroups
         uint64_t *dtl; const size_t tlw = (size_t)TL_WGS * 2 * MAX_BATCH * TL_PHASES;
         CK(hipMalloc(&dtl, tlw * 8)); CK(hipMemset(dtl, 0, tlw * 8));
@@ -173,7 +161,6 @@ int main()
             printf("cycles per frame %.0f\n", tot / (F - 2));
         }
     }
-    RUN1(32 | 64 | 8, "no barrier, no flush, no DMA");
     RUN1(16, "no hashing");
     RUN1(1, "no reductions (mod m)");
     RUN1(2, "no LDS probes");

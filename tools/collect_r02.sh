@@ -1,0 +1,22 @@
+# Round-2 evidence run on the GPU box (gpurun): everything DESIGN.md cites, written under gpurun_out/r02final/
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02final; mkdir -p $O
+./build/opbench > $O/opbench.txt 2>&1
+./build/dmabench > $O/dmabench.txt 2>&1
+./build/bench_query > $O/bench_query.txt 2>&1
+./build/bench_insert > $O/bench_insert.txt 2>&1
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --no-cpu-baseline --rebuild-hash-table > $O/bench_rebuild_hash_table.json 2>> $O/bench_default.err
+for st in 1 2 4 6; do python bench.py --no-cpu-baseline --no-verify --streams $st 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('streams %d: %.0f Mpixel/s, %.4f ms/step, alone %s' % ($st, d['value'], d['ms_per_step'], d['kernels_ms_per_step_alone']))"; done > $O/streams_sweep.txt
+for args in "--width 2560 --height 1440 --frames 30 --steps 60" "--width 3840 --height 2160 --frames 9 --steps 40" "--width 5120 --height 2880 --frames 9 --steps 20" "--width 7680 --height 4320 --frames 5 --steps 10"; do
+python bench.py --no-cpu-baseline $args 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print(d['config']['workload'][:44], '| %.0f Mpixel/s | %.4f ms/step | alone' % (d['value'], d['ms_per_step']), d['kernels_ms_per_step_alone'], '| verified', d.get('verified_vs_oracle',{}).get('frames'))"; done > $O/large_frames.txt
+for p in 0.01 0.05 0.2 0.3; do python bench.py --no-cpu-baseline --density $p 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('p=$p | %.0f Mpixel/s | %.4f ms/step | alone' % (d['value'], d['ms_per_step']), d['kernels_ms_per_step_alone'], '| verified', d.get('verified_vs_oracle',{}).get('frames'))"; done > $O/density_sweep.txt
+python bench.py --no-cpu-baseline --bits 16 2>/dev/null | tail -1 > $O/bench_uint16.json
+bash tools/profile.sh r02final > $O/profile.log 2>&1
+cp gpurun_out/prof_r02final/summary.txt $O/rocprofv3_summary.txt
+cp gpurun_out/prof_r02final/stats/*kernel_stats.csv $O/kernel_stats_streams1.csv 2>/dev/null
+cp gpurun_out/prof_r02final/stats_default/*kernel_stats.csv $O/kernel_stats_default_4pipelines.csv 2>/dev/null
+ls -la $O
