@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--lds-tile-kib", type=int, default=0, help="cap the LDS filter tile (KiB) -> tiled kernels; 0 = auto (BASELINE config 4 sweep)")
     ap.add_argument("--gather-every", type=int, default=16, help="N>1: steps whose records travel in one RCCL gather")
     ap.add_argument("--rebuild-hash-table", action="store_true", help="diagnostic: run k_hash_table in every step instead of taking the table the previous step's query kernel wrote")
+    ap.add_argument("--force-bits", type=int, default=0, help="diagnostic: extra rbf_ctx_force_generic bits (see include/rbf.h)")
     ap.add_argument("--generic-kernels", action="store_true", help="diagnostic: global-memory insert / query kernels instead of the LDS ones")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather to rank 0")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and gather) even with one rank (smoke-tests the N>1 path)")
@@ -115,9 +116,9 @@ def main():
     # neighbours, and (N > 1) the async RCCL gather of step s overlaps the kernels of step s+1.  Every step
     # still does all of its work inside the timed region.
     ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
-    if args.lds_tile_kib or args.generic_kernels or args.rebuild_hash_table:
+    if args.lds_tile_kib or args.generic_kernels or args.rebuild_hash_table or args.force_bits:
         for c in ctxs:
-            c.force_generic(((args.lds_tile_kib * 1024 // 256) << 16) | (1 if args.generic_kernels else 0) | (16 if args.rebuild_hash_table else 0))      # tile unit: 64 dwords
+            c.force_generic(((args.lds_tile_kib * 1024 // 256) << 16) | (1 if args.generic_kernels else 0) | (16 if args.rebuild_hash_table else 0) | args.force_bits)      # tile unit: 64 dwords
     ctx = ctxs[0]
     arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
     coders = []

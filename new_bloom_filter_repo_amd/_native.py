@@ -7,7 +7,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librbf_hip.so")
+LIB_PATH = os.environ.get("RBF_LIB_PATH") or os.path.join(_HERE, "librbf_hip.so")      # RBF_LIB_PATH: A/B runs of differently built libraries
 
 RBF_OK = 0
 RBF_EINVAL = -22
