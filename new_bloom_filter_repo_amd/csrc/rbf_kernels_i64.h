@@ -51,6 +51,20 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash_table(uint64_t n, Seeds see
     for (int it = 0; it < QL_P; ++it) hash_table_store(table, seg, lane, it, h1[it], h2[it], ha[it]);
 }
 
+// Inclusive prefix sum over the wave's 64 lanes in six DPP adds: a Hillis-Steele scan inside every row of 16 lanes
+// (row_shr 1, 2, 4, 8; lanes without a source add 0), then row 0's / row 2's total onto rows 1 / 3 (row_bcast:15) and the
+// total of rows 0-1 onto rows 2-3 (row_bcast:31).  No LDS, no ballots.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
 constexpr int IT_STEP_BYTES = 128;                 // mask bytes per wave step: a lane owns 16 pixels (two bytes)
 constexpr int IT_QUEUE = 64 + IT_STEP_BYTES * 8;   // carry (< 64) + one wave step
 
@@ -141,12 +155,12 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     for (uint64_t g = g0 + wave; g < g1; g += IL_WAVES) {
         uint32_t bits = (IAB & 8) ? (nxt & 0u) : nxt;
         nxt = load_bits(g + IL_WAVES);                             // prefetch
-        // exclusive prefix of the per-lane counts (0..16) without a cross-lane scan: one ballot per bit of the count
+        // exclusive prefix of the per-lane counts (0..16): six DPP adds (the five ballots + ten mbcnt of k_insert_lds were a
+        // third of this loop's skeleton)
         const uint32_t c = __popc(bits);
-        const uint64_t b0 = __ballot((c & 1u) != 0), b1 = __ballot((c & 2u) != 0), b2 = __ballot((c & 4u) != 0);
-        const uint64_t b3 = __ballot((c & 8u) != 0), b4 = __ballot((c & 16u) != 0);
-        const uint32_t excl = rank_below(b0) + 2u * rank_below(b1) + 4u * rank_below(b2) + 8u * rank_below(b3) + 16u * rank_below(b4);
-        const uint32_t total = __popcll(b0) + 2u * __popcll(b1) + 4u * __popcll(b2) + 8u * __popcll(b3) + 16u * __popcll(b4);
+        const uint32_t incl = wave_inclusive_scan(c);
+        const uint32_t excl = incl - c;
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
         uint32_t off = qn + excl;
         const uint32_t base = (uint32_t)((g * IT_STEP_BYTES + lane * 2) << 3);
         while (bits) {
