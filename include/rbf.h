@@ -112,7 +112,8 @@ int rbf_timing_enable(rbf_ctx *ctx, int on);
  * hash table the insert kernel gathers from, 32 bytes per pixel) for every batch instead of taking the copy the previous
  * batch's query kernel wrote while hashing the same indices for its own probes; bit 6 = the 4-pixels-per-lane FP64 query
  * kernel (k_query_p4: 64 VGPRs, two single-buffered workgroups per CU) instead of k_query_f64 (8 pixels per lane, double-buffered); bit 5 = never use that table
- * (the insert kernel hashes the set positions itself, as in ABI build 1).  0 (default) = pick the fastest
+ * (the insert kernel hashes the set positions itself, as in ABI build 1); bit 7 = filters of several LDS tiles are inserted by the
+ * tiled k_insert_tab even inside rbf_encode_gop (default there: k_insert_positions + k_insert_records).  0 (default) = pick the fastest
  * variant that fits: the LDS-resident path needs the batch's largest filter to fit in LDS. */
 int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
 int rbf_timing_reset(rbf_ctx *ctx);

@@ -50,6 +50,9 @@ struct rbf_ctx {
     uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
     uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
     uint32_t *partials = nullptr;    size_t partials_cap = 0;
+    uint2 *ins_records = nullptr;    size_t ins_records_cap = 0;  // two-kernel insert: 8 bytes per set mask bit of the batch
+    uint32_t *ins_counters = nullptr; size_t ins_counters_cap = 0; // ... and the records appended so far, per frame
+    int no_two_phase = 0;            // 1 = tiled k_insert_tab even when the filter needs several LDS tiles
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
@@ -191,6 +194,8 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (ctx->seg_off) (void)hipFree(ctx->seg_off);
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->ins_records) (void)hipFree(ctx->ins_records);
+    if (ctx->ins_counters) (void)hipFree(ctx->ins_counters);
     if (ctx->qimage) (void)hipFree(ctx->qimage);
     if (ctx->ones_acc) (void)hipFree(ctx->ones_acc);
     if (ctx->hash_tab) (void)hipFree(ctx->hash_tab);
@@ -275,6 +280,7 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->hash_rebuild = (on & 16) ? 1 : 0;
     ctx->query_p4 = (on & 64) ? 1 : 0;
     ctx->no_hash_table = (on & 32) ? 1 : 0;
+    ctx->no_two_phase = (on & 128) ? 1 : 0;
     ctx->mask_chunks = (uint32_t)(on >> 8) & 0xFF;           // tuning knob, bits 8..15
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
     return RBF_OK;
@@ -402,6 +408,7 @@ struct Plan {
     bool double_buffer, small_m;
     bool query_p4;               // k_query_p4 instead of k_query_f64
     bool insert_tab;             // insert through the hash table + FP64 reductions (same size condition, any LDS fit)
+    bool insert_two_phase;       // ... as k_insert_positions + k_insert_records (filters of more than one LDS tile, counts known on the host)
     bool f64_mod;                // every coded frame has F64MOD_M_MIN <= m <= F64MOD_M_MAX: reductions through the FP64 pipe
     uint32_t fwords_max, S /* slices of a coded frame */, per_tile /* sum of slices */, insert_group /* coded frames per insert launch */;
     SliceTable slices;
@@ -413,7 +420,7 @@ struct Plan {
 
 constexpr uint32_t MAX_INSERT_TILES = 7, MAX_QUERY_TILES = 3;     // measured crossovers, see make_plan
 
-static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n)
+static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n, bool have_ones = false)
 {
     Plan p{};
     uint32_t mmax = 0, active = 0;
@@ -470,6 +477,19 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     // inserted in groups of `insert_group` coded frames, each group one launch with >= INSERT_SLICES slices per frame
     // (4K: 10 frames x 8 slices x 3 tiles = 240 workgroups).  Handing out uneven slices to use all 256 CUs was
     // measured and buys nothing: a launch lasts as long as its largest slice.
+    // Filters of several tiles, set-bit counts known (rbf_encode_gop): one walk of the masks into position records, then the tiles
+    // are filled from the records -- no queues in that kernel, so a tile may take all of LDS.
+    p.insert_two_phase = p.fast_insert && sizes_f64 && !ctx->no_hash_table && !ctx->barrett_only && !ctx->no_two_phase && have_ones && p.insert_tiles > 1;
+    if (p.insert_two_phase) {
+        const uint32_t cap = (uint32_t)(LDS_LIMIT / 4) & ~3u;
+        uint32_t tw = (p.fwords_max + 3u) & ~3u;
+        if (tw > cap) { const uint32_t nt = (p.fwords_max + cap - 1) / cap; tw = (((p.fwords_max + nt - 1) / nt) + 3u) & ~3u; }
+        if (ctx->tile_words && (ctx->tile_words & ~3u) < tw) tw = ctx->tile_words & ~3u;
+        if (tw < 4) tw = 4;
+        p.insert_tile_words = tw;
+        p.insert_tiles = (p.fwords_max + tw - 1) / tw;
+        p.insert_lds_bytes = (size_t)tw * 4;
+    }
     constexpr uint32_t INSERT_SLICES = 8;
     const uint32_t units = ctx->cus / p.insert_tiles ? ctx->cus / p.insert_tiles : 1u;     // workgroups per tile layer
     uint32_t group = units / INSERT_SLICES;                                  // coded frames per launch
@@ -776,9 +796,11 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
                         const rbf_seeds *seeds,
                         void *filters_dev, uint64_t filter_stride_bytes,
                         void *witnesses_dev, uint64_t witness_stride_bytes,
-                        uint64_t *stats_dev, bool outputs_zeroed)
+                        uint64_t *stats_dev, bool outputs_zeroed, const uint64_t *ones_host /* nullable: set bits of every mask */)
 {
-    const Plan pl = make_plan(ctx, params, nframes, n);
+    uint64_t nrecords = 0;
+    if (ones_host) for (uint32_t f = 0; f < nframes; ++f) if (params[f].m) nrecords += ones_host[f];
+    const Plan pl = make_plan(ctx, params, nframes, n, ones_host && nrecords < (1ull << 32));
     FrameTable tab;
     if (int r = fill_table(params, nframes, &tab)) return r;
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * pl.words_per_seg * 8)) return r;
@@ -827,6 +849,30 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         auto ikern = pl.small_m ? k_insert_lds<true> : k_insert_lds<false>;
         if (int r = allow_big_lds((const void *)ikern)) return r;
         if (int r = allow_big_lds((const void *)k_insert_tab<0>)) return r;
+        bool two_phase = pl.insert_two_phase && use_tab;
+        if (two_phase) {
+            if (grow((void **)&ctx->ins_records, &ctx->ins_records_cap, (size_t)(nrecords ? nrecords : 1) * 8) ||
+                grow((void **)&ctx->ins_counters, &ctx->ins_counters_cap, (size_t)MAX_BATCH * 4)) two_phase = false;
+        }
+        if (pl.insert_two_phase && !two_phase) return fail(RBF_ENOMEM, "no device memory for %llu insert records", (unsigned long long)nrecords);
+        if (two_phase) {
+            // itab.floor_k / rtab.T carry the index of the frame's first record (the kernels' own use of those fields: none)
+            uint64_t first = 0;
+            for (uint32_t f = 0; f < nframes; ++f) {
+                itab.f[f].floor_k = (uint32_t)first;
+                if (params[f].m) first += ones_host[f];
+            }
+            HIP_TRY(hipMemsetAsync(ctx->ins_counters, 0, (size_t)nframes * 4, ctx->stream));
+            const uint64_t groups = (((n + 7) >> 3) + IT_STEP_BYTES - 1) / IT_STEP_BYTES;
+            uint64_t S1 = (uint64_t)ctx->cus * 4 / (nframes ? nframes : 1);           // ~4 workgroups of 4 waves per CU (2160p x 8: 96 us; 8 per CU: 115) ...
+            if (S1 > groups / (IP_WAVES * 4)) S1 = groups / (IP_WAVES * 4);           // ... each wave with >= 4 steps
+            S1 &= ~7ull;                                                              // a slice stays on one XCD across frames
+            if (S1 < 1) S1 = 1;
+            if (int r = allow_big_lds((const void *)k_insert_records)) return r;
+            LaunchTimer t(ctx, RBF_K_INSERT);
+            hipLaunchKernelGGL(k_insert_positions<0>, dim3((uint32_t)S1, nframes), dim3(IP_THREADS), 0, ctx->stream,
+                               (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, ctx->ins_records, ctx->ins_counters);
+        }
         for (uint32_t f0 = 0; f0 < nframes;) {                    // groups of pl.insert_group coded frames
             SliceTable grp{};
             uint32_t per_tile = 0, coded = 0, f = f0;
@@ -838,7 +884,14 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
             f0 = f;
             if (!per_tile) continue;
             LaunchTimer t(ctx, RBF_K_INSERT);
-            if (use_tab)
+            if (two_phase) {
+                FrameTable rtab = tab;
+                uint64_t first = 0;
+                for (uint32_t g = 0; g < nframes; ++g) { rtab.f[g].T = first; if (params[g].m) first += ones_host[g]; }
+                hipLaunchKernelGGL(k_insert_records, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                                   (const uint2 *)ctx->ins_records, (const uint32_t *)ctx->ins_counters, rtab, ctx->partials, part_stride,
+                                   pl.insert_tile_words, grp, per_tile, pl.S);
+            } else if (use_tab)
                 hipLaunchKernelGGL(k_insert_tab<0>, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
                                    (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, ctx->partials, part_stride,
                                    pl.insert_tile_words, grp, per_tile, pl.S);
@@ -901,7 +954,7 @@ static int encode_batch_impl(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                              const rbf_seeds *seeds,
                              void *filters_dev, uint64_t filter_stride_bytes,
                              void *witnesses_dev, uint64_t witness_stride_bytes,
-                             uint64_t *stats_dev, bool outputs_zeroed)
+                             uint64_t *stats_dev, bool outputs_zeroed, const uint64_t *ones_host = nullptr)
 {
     if (int r = set_device(ctx)) return r;
     if (!masks_dev || !params || !seeds || !filters_dev || !witnesses_dev || !stats_dev) return fail(RBF_EINVAL, "null pointer");
@@ -913,7 +966,7 @@ static int encode_batch_impl(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         if (int r = encode_chunk(ctx, (const uint8_t *)masks_dev + (uint64_t)f0 * mask_stride_bytes, mask_stride_bytes, n, cnt, params + f0, seeds,
                                  (uint8_t *)filters_dev + (uint64_t)f0 * filter_stride_bytes, filter_stride_bytes,
                                  (uint8_t *)witnesses_dev + (uint64_t)f0 * witness_stride_bytes, witness_stride_bytes,
-                                 stats_dev + (uint64_t)f0 * RBF_STATS_PER_FRAME, outputs_zeroed))
+                                 stats_dev + (uint64_t)f0 * RBF_STATS_PER_FRAME, outputs_zeroed, ones_host ? ones_host + f0 : nullptr))
             return r;
     }
     return RBF_OK;
@@ -1042,7 +1095,7 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
     if (params_out) memcpy(params_out, ctx->plan.data(), (size_t)pairs * sizeof(rbf_filter_params));
     if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)pairs * sizeof(double));
     return encode_batch_impl(ctx, masks_dev, mask_stride_bytes, n, pairs, ctx->plan.data(), seeds,
-                             filters_dev, filter_stride_bytes, witnesses_dev, witness_stride_bytes, stats_dev, true);
+                             filters_dev, filter_stride_bytes, witnesses_dev, witness_stride_bytes, stats_dev, true, ctx->ones_pinned + 1);
 }
 
 // ------------------------------------------------------------------------------------------

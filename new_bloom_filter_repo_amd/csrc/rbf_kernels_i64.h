@@ -29,6 +29,7 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash_table(uint64_t n, Seeds see
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t seg = (uint64_t)blockIdx.x * (HT_THREADS / WAVE) + wave;
+    if (seg * QL_SEG_PIXELS >= n) return;                        // the grid is rounded up to 4 segments; the table is not
     const uint64_t i0 = seg * QL_SEG_PIXELS + (uint64_t)lane * QL_P;
     uint64_t h1[QL_P], h2[QL_P], ha[QL_P];
     uint32_t validmask = 0;
@@ -68,47 +69,30 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 constexpr int IT_STEP_BYTES = 128;                 // mask bytes per wave step: a lane owns 16 pixels (two bytes)
 constexpr int IT_QUEUE = 64 + IT_STEP_BYTES * 8;   // carry (< 64) + one wave step
 
-// IAB (ablation mask, tools/bench_insert.hip only; 0 in the library): 1 = no table gather (fake entries), 2 = no LDS
+// IAB (ablation mask, tools/bench_insert.hip only; 0 in the library): 1 = no table gather (fake entries), 2 = no
 // atomics, 4 = no LDS zeroing / partial store, 8 = no queueing (mask bytes read, nothing queued).
-// `tab`: M carries the bits of -1.0 / m (IEEE double, computed on the host) instead of the Barrett constant.
-template <int IAB = 0>
-__global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
-    const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
-    const FrameTable tab, const uint4 *__restrict__ table,
-    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t tile_words /* even */,
-    const SliceTable slices, uint32_t per_tile /* sum of slices.n */, uint32_t Smax /* max of slices.n: row pitch of the partials */)
+// `fd`: M carries the bits of -1.0 / m (IEEE double, computed on the host) instead of the Barrett constant.
+//
+// The body shared by the two table-driven kernels that walk a mask: this wave takes wave steps g0 + wave, + NWAVES, ... < g1,
+// compacts the set positions through its LDS queue `q` and, for every batch of <= 64 keys, gathers the table entries and
+// reduces them.  RECORDS = false (k_insert_tab): the probe positions are OR-ed into the LDS tile `filt` covering bits
+// [tile_bit0, tile_bit0 + tile_bits).  RECORDS = true (k_insert_positions): the batch is appended to the frame's list of
+// InsertRecords, 64 contiguous records per batch, starting at records[rpos] (this wave's own range of the list).
+template <int IAB, bool RECORDS, int NWAVES>
+__device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mask, uint64_t n, const FrameDev &fd, const uint4 *__restrict__ table,
+                                                 uint32_t *filt, uint32_t tile_bit0, uint32_t tile_bits, uint2 *__restrict__ records, uint32_t rpos,
+                                                 uint32_t *q, uint64_t g0, uint64_t g1, uint32_t lane, uint32_t wave)
 {
-    // workgroup -> (tile, frame, slice) exactly as in k_insert_lds (one-dimensional grid, slice fastest)
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *filt = lds;                                         // [tile_words]
-    uint32_t *queues = lds + tile_words;                          // [IL_WAVES][IT_QUEUE]
-    const uint32_t tile = blockIdx.x / per_tile;
-    uint32_t s = blockIdx.x - tile * per_tile, f = 0;
-    while (s >= slices.n[f]) { s -= slices.n[f]; ++f; }
-    const uint32_t S = slices.n[f];
-    const FrameDev fd = tab.f[f];
-    if (fd.m == 0) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t fwords = filter_words(fd.m);
-    const uint32_t tile0 = tile * tile_words;
-    if (tile0 >= fwords) return;
-    const uint32_t tile_bit0 = tile0 << 5, tile_bits = tile_words << 5;
-    if (!(IAB & 4)) for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
-    __syncthreads();
-
-    const uint8_t *mask = masks + (uint64_t)f * mask_stride_bytes;
     const uint64_t nbytes = (n + 7) >> 3;
-    const uint64_t groups = (nbytes + IT_STEP_BYTES - 1) / IT_STEP_BYTES;   // wave steps of 128 mask bytes = 1024 pixels
-    const uint64_t gper = (groups + S - 1) / S;
-    const uint64_t g0 = (uint64_t)s * gper;
-    const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
-    uint32_t *q = queues + wave * IT_QUEUE;
     uint32_t qn = 0;                                               // wave-uniform queue length
-
     const uint32_t m = vgpr_copy(__builtin_amdgcn_readfirstlane(fd.m));
     const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
     const double ninv = __builtin_bit_cast(double, fd.M);
     const uint64_t T = fd.T;
+    auto set_bit = [&](uint32_t pos) {
+        const uint32_t rel = pos - tile_bit0;                      // unsigned: out-of-tile positions wrap high
+        if (rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
+    };
 
     // one batch of <= 64 keys in flight: its table entries are requested (`fetch`) when the batch leaves the queue and
     // consumed (`finish`) when the next batch is ready -- or at the end -- so the gather latency hides under compaction
@@ -127,15 +111,18 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
             const uint64_t ha = ((uint64_t)e1.w << 32) | e1.z;
             uint32_t pos = mod_m_f64(hd1, e1.x, ninv, m);
             const uint32_t step = mod_m_f64(hd2, e1.y, ninv, m);
-            for (uint32_t j = 0; j < fk; ++j) {
-                const uint32_t rel = pos - tile_bit0;              // unsigned: out-of-tile positions wrap high
-                if (rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
-                const uint32_t s2 = pos + step;
-                pos = min(s2, s2 - m);
+            if (RECORDS) {
+                records[rpos + lane] = make_uint2(pos, step | (ha < T ? 0x80000000u : 0u));
+            } else {
+                for (uint32_t j = 0; j < fk; ++j) {
+                    set_bit(pos);
+                    const uint32_t s2 = pos + step;
+                    pos = min(s2, s2 - m);
+                }
+                if (ha < T) set_bit(pos);
             }
-            const uint32_t rel = pos - tile_bit0;
-            if (ha < T && rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
         }
+        if (RECORDS) rpos += pending;
         pending = 0;
     };
 
@@ -152,9 +139,9 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
         return b;
     };
     uint32_t nxt = load_bits(g0 + wave);
-    for (uint64_t g = g0 + wave; g < g1; g += IL_WAVES) {
+    for (uint64_t g = g0 + wave; g < g1; g += NWAVES) {
         uint32_t bits = (IAB & 8) ? (nxt & 0u) : nxt;
-        nxt = load_bits(g + IL_WAVES);                             // prefetch
+        nxt = load_bits(g + NWAVES);                               // prefetch
         // exclusive prefix of the per-lane counts (0..16): six DPP adds (the five ballots + ten mbcnt of k_insert_lds were a
         // third of this loop's skeleton)
         const uint32_t c = __popc(bits);
@@ -178,12 +165,165 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     }
     finish();
     if (qn) { fetch(0, qn); finish(); }
+}
+
+template <int IAB = 0>
+__global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
+    const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
+    const FrameTable tab, const uint4 *__restrict__ table,
+    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t tile_words /* even */,
+    const SliceTable slices, uint32_t per_tile /* sum of slices.n */, uint32_t Smax /* max of slices.n: row pitch of the partials */)
+{
+    // workgroup -> (tile, frame, slice) exactly as in k_insert_lds (one-dimensional grid, slice fastest)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *filt = lds;                                         // [tile_words]
+    uint32_t *queues = lds + tile_words;                          // [IL_WAVES][IT_QUEUE]
+    const uint32_t tile = blockIdx.x / per_tile;
+    uint32_t s = blockIdx.x - tile * per_tile, f = 0;
+    while (s >= slices.n[f]) { s -= slices.n[f]; ++f; }
+    const uint32_t S = slices.n[f];
+    const FrameDev fd = tab.f[f];
+    if (fd.m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t fwords = filter_words(fd.m);
+    const uint32_t tile0 = tile * tile_words;
+    if (tile0 >= fwords) return;
+    if (!(IAB & 4)) for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
+    __syncthreads();
+
+    const uint64_t nbytes = (n + 7) >> 3;
+    const uint64_t groups = (nbytes + IT_STEP_BYTES - 1) / IT_STEP_BYTES;   // wave steps of 128 mask bytes = 1024 pixels
+    const uint64_t gper = (groups + S - 1) / S;
+    const uint64_t g0 = (uint64_t)s * gper;
+    const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
+    insert_tab_steps<IAB, false, IL_WAVES>(masks + (uint64_t)f * mask_stride_bytes, n, fd, table, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
+                                           queues + wave * IT_QUEUE, g0, g1, lane, wave);
     __syncthreads();
     uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;
     const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
     const uint32_t pairs = (IAB & 4) ? 1u : (mine + 1) >> 1;      // tile0 is even: 8-byte aligned
     for (uint32_t i = threadIdx.x; i < pairs; i += IL_THREADS)
         reinterpret_cast<uint2 *>(part)[i] = reinterpret_cast<const uint2 *>(filt)[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Filters that do not fit one LDS tile next to the queues (1440p and up).  k_insert_tab walks the mask, compacts and
+// gathers the table once PER TILE (2160p: 3 tiles, 166 us for 8 frames; the 265 MB table no longer sits in the 256 MB L3).
+// Two kernels instead:
+//   k_insert_positions   one walk: (slice, frame) workgroups of 256 threads compact + gather + reduce as above and append
+//                        one 8-byte InsertRecord per set position -- x = first probe position, y = probe step | activated
+//                        extra probe << 31 -- to the frame's list, in no particular order (the filter is an OR).  A
+//                        workgroup first counts the set bits of its slice (the mask row is L2-resident) and reserves its
+//                        range of the list with ONE atomicAdd; every wave then owns a contiguous sub-range.  (One atomicAdd
+//                        per 64-record batch was measured first: same-address atomics with return complete every ~90 ns,
+//                        1.07 ms for the 92 k batches of a 2160p GOP.)
+//   k_insert_records     (tile, frame, slice) workgroups stream their share of the list with coalesced loads -- full waves
+//                        by construction, no queue, so the tile may use all of LDS (2160p: 2 tiles) -- and OR the in-tile
+//                        probes into it; partial filters out, k_filter_reduce as before.
+// (OR-ing straight into the filter rows with no-return L2 atomics was measured first: 27 G atomics/s, 520 us at 2160p.)
+// ------------------------------------------------------------------------------------------
+constexpr int IP_THREADS = 256, IP_WAVES = IP_THREADS / WAVE;
+
+template <int IAB = 0>
+__global__ __launch_bounds__(IP_THREADS) void k_insert_positions(
+    const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
+    const FrameTable tab /* M = bits of -1.0 / m, floor_k = index of the frame's first record */, const uint4 *__restrict__ table,
+    uint2 *__restrict__ records, uint32_t *__restrict__ counters /* zeroed; records appended per frame */)
+{
+    __shared__ uint32_t queues[IP_WAVES * IT_QUEUE];
+    const uint32_t f = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+    const FrameDev fd = tab.f[f];
+    if (fd.m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t nbytes = (n + 7) >> 3;
+    const uint64_t groups = (nbytes + IT_STEP_BYTES - 1) / IT_STEP_BYTES;
+    const uint64_t gper = (groups + S - 1) / S;
+    const uint64_t g0 = (uint64_t)s * gper;
+    const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
+    const uint8_t *mask = masks + (uint64_t)f * mask_stride_bytes;
+    // set bits of this wave's steps -> the wave's range inside the workgroup's reservation
+    __shared__ uint32_t wcount[IP_WAVES];
+    __shared__ uint32_t wg_base;
+    uint32_t mine = 0;
+    for (uint64_t g = g0 + wave; g < g1; g += IP_WAVES) {
+        const uint64_t byte = g * IT_STEP_BYTES + lane * 2;
+        if (byte < nbytes) {
+            uint32_t v = *reinterpret_cast<const uint16_t *>(mask + byte);
+            const uint64_t rem = n - byte * 8;
+            if (rem < 16) {                                        // pad bits do not count (same bit order as load_bits)
+                const uint32_t x = __builtin_bitreverse32(v) >> 16;
+                v = (((x & 0xFFu) << 8) | (x >> 8)) & ((1u << rem) - 1u);
+            }
+            mine += __popc(v);
+        }
+    }
+    const uint32_t wave_total = __builtin_amdgcn_readlane(wave_inclusive_scan(mine), 63);
+    if (lane == 0) wcount[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < IP_WAVES; ++k) t += wcount[k];
+        wg_base = t ? atomicAdd(counters + f, t) : 0u;
+    }
+    __syncthreads();
+    uint32_t rpos = wg_base;
+    for (uint32_t k = 0; k < wave; ++k) rpos += wcount[k];
+    insert_tab_steps<IAB, true, IP_WAVES>(mask, n, fd, table, nullptr, 0u, 0u, records + fd.floor_k, (uint32_t)__builtin_amdgcn_readfirstlane((int)rpos),
+                                          queues + wave * IT_QUEUE, g0, g1, lane, wave);
+}
+
+constexpr int IR_UNROLL = 4;                        // records in flight per lane
+
+__global__ __launch_bounds__(IL_THREADS) void k_insert_records(
+    const uint2 *__restrict__ records, const uint32_t *__restrict__ counters, const FrameTable tab /* T = index of the frame's first record */,
+    uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t tile_words /* even */,
+    const SliceTable slices, uint32_t per_tile /* sum of slices.n */, uint32_t Smax)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [tile_words]
+    const uint32_t tile = blockIdx.x / per_tile;
+    uint32_t s = blockIdx.x - tile * per_tile, f = 0;
+    while (s >= slices.n[f]) { s -= slices.n[f]; ++f; }
+    const uint32_t S = slices.n[f];
+    const uint32_t m = tab.f[f].m;
+    if (m == 0) return;
+    const uint32_t fk = tab.f[f].floor_k;
+    const uint32_t fwords = filter_words(m);
+    const uint32_t tile0 = tile * tile_words;
+    if (tile0 >= fwords) return;
+    const uint32_t tile_bit0 = tile0 << 5, tile_bits = tile_words << 5;
+    for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) lds[i] = 0;
+    __syncthreads();
+    const uint32_t count = counters[f];
+    const uint32_t per = (((count + S - 1) / S) + 63u) & ~63u;
+    const uint32_t r0 = s * per < count ? s * per : count, r1 = r0 + per < count ? r0 + per : count;
+    const uint2 *rec = records + tab.f[f].T;
+    auto insert = [&](uint2 r) {
+        uint32_t pos = r.x;
+        const uint32_t step = r.y & 0x7FFFFFFFu;
+        for (uint32_t j = 0; j < fk; ++j) {
+            const uint32_t rel = pos - tile_bit0;
+            if (rel < tile_bits) atomicOr(&lds[rel >> 5], msb_bit(pos));
+            const uint32_t s2 = pos + step;
+            pos = min(s2, s2 - m);
+        }
+        const uint32_t rel = pos - tile_bit0;
+        if ((r.y >> 31) && rel < tile_bits) atomicOr(&lds[rel >> 5], msb_bit(pos));
+    };
+    uint32_t i = r0 + threadIdx.x;
+    for (; i + (IR_UNROLL - 1) * IL_THREADS < r1; i += IR_UNROLL * IL_THREADS) {
+        uint2 r[IR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < IR_UNROLL; ++u) r[u] = rec[i + u * IL_THREADS];
+#pragma unroll
+        for (int u = 0; u < IR_UNROLL; ++u) insert(r[u]);
+    }
+    for (; i < r1; i += IL_THREADS) insert(rec[i]);
+    __syncthreads();
+    uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;
+    const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
+    const uint32_t pairs = (mine + 1) >> 1;                       // tile0 is even: 8-byte aligned
+    for (uint32_t k = threadIdx.x; k < pairs; k += IL_THREADS)
+        reinterpret_cast<uint2 *>(part)[k] = reinterpret_cast<const uint2 *>(lds)[k];
 }
 
 }  // namespace rbf

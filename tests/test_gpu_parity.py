@@ -14,7 +14,8 @@ from new_bloom_filter_repo_amd.synthetic import make_gop, make_mask, P_KSTAR_2_3
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["lds_double_buffer", "lds_single_buffer", "lds_barrett_only", "lds_query_p4", "hash_in_insert", "lds_tiled_1KiB", "lds_tiled_8KiB", "generic"])
+@pytest.fixture(scope="module", params=["lds_double_buffer", "lds_single_buffer", "lds_barrett_only", "lds_query_p4", "hash_in_insert", "lds_tiled_1KiB", "lds_tiled_8KiB",
+                                        "lds_tiled_8KiB_insert_tab", "generic"])
 def eng(request):
     """Every kernel family must be bit-exact: the LDS-resident fast path (default whenever the filter
     fits in LDS; with and without filter double-buffering), the LDS-tiled path that 4K-class filters
@@ -23,9 +24,11 @@ def eng(request):
     pipe whenever every filter of the batch has 2^15 <= m < 2^23 (1080p / 2160p frames); "lds_barrett_only" keeps the
     integer Barrett reductions, so both forms are pinned to the same fixtures.  "lds_query_p4" selects the 4-pixels-per-
     lane FP64 query kernel, "hash_in_insert" the insert kernel that hashes the set positions itself instead of gathering
-    from the pixel-index hash table."""
+    from the pixel-index hash table.  With tiles, rbf_encode_gop (which knows the masks' set-bit counts) inserts through
+    k_insert_positions + k_insert_records; "lds_tiled_8KiB_insert_tab" keeps the tiled k_insert_tab there too."""
     ctx = nat.Context(0)
     ctx.force_generic({"lds_double_buffer": 0, "lds_single_buffer": 2, "lds_barrett_only": 8, "lds_query_p4": 64, "hash_in_insert": 32, "lds_tiled_1KiB": 4 << 16, "lds_tiled_8KiB": 32 << 16,
+                       "lds_tiled_8KiB_insert_tab": (32 << 16) | 128,
                        "generic": 1}[request.param])
     e = BloomEngine(ctx)
     yield e
@@ -344,6 +347,48 @@ def test_random_geometry_fuzz(oracle):
             dec = eng.decode(n, [P.filter_params(k, l)], [r["filter"]], [r["witness"]], seeds=seeds)
             assert np.array_equal(unpack(dec[0], n), want), (case, f)
         coder.close()
+    eng.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("force", [32 << 16, (32 << 16) | 128, 4 << 16, 0], ids=["records_8KiB_tiles", "insert_tab_8KiB_tiles", "records_1KiB_tiles", "default"])
+def test_gop_insert_paths_with_tiles(oracle, force):
+    """rbf_encode_gop on filters of several LDS tiles (forced by a tile cap on a 640x360 GOP, m ~ 60-70 kbit, inside the
+    FP64 reduction's range): the two-kernel insert (k_insert_positions + k_insert_records, taken because the call knows the
+    masks' set-bit counts) and the tiled k_insert_tab must both reproduce the oracle's filter and witness bytes, also for a
+    frame without changes (m = 0, no records) and for a dense one that is not Bloom-coded."""
+    from new_bloom_filter_repo_amd.gop import GopCoder
+    from new_bloom_filter_repo_amd.synthetic import next_frame
+    rng = np.random.default_rng(4242)
+    W, H, n = 640, 360, 640 * 360
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8)]
+    for p in (0.0889, 0.0, 0.05, 0.6, 0.2, 0.0889):
+        frames.append(next_frame(rng, frames[-1], p) if p else frames[-1].copy())
+    frames = np.stack(frames)
+    ctx = nat.Context(0)
+    ctx.force_generic(force)
+    eng = BloomEngine(ctx)
+    coder = GopCoder(ctx, W, H, len(frames))
+    coder.load_frames(frames)
+    for _ in range(2):                                        # second pass: hash table written by the previous query kernel
+        coder.encode()
+        coded = 0
+        for f, r in enumerate(coder.results()):
+            want = oracle.residual_mask(np.ascontiguousarray(frames[f][..., 0]), np.ascontiguousarray(frames[f + 1][..., 0]), 0.0).reshape(-1)
+            assert np.array_equal(unpack(r["mask"], n), want), f
+            bm, wit, p, _, _ = oracle.compress(want)
+            if len(wit) == 0:
+                assert r["l"] == 0 and r["witness_bits"] == 0, f
+                continue
+            coded += 1
+            k, l = oracle.optimal_params(n, p)
+            assert (r["k"], r["l"]) == (k, l), f
+            assert np.array_equal(unpack(r["filter"], l), bm), f
+            assert r["witness_bits"] == len(wit) and np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8)), f
+            dec = eng.decode(n, [P.filter_params(k, l)], [r["filter"]], [r["witness"]])
+            assert np.array_equal(unpack(dec[0], n), want), f
+        assert coded == 4
+    coder.close()
     eng.close()
     ctx.close()
 

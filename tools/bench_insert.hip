@@ -50,8 +50,92 @@ static float run_tab(const uint8_t *masks, uint64_t mstride, uint64_t n, uint32_
     return ms / R * 1000.f;
 }
 
+// BIG=1: the 2160p geometry (8 coded frames, 306 KB filters): k_insert_tab over 3 LDS tiles against k_insert_tab_g (L2 atomics)
+static int big()
+{
+    const uint64_t n = 3840ull * 2160; const uint32_t F = 8, m = 2444632;
+    const uint64_t mstride = ((n + 63) / 64) * 8, fwords = (m + 31) / 32, pstride = (fwords + 3) & ~3ull;
+    std::vector<uint8_t> hm(mstride * F);
+    srand(1);
+    for (auto &x : hm) { uint8_t v = 0; for (int b = 0; b < 8; ++b) if (rand() % 1000 < 89) v |= 1u << b; x = v; }
+    uint8_t *dm; uint32_t *dp, *dg; uint4 *dt;
+    const uint32_t S = 10, tiles = 4;
+    CK(hipMalloc(&dm, hm.size())); CK(hipMalloc(&dp, (size_t)F * S * pstride * 4)); CK(hipMalloc(&dg, (size_t)F * pstride * 4)); CK(hipMalloc(&dt, (n + 8192) * 32));
+    CK(hipMemcpy(dm, hm.data(), hm.size(), hipMemcpyHostToDevice));
+    FrameTable tab{};
+    for (uint32_t f = 0; f < F; ++f) { tab.f[f].m = m - 37 * f; tab.f[f].floor_k = 2; tab.f[f].T = 0x4D00000000000000ull; const double ninv = -1.0 / (double)tab.f[f].m; memcpy(&tab.f[f].M, &ninv, 8); }
+    Seeds sd{0x12345678, 0x87654321, 999};
+    const uint32_t segs = (uint32_t)((n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS);
+    hipLaunchKernelGGL(k_hash_table, dim3((segs + 3) / 4), dim3(HT_THREADS), 0, 0, n, sd, dt);
+    CK(hipDeviceSynchronize());
+    printf("masks %p..%p partials %p..%p filters %p..%p table %p..%p\n", dm, dm + hm.size(), dp, dp + (size_t)F * S * pstride, dg, dg + (size_t)F * pstride, dt, dt + 2 * (n + 8192)); fflush(stdout);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float ms;
+    const size_t pw = (size_t)F * S * pstride;
+    std::vector<uint32_t> ref(pw), got((size_t)F * pstride);
+    {
+        const uint32_t tile_words = (uint32_t)(((fwords + tiles - 1) / tiles + 3) & ~3ull);
+        const size_t lds = (size_t)tile_words * 4 + (size_t)IL_WAVES * IT_QUEUE * 4;
+        auto kern = k_insert_tab<0>;
+        CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SliceTable sl{}; uint32_t per_tile = 0;
+        for (uint32_t f = 0; f < F; ++f) { sl.n[f] = (uint8_t)S; per_tile += S; }
+        CK(hipMemset(dp, 0, pw * 4));
+        for (int r = 0; r < 12; ++r) {
+            if (r == 2) CK(hipEventRecord(a));
+            hipLaunchKernelGGL(kern, dim3(per_tile * tiles), dim3(IL_THREADS), lds, 0, dm, mstride, n, tab, dt, dp, pstride, tile_words, sl, per_tile, S);
+        }
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+        CK(hipGetLastError());
+        printf("%-52s %8.1f us\n", "2160p x 8: k_insert_tab, 4 LDS tiles, 10 slices", ms * 100.f); fflush(stdout);
+        CK(hipMemcpy(ref.data(), dp, pw * 4, hipMemcpyDeviceToHost));
+    }
+    // two kernels: one walk into position records, then tiles of all of LDS filled from the records
+    uint2 *dr; uint32_t *dc;
+    std::vector<uint64_t> ones(F, 0);
+    for (uint32_t f = 0; f < F; ++f) for (uint64_t i = 0; i < mstride; ++i) ones[f] += __builtin_popcount(hm[f * mstride + i]);     // n is a multiple of 64: no pad bits
+    uint64_t total = 0;
+    FrameTable itab = tab, rtab = tab;
+    for (uint32_t f = 0; f < F; ++f) { itab.f[f].floor_k = (uint32_t)total; rtab.f[f].T = total; total += ones[f]; }
+    CK(hipMalloc(&dr, total * 8)); CK(hipMalloc(&dc, F * 4));
+    const uint32_t tiles2 = 2, S2 = 16;
+    const uint32_t tw2 = (uint32_t)(((fwords + tiles2 - 1) / tiles2 + 3) & ~3ull);
+    CK(hipFuncSetAttribute((const void *)k_insert_records, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SliceTable sl2{}; uint32_t per_tile2 = 0;
+    for (uint32_t f = 0; f < F; ++f) { sl2.n[f] = (uint8_t)S2; per_tile2 += S2; }
+    uint32_t *dp2; CK(hipMalloc(&dp2, (size_t)F * S2 * pstride * 4)); CK(hipMemset(dp2, 0, (size_t)F * S2 * pstride * 4));
+    const uint32_t S1s[] = {64, 128, 248, 504};
+    for (uint32_t S1 : S1s) {
+        float t1 = 0, t2 = 0;
+        hipEvent_t c; CK(hipEventCreate(&c));
+        for (int r = 0; r < 12; ++r) {
+            CK(hipMemsetAsync(dc, 0, F * 4, 0));
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL(k_insert_positions<0>, dim3(S1, F), dim3(IP_THREADS), 0, 0, dm, mstride, n, itab, dt, dr, dc);
+            CK(hipEventRecord(c));
+            hipLaunchKernelGGL(k_insert_records, dim3(per_tile2 * tiles2), dim3(IL_THREADS), (size_t)tw2 * 4, 0, dr, dc, rtab, dp2, pstride, tw2, sl2, per_tile2, S2);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float x, y; CK(hipEventElapsedTime(&x, a, c)); CK(hipEventElapsedTime(&y, c, b));
+            if (r >= 2) { t1 += x; t2 += y; }
+        }
+        CK(hipGetLastError());
+        std::vector<uint32_t> got2((size_t)F * S2 * pstride);
+        CK(hipMemcpy(got2.data(), dp2, got2.size() * 4, hipMemcpyDeviceToHost));
+        size_t diff = 0;
+        for (uint32_t f = 0; f < F; ++f) for (uint32_t w = 0; w < (tab.f[f].m + 31) / 32; ++w) {
+            uint32_t x = 0, y = 0;
+            for (uint32_t sl = 0; sl < S; ++sl) x |= ref[((size_t)f * S + sl) * pstride + w];
+            for (uint32_t sl = 0; sl < S2; ++sl) y |= got2[((size_t)f * S2 + sl) * pstride + w];
+            diff += x != y; }
+        printf("2160p x 8: k_insert_positions (%3u slices) %6.1f us + k_insert_records (2 tiles x 16 slices) %6.1f us   (%zu words differ from the tiled kernel's)\n",
+               S1, t1 * 100.f, t2 * 100.f, diff);
+    }
+    return 0;
+}
+
 int main()
 {
+    if (getenv("BIG")) return big();
     const uint64_t n = 1920 * 1080; const uint32_t F = getenv("F") ? (uint32_t)atoi(getenv("F")) : 29, S = 8; const uint32_t m = 611158;
     const uint64_t mstride = ((n + 63) / 64) * 8, fwords = (m + 31) / 32, pstride = (fwords + 3) & ~3ull;
     std::vector<uint8_t> hm(mstride * F);
