@@ -499,31 +499,43 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64t(
     uint32_t ntiles = (fwords + tile_words - 1) / tile_words;
     const uint32_t fbase = vgpr_copy(__builtin_amdgcn_readfirstlane(lds_addr_of(lds)));
 
-    while (f < nframes) {
-        // ---- per frame: the two reductions of every pixel, once
-        const FrameDev fd = tab.f[f];
+    // Software-pipelined over the frames: the DMA of the NEXT frame's first tile is issued as soon as the last probes of this
+    // frame are done (one barrier), and flies while this frame's verdicts go out and the next frame's 16 reductions per lane
+    // -- which need no filter -- are computed (~1 600 of the ~2 400 cycles a 153 KB tile takes to arrive).
+    uint32_t pos0[QL_P], step[QL_P], fail[QL_P];
+    uint32_t notact = 0, m_v = 0, fk = 0;
+    auto frame_setup = [&](uint32_t ff) {                            // geometry scalars + the two reductions of every pixel, once per frame
+        const FrameDev fd = tab.f[ff];
         const uint32_t m_s = __builtin_amdgcn_readfirstlane(fd.m);
-        const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
-        const uint32_t m_v = vgpr_copy(m_s);
+        fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
+        m_v = vgpr_copy(m_s);
         // (__builtin_amdgcn_readfirstlane returns int: every half goes through uint32_t, or the low one sign-extends into the high one)
         const uint32_t nhi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32)), nlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.M);
         const uint32_t thi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.T >> 32)), tlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.T);
         const double ninv = __builtin_bit_cast(double, ((uint64_t)nhi << 32) | nlo);
         const uint64_t T = ((uint64_t)thi << 32) | tlo;
-        uint32_t pos0[QL_P], step[QL_P], fail[QL_P];
-        uint32_t notact = 0;
+        notact = 0;
 #pragma unroll
         for (int it = 0; it < QL_P; ++it) {
-            pos0[it] = mod_m_f64((double)h1[it], (uint32_t)h1[it], ninv, m_v);
-            step[it] = mod_m_f64((double)h2[it], (uint32_t)h2[it], ninv, m_v);
+            // opaque copies: with the setup inlined before the loop and at its end, the compiler would otherwise keep the
+            // 16 converted doubles (frame-invariant) live across the whole loop -- 32 registers, 174 dwords of spills
+            uint64_t a1 = h1[it], a2 = h2[it];
+            asm volatile("" : "+v"(a1), "+v"(a2));
+            pos0[it] = mod_m_f64((double)a1, (uint32_t)a1, ninv, m_v);
+            step[it] = mod_m_f64((double)a2, (uint32_t)a2, ninv, m_v);
             notact |= (ha[it] < T) ? 0u : (1u << it);
             fail[it] = 0;
         }
-        const uint32_t fnext = __builtin_amdgcn_readfirstlane(next_active(f + 1));
-        const uint32_t fwords_next = fnext < nframes ? __builtin_amdgcn_readfirstlane(filter_words(tab.f[fnext].m)) : 0u;
+    };
+    frame_setup(f);
+    if (!(AB & 32)) __syncthreads();              // the SAFE dword is in place
+    stage_dma(f, fwords, 0);
+    while (true) {
         for (uint32_t t = 0; t < ntiles; ++t) {
-            if (!(AB & 32)) __syncthreads();      // the previous stage's probes are done
-            stage_dma(f, fwords, t);
+            if (t) {
+                if (!(AB & 32)) __syncthreads();  // the previous tile's probes are done
+                stage_dma(f, fwords, t);
+            }
             if (!(AB & 32)) {
                 dma_wait_all();                   // my share has landed ...
                 __syncthreads();                  // ... and everyone's
@@ -536,10 +548,16 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64t(
             default: tile_part_f64<-1, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
             }
         }
-        // ---- verdicts of the frame
         uint32_t pbf = 0, npass = 0;
 #pragma unroll
         for (int it = 0; it < QL_P; ++it) pbf = __builtin_amdgcn_alignbit(pbf, fail[it], 31);
+        const uint32_t fnext = __builtin_amdgcn_readfirstlane(next_active(f + 1));
+        const uint32_t fwords_next = fnext < nframes ? __builtin_amdgcn_readfirstlane(filter_words(tab.f[fnext].m)) : 0u;
+        if (fnext < nframes) {
+            if (!(AB & 32)) __syncthreads();      // this frame's last probes are done: the buffer is free
+            stage_dma(fnext, fwords_next, 0);
+        }
+        // ---- verdicts of the frame
         const uint32_t pb = ~(pbf | invalid_byte) & 0xFFu;
 #pragma unroll
         for (int it = 0; it < QL_P; ++it) npass += __popcll(__ballot(((pb >> (7 - it)) & 1u) != 0));
@@ -547,9 +565,11 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_f64t(
             pass_bytes[((uint64_t)f * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)pb;
             if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
         }
+        if (fnext >= nframes) break;
         f = fnext;
         fwords = fwords_next;
         ntiles = (fwords + tile_words - 1) / tile_words;
+        frame_setup(f);
     }
 }
 
