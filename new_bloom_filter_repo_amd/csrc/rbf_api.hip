@@ -53,6 +53,7 @@ struct rbf_ctx {
     uint2 *ins_records = nullptr;    size_t ins_records_cap = 0;  // two-kernel insert: 8 bytes per set mask bit of the batch
     uint32_t *ins_counters = nullptr; size_t ins_counters_cap = 0; // ... and the records appended so far, per frame
     int no_two_phase = 0;            // 1 = tiled k_insert_tab even when the filter needs several LDS tiles
+    int hash_positions = 0;          // 1 = k_insert_positions hashes the set positions itself whatever the table size
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
@@ -281,7 +282,8 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->query_p4 = (on & 64) ? 1 : 0;
     ctx->no_hash_table = (on & 32) ? 1 : 0;
     ctx->no_two_phase = (on & 128) ? 1 : 0;
-    ctx->mask_chunks = (uint32_t)(on >> 8) & 0xFF;           // tuning knob, bits 8..15
+    ctx->mask_chunks = (uint32_t)(on >> 8) & 0x3F;           // tuning knob, bits 8..13
+    ctx->hash_positions = (on & (1 << 14)) ? 1 : 0;
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
     return RBF_OK;
 }
@@ -418,6 +420,7 @@ struct Plan {
     uint32_t image_stride_words;  // row pitch of the probe image (dwords, multiple of 4)
 };
 
+constexpr size_t HASH_TABLE_CACHE_BYTES = (size_t)192 << 20;   // a pixel-index hash table larger than this is not worth gathering from (measured at 265 MB)
 constexpr uint32_t MAX_INSERT_TILES = 7, MAX_QUERY_TILES = 3;     // measured crossovers, see make_plan
 
 static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n, bool have_ones = false)
@@ -822,7 +825,10 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         // hash table of the pixel indices (k_hash_table): built for this batch, or kept from the last one when the
         // context was told to cache it; without device memory for it the insert kernel hashes for itself
         bool use_tab = pl.insert_tab;
-        if (use_tab) {
+        // two-kernel insert of frames whose table (32 B per pixel) would not fit the 256 MB Infinity Cache: the set positions are
+        // hashed in the kernel instead (2160p: 72 us against 96 with the gather) and no table is built
+        const bool hashed_positions = pl.insert_two_phase && (ctx->hash_positions || ((size_t)n + QL_SEG_PIXELS) * 32 > HASH_TABLE_CACHE_BYTES);
+        if (use_tab && !hashed_positions) {
             const size_t need = ((size_t)n + QL_SEG_PIXELS) * 32;
             if (ctx->hash_tab_cap < need) {
                 if (ctx->hash_tab) { HIP_TRY(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->hash_tab); }
@@ -831,7 +837,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
                 else ctx->hash_tab_cap = need;
             }
         }
-        if (use_tab) {
+        if (use_tab && !hashed_positions) {
             const bool same = ctx->hash_tab_valid && ctx->hash_tab_n == n && ctx->hash_tab_seeds.h1 == seeds->h1 &&
                               ctx->hash_tab_seeds.h2 == seeds->h2 && ctx->hash_tab_seeds.act == seeds->act;
             if (ctx->hash_rebuild || !same) {
@@ -870,8 +876,12 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
             if (S1 < 1) S1 = 1;
             if (int r = allow_big_lds((const void *)k_insert_records)) return r;
             LaunchTimer t(ctx, RBF_K_INSERT);
-            hipLaunchKernelGGL(k_insert_positions<0>, dim3((uint32_t)S1, nframes), dim3(IP_THREADS), 0, ctx->stream,
-                               (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, ctx->ins_records, ctx->ins_counters);
+            if (hashed_positions)
+                hipLaunchKernelGGL((k_insert_positions<0, true>), dim3((uint32_t)S1, nframes), dim3(IP_THREADS), 0, ctx->stream,
+                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)nullptr, sd, ctx->ins_records, ctx->ins_counters);
+            else
+                hipLaunchKernelGGL((k_insert_positions<0, false>), dim3((uint32_t)S1, nframes), dim3(IP_THREADS), 0, ctx->stream,
+                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, sd, ctx->ins_records, ctx->ins_counters);
         }
         for (uint32_t f0 = 0; f0 < nframes;) {                    // groups of pl.insert_group coded frames
             SliceTable grp{};

@@ -78,8 +78,11 @@ constexpr int IT_QUEUE = 64 + IT_STEP_BYTES * 8;   // carry (< 64) + one wave st
 // reduces them.  RECORDS = false (k_insert_tab): the probe positions are OR-ed into the LDS tile `filt` covering bits
 // [tile_bit0, tile_bit0 + tile_bits).  RECORDS = true (k_insert_positions): the batch is appended to the frame's list of
 // InsertRecords, 64 contiguous records per batch, starting at records[rpos] (this wave's own range of the list).
-template <int IAB, bool RECORDS, int NWAVES>
-__device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mask, uint64_t n, const FrameDev &fd, const uint4 *__restrict__ table,
+// HASHED: no table -- the batch's three hashes are computed on the spot (hash3_index, as k_insert_lds does).  Cheaper than the
+// gather once the table (32 B per pixel) no longer fits the 256 MB Infinity Cache: at 2160p the gather of a GOP's 5.9 M
+// entries costs 58 us of random HBM reads, hashing them ~35.
+template <int IAB, bool RECORDS, int NWAVES, bool HASHED = false>
+__device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mask, uint64_t n, const FrameDev &fd, const uint4 *__restrict__ table, const Seeds &seeds,
                                                  uint32_t *filt, uint32_t tile_bit0, uint32_t tile_bits, uint2 *__restrict__ records, uint32_t rpos,
                                                  uint32_t *q, uint64_t g0, uint64_t g1, uint32_t lane, uint32_t wave)
 {
@@ -101,7 +104,12 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     auto fetch = [&](uint32_t first, uint32_t count) {
         const uint32_t idx = lane < count ? q[first + lane] : 0u;  // idle lanes read entry 0 (always there)
         if (IAB & 1) { e0 = make_uint4(idx * 0x9E3779B1u, 0x41D00000u + (idx & 0xFFFFFu), idx * 0x85EBCA77u, 0x41E00000u + (idx & 0xFFFFu)); e1 = make_uint4(idx * 3u, idx * 7u, idx * 11u, idx * 13u); }
-        else { const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = table[2 * slot + 1]; }
+        else if (HASHED) {
+            const Hash3 h = hash3_index(idx, lane < count, seeds);      // wave-uniform call (it votes on the key length)
+            const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h.h1), d2 = __builtin_bit_cast(uint64_t, (double)h.h2);
+            e0 = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));    // the table's entry format
+            e1 = make_uint4((uint32_t)h.h1, (uint32_t)h.h2, (uint32_t)h.ha, (uint32_t)(h.ha >> 32));
+        } else { const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = table[2 * slot + 1]; }
         pending = count;
     };
     auto finish = [&]() {
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     const uint64_t gper = (groups + S - 1) / S;
     const uint64_t g0 = (uint64_t)s * gper;
     const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
-    insert_tab_steps<IAB, false, IL_WAVES>(masks + (uint64_t)f * mask_stride_bytes, n, fd, table, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
+    insert_tab_steps<IAB, false, IL_WAVES>(masks + (uint64_t)f * mask_stride_bytes, n, fd, table, Seeds{}, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
                                            queues + wave * IT_QUEUE, g0, g1, lane, wave);
     __syncthreads();
     uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;
@@ -224,10 +232,10 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
 // ------------------------------------------------------------------------------------------
 constexpr int IP_THREADS = 256, IP_WAVES = IP_THREADS / WAVE;
 
-template <int IAB = 0>
+template <int IAB = 0, bool HASHED = false>
 __global__ __launch_bounds__(IP_THREADS) void k_insert_positions(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
-    const FrameTable tab /* M = bits of -1.0 / m, floor_k = index of the frame's first record */, const uint4 *__restrict__ table,
+    const FrameTable tab /* M = bits of -1.0 / m, floor_k = index of the frame's first record */, const uint4 *__restrict__ table /* unused when HASHED */, Seeds seeds,
     uint2 *__restrict__ records, uint32_t *__restrict__ counters /* zeroed; records appended per frame */)
 {
     __shared__ uint32_t queues[IP_WAVES * IT_QUEUE];
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_insert_positions(
     __syncthreads();
     uint32_t rpos = wg_base;
     for (uint32_t k = 0; k < wave; ++k) rpos += wcount[k];
-    insert_tab_steps<IAB, true, IP_WAVES>(mask, n, fd, table, nullptr, 0u, 0u, records + fd.floor_k, (uint32_t)__builtin_amdgcn_readfirstlane((int)rpos),
+    insert_tab_steps<IAB, true, IP_WAVES, HASHED>(mask, n, fd, table, seeds, nullptr, 0u, 0u, records + fd.floor_k, (uint32_t)__builtin_amdgcn_readfirstlane((int)rpos),
                                           queues + wave * IT_QUEUE, g0, g1, lane, wave);
 }
 

@@ -351,11 +351,13 @@ def test_random_geometry_fuzz(oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("force", [32 << 16, (32 << 16) | 128, 4 << 16, 0], ids=["records_8KiB_tiles", "insert_tab_8KiB_tiles", "records_1KiB_tiles", "default"])
+@pytest.mark.parametrize("force", [32 << 16, (32 << 16) | (1 << 14), (32 << 16) | 128, 4 << 16, 0],
+                         ids=["records_8KiB_tiles", "records_hashed_8KiB_tiles", "insert_tab_8KiB_tiles", "records_1KiB_tiles", "default"])
 def test_gop_insert_paths_with_tiles(oracle, force):
     """rbf_encode_gop on filters of several LDS tiles (forced by a tile cap on a 640x360 GOP, m ~ 60-70 kbit, inside the
     FP64 reduction's range): the two-kernel insert (k_insert_positions + k_insert_records, taken because the call knows the
-    masks' set-bit counts) and the tiled k_insert_tab must both reproduce the oracle's filter and witness bytes, also for a
+    masks' set-bit counts; with the positions gathered from the pixel-index hash table or hashed in the kernel, as frames of
+    more than ~6 Mpixel do) and the tiled k_insert_tab must all reproduce the oracle's filter and witness bytes, also for a
     frame without changes (m = 0, no records) and for a dense one that is not Bloom-coded."""
     from new_bloom_filter_repo_amd.gop import GopCoder
     from new_bloom_filter_repo_amd.synthetic import next_frame

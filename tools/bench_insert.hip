@@ -111,7 +111,7 @@ static int big()
         for (int r = 0; r < 12; ++r) {
             CK(hipMemsetAsync(dc, 0, F * 4, 0));
             CK(hipEventRecord(a));
-            hipLaunchKernelGGL(k_insert_positions<0>, dim3(S1, F), dim3(IP_THREADS), 0, 0, dm, mstride, n, itab, dt, dr, dc);
+            hipLaunchKernelGGL(k_insert_positions<0>, dim3(S1, F), dim3(IP_THREADS), 0, 0, dm, mstride, n, itab, dt, sd, dr, dc);
             CK(hipEventRecord(c));
             hipLaunchKernelGGL(k_insert_records, dim3(per_tile2 * tiles2), dim3(IL_THREADS), (size_t)tw2 * 4, 0, dr, dc, rtab, dp2, pstride, tw2, sl2, per_tile2, S2);
             CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
@@ -129,6 +129,40 @@ static int big()
             diff += x != y; }
         printf("2160p x 8: k_insert_positions (%3u slices) %6.1f us + k_insert_records (2 tiles x 16 slices) %6.1f us   (%zu words differ from the tiled kernel's)\n",
                S1, t1 * 100.f, t2 * 100.f, diff);
+    }
+    for (uint32_t S1 : {64u, 128u, 256u, 504u, 1008u}) {   // hashing the set positions in the kernel instead of gathering their table entries
+        float t = 0;
+        for (int r = 0; r < 12; ++r) {
+            CK(hipMemsetAsync(dc, 0, F * 4, 0));
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL((k_insert_positions<0, true>), dim3(S1, F), dim3(IP_THREADS), 0, 0, dm, mstride, n, itab, dt, sd, dr, dc);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float x; CK(hipEventElapsedTime(&x, a, b));
+            if (r >= 2) t += x;
+        }
+        hipLaunchKernelGGL(k_insert_records, dim3(per_tile2 * tiles2), dim3(IL_THREADS), (size_t)tw2 * 4, 0, dr, dc, rtab, dp2, pstride, tw2, sl2, per_tile2, S2);
+        std::vector<uint32_t> got2((size_t)F * S2 * pstride);
+        CK(hipMemcpy(got2.data(), dp2, got2.size() * 4, hipMemcpyDeviceToHost));
+        size_t diff = 0;
+        for (uint32_t f = 0; f < F; ++f) for (uint32_t w = 0; w < (tab.f[f].m + 31) / 32; ++w) {
+            uint32_t x = 0, y = 0;
+            for (uint32_t sl = 0; sl < S; ++sl) x |= ref[((size_t)f * S + sl) * pstride + w];
+            for (uint32_t sl = 0; sl < S2; ++sl) y |= got2[((size_t)f * S2 + sl) * pstride + w];
+            diff += x != y; }
+        printf("2160p x 8: k_insert_positions<HASHED> (%4u slices) %6.1f us   (%zu words differ from the tiled kernel's)\n", S1, t * 100.f, diff);
+    }
+    for (int ab : {1, 8}) {                                       // what the walk costs without the table gather / without the queueing
+        float t = 0;
+        for (int r = 0; r < 12; ++r) {
+            CK(hipMemsetAsync(dc, 0, F * 4, 0));
+            CK(hipEventRecord(a));
+            if (ab == 1) hipLaunchKernelGGL(k_insert_positions<1>, dim3(128, F), dim3(IP_THREADS), 0, 0, dm, mstride, n, itab, dt, sd, dr, dc);
+            else hipLaunchKernelGGL(k_insert_positions<8>, dim3(128, F), dim3(IP_THREADS), 0, 0, dm, mstride, n, itab, dt, sd, dr, dc);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float x; CK(hipEventElapsedTime(&x, a, b));
+            if (r >= 2) t += x;
+        }
+        printf("2160p x 8: k_insert_positions (128 slices), ablation %d (1 = no table gather, 8 = mask bytes read only) %6.1f us\n", ab, t * 100.f);
     }
     return 0;
 }
