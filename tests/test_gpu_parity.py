@@ -395,6 +395,52 @@ def test_gop_insert_paths_with_tiles(oracle, force):
     ctx.close()
 
 
+def test_shared_hash_table_across_contexts(oracle):
+    """Contexts of one process share the pixel-index hash table of a (device, frame size, seeds) triple: the first one builds
+    it, the others wait for it, it outlives the context that built it, and other seeds or sizes get their own.  Every
+    context must still reproduce the oracle (a stale or half-built table would corrupt the filters)."""
+    from new_bloom_filter_repo_amd.gop import GopCoder
+    from new_bloom_filter_repo_amd.synthetic import next_frame
+    rng = np.random.default_rng(99)
+    W, H, n = 640, 360, 640 * 360
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8)]
+    for p in (0.0889, 0.05, 0.2):
+        frames.append(next_frame(rng, frames[-1], p))
+    frames = np.stack(frames)
+    small = np.ascontiguousarray(frames[:, :300, :500])
+
+    def check(coder, fr, seeds):
+        hh, ww = fr.shape[1], fr.shape[2]
+        coder.encode()
+        for f, r in enumerate(coder.results()):
+            want = oracle.residual_mask(np.ascontiguousarray(fr[f][..., 0]), np.ascontiguousarray(fr[f + 1][..., 0]), 0.0).reshape(-1)
+            bm, wit, p, _, _ = oracle.compress(want, seeds=seeds)
+            k, l = oracle.optimal_params(hh * ww, p)
+            assert (r["k"], r["l"]) == (k, l), f
+            assert np.array_equal(unpack(r["filter"], l), bm), f
+            assert r["witness_bits"] == len(wit) and np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8)), f
+
+    ctxs = [nat.Context(0) for _ in range(3)]
+    coders = [GopCoder(c, W, H, len(frames)) for c in ctxs]
+    for c in coders:
+        c.load_frames(frames)
+    for c in coders:                                           # builder first, then two that take the same table
+        check(c, frames, P.SEEDS_VIDEO)
+    coders[0].close(); ctxs[0].close()                         # the builder goes away; the table must not
+    check(coders[1], frames, P.SEEDS_VIDEO)
+    other = GopCoder(ctxs[1], W, H, len(frames), seeds=P.SEEDS_BLOOM_COMPRESS)      # same context, other seeds: another table
+    other.load_frames(frames)
+    check(other, frames, P.SEEDS_BLOOM_COMPRESS)
+    check(coders[1], frames, P.SEEDS_VIDEO)                    # ... and back
+    sm = GopCoder(ctxs[2], 500, 300, len(small))               # other frame size on a context that held the 640x360 table
+    sm.load_frames(small)
+    check(sm, small, P.SEEDS_VIDEO)
+    check(coders[2], frames, P.SEEDS_VIDEO)
+    for c in (other, sm, coders[1], coders[2]):
+        c.close()
+    ctxs[1].close(); ctxs[2].close()
+
+
 def test_key_length_boundary_at_ten_million(eng, oracle):
     """Indices around 10^7 (7- and 8-character keys in the same wave) through every kernel family: the LDS kernels'
     fixed-length and shared-prefix hash paths must hand over to the generic one exactly at the boundary."""
