@@ -115,7 +115,8 @@ int rbf_timing_enable(rbf_ctx *ctx, int on);
  * (the insert kernel hashes the set positions itself, as in ABI build 1); bit 7 = filters of several LDS tiles are inserted by the
  * tiled k_insert_tab even inside rbf_encode_gop (default there: k_insert_positions + k_insert_records); bits 8..13 = temporal
  * chunks of the GOP mask kernel (0 = auto); bit 14 = k_insert_positions hashes the set positions itself whatever the frame size
- * (default: only when the 32-byte-per-pixel table would exceed 96 MB); bits 16..31 = LDS tile cap in units of 64 dwords.  0 (default) = pick the fastest
+ * (default: only when the 32-byte-per-pixel table would exceed 96 MB); bit 15 = the query kernel never rewrites the pixel-index
+ * hash table (default: a context that is the table's only holder has it rewritten, to keep it in the Infinity Cache); bits 16..31 = LDS tile cap in units of 64 dwords.  0 (default) = pick the fastest
  * variant that fits: the LDS-resident path needs the batch's largest filter to fit in LDS. */
 int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
 int rbf_timing_reset(rbf_ctx *ctx);

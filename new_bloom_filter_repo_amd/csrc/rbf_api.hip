@@ -55,6 +55,7 @@ struct rbf_ctx {
     uint32_t *ins_counters = nullptr; size_t ins_counters_cap = 0; // ... and the records appended so far, per frame
     int no_two_phase = 0;            // 1 = tiled k_insert_tab even when the filter needs several LDS tiles
     int hash_positions = 0;          // 1 = k_insert_positions hashes the set positions itself whatever the table size
+    int no_table_rewrite = 0;        // 1 = the query kernel never rewrites the hash table, sole holder or not
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
@@ -350,6 +351,7 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->no_two_phase = (on & 128) ? 1 : 0;
     ctx->mask_chunks = (uint32_t)(on >> 8) & 0x3F;           // tuning knob, bits 8..13
     ctx->hash_positions = (on & (1 << 14)) ? 1 : 0;
+    ctx->no_table_rewrite = (on & (1 << 15)) ? 1 : 0;
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
     return RBF_OK;
 }
@@ -827,7 +829,7 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         if (table_for_next && sh && sh->n == n && sh->seeds.h1 == sd.h1 && sh->seeds.h2 == sd.h2 && sh->seeds.act == sd.act && !ctx->no_hash_table) {
             bool sole;
             { std::lock_guard<std::mutex> lk(g_hash_mu); sole = sh->refs == 1; }
-            if (sole) table_out = ctx->hash_tab;
+            if (sole && !ctx->no_table_rewrite) table_out = ctx->hash_tab;
         }
         if (pl.query_p4) {
             if (int r = allow_big_lds((const void *)k_query_p4<0>)) return r;

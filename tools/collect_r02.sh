@@ -1,13 +1,16 @@
 # Round-2 evidence run on the GPU box (gpurun): everything DESIGN.md cites, written under gpurun_out/r02final/
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02final; mkdir -p $O
+if [ -z "${SKIP_MICRO:-}" ]; then       # unchanged since the query kernel was last touched: SKIP_MICRO=1 keeps the committed copies
 ./build/opbench > $O/opbench.txt 2>&1
 ./build/dmabench > $O/dmabench.txt 2>&1
 ./build/bench_query > $O/bench_query.txt 2>&1
+fi
 ./build/bench_insert > $O/bench_insert.txt 2>&1
+BIG=1 ./build/bench_insert > $O/bench_insert_2160p.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --no-cpu-baseline --rebuild-hash-table > $O/bench_rebuild_hash_table.json 2>> $O/bench_default.err
-for st in 1 2 4 6; do python bench.py --no-cpu-baseline --no-verify --streams $st 2>/dev/null | python -c "
+for st in 1 2 3 4 6; do python bench.py --no-cpu-baseline --no-verify --streams $st 2>/dev/null | python -c "
 import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('streams %d: %.0f Mpixel/s, %.4f ms/step, alone %s' % ($st, d['value'], d['ms_per_step'], d['kernels_ms_per_step_alone']))"; done > $O/streams_sweep.txt
 for args in "--width 2560 --height 1440 --frames 30 --steps 60" "--width 3840 --height 2160 --frames 9 --steps 40" "--width 5120 --height 2880 --frames 9 --steps 20" "--width 7680 --height 4320 --frames 5 --steps 10"; do
 python bench.py --no-cpu-baseline $args 2>/dev/null | python -c "
@@ -19,4 +22,9 @@ bash tools/profile.sh r02final > $O/profile.log 2>&1
 cp gpurun_out/prof_r02final/summary.txt $O/rocprofv3_summary.txt
 cp gpurun_out/prof_r02final/stats/*kernel_stats.csv $O/kernel_stats_streams1.csv 2>/dev/null
 cp gpurun_out/prof_r02final/stats_default/*kernel_stats.csv $O/kernel_stats_default_4pipelines.csv 2>/dev/null
+bash tools/profile.sh r02final_2160p --width 3840 --height 2160 --frames 9 > $O/profile_2160p.log 2>&1
+cp gpurun_out/prof_r02final_2160p/summary.txt $O/rocprofv3_summary_2160p.txt
+cp gpurun_out/prof_r02final_2160p/stats/*kernel_stats.csv $O/kernel_stats_2160p_streams1.csv 2>/dev/null
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ktrace && rocprofv3 --kernel-trace --output-format csv -d /tmp/ktrace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-verify --no-kernel-timing --steps 200 --exact-steps > /tmp/ktrace.log 2>&1 )
+python tools/overlap_report.py $(find /tmp/ktrace -name "*kernel_trace.csv" | head -1) > $O/overlap_4pipelines.txt 2>&1
 ls -la $O

@@ -20,6 +20,10 @@ rocprofv3 --output-format csv --pmc $PMC1 --kernel-trace -d "$OUT/pmc1" -o pmc -
 rocprofv3 --output-format csv --pmc $PMC2 --kernel-trace -d "$OUT/pmc2" -o pmc -- $BENCH > "$OUT/pmc2.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc3" -o pmc -- $BENCH > "$OUT/pmc3.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc4" -o pmc -- $BENCH > "$OUT/pmc4.log" 2>&1
+# the query kernel WITHOUT its rewrite of the pixel-index hash table (what it does whenever several contexts share the table, i.e. in
+# the default four-pipeline run; one pipeline alone rewrites it to keep it cached): force bit 15
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc5" -o pmc -- $BENCH --force-bits 32768 > "$OUT/pmc5.log" 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc6" -o pmc -- $BENCH --force-bits 32768 > "$OUT/pmc6.log" 2>&1
 find "$OUT" -name "*.csv" | head -30
 python $ROOT/tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
