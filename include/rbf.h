@@ -105,19 +105,23 @@ int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes); 
 #define RBF_K_HASHTAB 12      /* k_hash_table: the per-batch table of the pixel indices' three hashes */
 #define RBF_K_COUNT   13
 int rbf_timing_enable(rbf_ctx *ctx, int on);
-/* Testing knob (bit mask): bit 0 = always use the generic (global-memory filter) kernels;
- * bit 1 = LDS fast path without double-buffering the filter; bit 2 = per-pixel threshold compare in the
- * GOP mask kernel even for threshold 0; bit 3 = Barrett reductions only (never the FP64 h mod m of the query
- * kernel, which is taken when every filter of a batch has 2^15 <= m < 2^23); bit 4 = run k_hash_table (the pixel-index
- * hash table the insert kernel gathers from, 32 bytes per pixel) for every batch instead of taking the copy the previous
- * batch's query kernel wrote while hashing the same indices for its own probes; bit 6 = the 4-pixels-per-lane FP64 query
- * kernel (k_query_p4: 64 VGPRs, two single-buffered workgroups per CU) instead of k_query_f64 (8 pixels per lane, double-buffered); bit 5 = never use that table
- * (the insert kernel hashes the set positions itself, as in ABI build 1); bit 7 = filters of several LDS tiles are inserted by the
- * tiled k_insert_tab even inside rbf_encode_gop (default there: k_insert_positions + k_insert_records); bits 8..13 = temporal
- * chunks of the GOP mask kernel (0 = auto); bit 14 = k_insert_positions hashes the set positions itself whatever the frame size
- * (default: only when the 32-byte-per-pixel table would exceed 96 MB); bit 15 = the query kernel never rewrites the pixel-index
- * hash table (default: a context that is the table's only holder has it rewritten, to keep it in the Infinity Cache); bits 16..31 = LDS tile cap in units of 64 dwords.  0 (default) = pick the fastest
- * variant that fits: the LDS-resident path needs the batch's largest filter to fit in LDS. */
+/* Testing / tuning knob (bit mask).  0 (default) = pick the fastest variant that fits.
+ *   bit 0       always the generic (global-memory filter) kernels
+ *   bit 1       LDS fast path without double-buffering the filter
+ *   bit 2       per-pixel threshold compare in the GOP mask kernel even for threshold 0
+ *   bit 3       Barrett reductions only (never the FP64 h mod m, which is taken when every filter of a batch has 2^15 <= m < 2^23)
+ *   bit 4       run k_hash_table (the pixel-index hash table the insert kernel gathers from, 32 bytes per pixel, shared by the
+ *               contexts of a process) for every batch instead of once per (device, frame size, seeds)
+ *   bit 5       never use that table: the insert kernel hashes the set positions itself, as in ABI build 1
+ *   bit 6       the 4-pixels-per-lane FP64 query kernel (k_query_p4) instead of k_query_f64
+ *   bit 7       filters of several LDS tiles are inserted by the tiled k_insert_tab even inside rbf_encode_gop (default there:
+ *               k_insert_positions + k_insert_records)
+ *   bits 8..13  temporal chunks of the GOP mask kernel (0 = auto)
+ *   bit 14      k_insert_positions hashes the set positions itself whatever the frame size (default: only when the table would
+ *               exceed 96 MB)
+ *   bit 15      the query kernel never rewrites the hash table (default: a context that is the table's only holder has it
+ *               rewritten in every batch, which keeps it in the Infinity Cache)
+ *   bits 16..31 LDS tile cap in units of 64 dwords (0 = all of LDS) */
 int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
 int rbf_timing_reset(rbf_ctx *ctx);
 int rbf_timing_read(rbf_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
