@@ -4,7 +4,8 @@
   kernels: 29-frame frames-inner query, (29 frames x 8 slices) LDS insert), FOUR contexts in flight on four
   HIP streams sharing the resident frames -- every pipeline's 29 (mask, k, l, filter, witness, counts) against
   oracle.residual_mask / orc_compress, then decoded back on the GPU.
-* BASELINE config 4: 3840x2160 x 9 frames (tiled kernels) the same way.
+* BASELINE config 4: 3840x2160 x 9 frames (two-kernel insert over LDS tiles, tiled query) the same way, plus the tiled
+  insert it replaced and a 2560x1440 GOP (one 136 KB tile per frame).
 * BASELINE config 5, single-GPU half: 1920x1080 uint16 x 30 frames, GOP record vs the oracle and the whole
   ImprovedVideoCompressor round trip under verify_lossless / verify_bit_exact
   (verify_true_lossless.py:241-249,338-492 semantics).
@@ -104,18 +105,24 @@ def test_config2_1080p_gop_four_pipelines_vs_oracle(oracle):
         c.close()
 
 
-def test_config4_2160p_gop_vs_oracle(oracle):
-    W, H, F = 3840, 2160, 9
+@pytest.mark.parametrize("W,H,F,force", [(3840, 2160, 9, 0), (3840, 2160, 5, 128), (2560, 1440, 6, 0), (2560, 1440, 4, 1 << 15)],
+                         ids=["2160p_records_hashed_2_tiles", "2160p_tiled_insert_tab", "1440p_records_hashed_1_tile", "1440p_again_no_table_rewrite"])
+def test_config4_large_frames_gop_vs_oracle(oracle, W, H, F, force):
+    """BASELINE config 4 (3840x2160 x 9) on its default kernels -- k_insert_positions (positions hashed: the pixel-index
+    table would be 265 MB) + k_insert_records over 2 LDS tiles, k_query_f64t with 2 stages per frame -- and the tiled
+    k_insert_tab it replaced; 2560x1440 takes the same kernels with ONE 136 KB tile per frame."""
     n = W * H
-    frames = np.stack(make_gop(4000, W, H, F))
+    frames = np.stack(make_gop(4000 + W, W, H, F))
     want = oracle_gop(oracle, frames)
     with nat.Context(0) as ctx:
+        ctx.force_generic(force)
         coder = GopCoder(ctx, W, H, F, channels=3, sample_bytes=1)
         coder.load_frames(frames)
-        coder.encode()
-        res = coder.results()
-        check_records(res, want, n, "2160p")
-        decode_back(ctx, res, n, "2160p")
+        for _ in range(2):
+            coder.encode()
+            res = coder.results()
+            check_records(res, want, n, "%dx%d" % (W, H))
+        decode_back(ctx, res, n, "%dx%d" % (W, H))
         coder.close()
 
 
