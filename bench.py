@@ -295,7 +295,7 @@ def main():
         if q_alone:
             achieved = alg_bytes / (q_alone * 1e-3) / 1e9
             default_shape = (W, H, F, args.bits) == (1920, 1080, 30, 8)
-            qname = "k_query_f64" if default_shape else "query kernel of this geometry (DESIGN.md 4)"
+            qname = "k_query_r64" if default_shape else "query kernel of this geometry (DESIGN.md 4)"
             rf = {"bound": "hbm", "kernel": qname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                   "avg_launch_ms": q_alone, "launches_averaged": ALONE_LAUNCHES,

@@ -116,7 +116,9 @@ int rbf_timing_enable(rbf_ctx *ctx, int on);
  *   bit 6       the 4-pixels-per-lane FP64 query kernel (k_query_p4) instead of k_query_f64
  *   bit 7       filters of several LDS tiles are inserted by the tiled k_insert_tab even inside rbf_encode_gop (default there:
  *               k_insert_positions + k_insert_records)
- *   bits 8..13  temporal chunks of the GOP mask kernel (0 = auto)
+ *   bits 8..12  temporal chunks of the GOP mask kernel (0 = auto)
+ *   bit 13      k_query_f64 (probe image staged by LDS-DMA, 64-bit activation hashes) instead of k_query_r64 (staged through
+ *               registers, activation ranks), the default FP64 query kernel
  *   bit 14      k_insert_positions hashes the set positions itself whatever the frame size (default: only when the table would
  *               exceed 96 MB)
  *   bit 15      the query kernel never rewrites the hash table (default: a context that is the table's only holder has it

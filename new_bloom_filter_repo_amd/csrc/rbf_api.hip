@@ -2,6 +2,7 @@
 // scratch management, launches on the context's single HIP stream, optional per-kernel timing.
 #include "../../include/rbf.h"
 #include "rbf_kernels_i64.h"
+#include "rbf_kernels_r64.h"
 #include "rbf_kernels_noise.h"
 #include "rbf_kernels_pack.h"
 
@@ -9,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -56,6 +58,7 @@ struct rbf_ctx {
     int no_two_phase = 0;            // 1 = tiled k_insert_tab even when the filter needs several LDS tiles
     int hash_positions = 0;          // 1 = k_insert_positions hashes the set positions itself whatever the table size
     int no_table_rewrite = 0;        // 1 = the query kernel never rewrites the hash table, sole holder or not
+    int query_dma = 0;               // 1 = k_query_f64 (LDS-DMA staging, 64-bit activation hashes) instead of k_query_r64
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
@@ -349,7 +352,8 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->query_p4 = (on & 64) ? 1 : 0;
     ctx->no_hash_table = (on & 32) ? 1 : 0;
     ctx->no_two_phase = (on & 128) ? 1 : 0;
-    ctx->mask_chunks = (uint32_t)(on >> 8) & 0x3F;           // tuning knob, bits 8..13
+    ctx->mask_chunks = (uint32_t)(on >> 8) & 0x1F;           // tuning knob, bits 8..12
+    ctx->query_dma = (on & (1 << 13)) ? 1 : 0;
     ctx->hash_positions = (on & (1 << 14)) ? 1 : 0;
     ctx->no_table_rewrite = (on & (1 << 15)) ? 1 : 0;
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
@@ -835,6 +839,22 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
             if (int r = allow_big_lds((const void *)k_query_p4<0>)) return r;
             hipLaunchKernelGGL(k_query_p4<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                                n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+                               ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
+        } else if (!ctx->query_dma) {
+            // k_query_r64's table: T = the coded frames' thresholds SORTED (entry j = j-th smallest, ~0 past the last),
+            // floor_k |= c << 8 with c = number of coded thresholds below the frame's own (rbf_kernels_r64.h)
+            FrameTable rtab = qtab;
+            uint64_t sorted[MAX_BATCH];
+            uint32_t coded = 0;
+            for (uint32_t f = 0; f < nframes; ++f) if (tab.f[f].m) sorted[coded++] = tab.f[f].T;
+            std::sort(sorted, sorted + coded);
+            for (uint32_t f = 0; f < nframes; ++f) {
+                rtab.f[f].T = f < coded ? sorted[f] : ~0ull;
+                if (tab.f[f].m) rtab.f[f].floor_k = tab.f[f].floor_k | ((uint32_t)(std::lower_bound(sorted, sorted + coded, tab.f[f].T) - sorted) << 8);
+            }
+            if (int r = allow_big_lds((const void *)k_query_r64<0>)) return r;
+            hipLaunchKernelGGL(k_query_r64<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
+                               n, nframes, rtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                                ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
         } else
         hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,

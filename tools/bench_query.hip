@@ -4,8 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include <cstring>
-#include "../new_bloom_filter_repo_amd/csrc/rbf_kernels_q64.h"
+#include "../new_bloom_filter_repo_amd/csrc/rbf_kernels_r64.h"
 using namespace rbf;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -20,11 +21,24 @@ static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F
         filters = g_image; lds += 32;
         for (uint32_t f = 0; f < F; ++f) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
     }
+    if (MODK == 2) {                                             // k_query_r64: sorted thresholds in T, c << 8 in floor_k (rbf_kernels_r64.h)
+        filters = g_image; lds += 32;
+        std::vector<uint64_t> ts;
+        for (uint32_t f = 0; f < F; ++f) ts.push_back(tab.f[f].T);
+        std::sort(ts.begin(), ts.end());
+        for (uint32_t f = 0; f < F; ++f) {
+            const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8);
+            uint32_t c = 0; for (uint64_t t : ts) c += t < tab.f[f].T;
+            qtab.f[f].floor_k = tab.f[f].floor_k | (c << 8);
+            qtab.f[f].T = ts[f];
+        }
+    }
     auto launch = [&](dim3 g, dim3 b, size_t sh, hipStream_t st, uint64_t n_, uint32_t F_, const FrameTable &t_, Seeds s_, const uint32_t *f_, uint64_t fs_, uint32_t fw_, uint32_t *sc_, uint64_t ns_, uint64_t *pw_) {
-        if constexpr (MODK == 1) k_query_f64<AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out);
+        if constexpr (MODK == 2) k_query_r64<AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out);
+        else if constexpr (MODK == 1) k_query_f64<AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out);
         else k_query_lds<DB, true, AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_);
     };
-    const void *kern = MODK == 1 ? (const void *)k_query_f64<AB> : (const void *)k_query_lds<DB, true, AB>;
+    const void *kern = MODK == 2 ? (const void *)k_query_r64<AB> : MODK == 1 ? (const void *)k_query_f64<AB> : (const void *)k_query_lds<DB, true, AB>;
     uint64_t *pwords = (uint64_t *)seg_bits;
     CK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const uint32_t bx = (uint32_t)((nseg + THREADS / 64 - 1) / (THREADS / 64));
@@ -96,6 +110,26 @@ int main()
         size_t dc = 0; for (size_t i = 0; i < ca.size(); ++i) dc += ca[i] != cb[i];
         uint64_t passes = 0; for (auto c : ca) passes += c;
         printf("fp64-mod kernel vs Barrett kernel: %zu differing pass bytes, %zu differing segment counts (%llu passes)\n", diff, dc, (unsigned long long)passes);
+    }
+    if (getenv("R64")) {   // k_query_r64 (register staging + activation ranks) against k_query_f64: same pass bytes and counts; thresholds varied per frame
+        FrameTable vt = tab;
+        for (uint32_t f = 0; f < F; ++f) vt.f[f].T = 0x1000000000000000ull * ((f * 7) % 13 + 1) + f % 3;      // distinct and repeated values
+        const size_t pwb = (size_t)F * nseg * QL_P * 8, scb = (size_t)F * nseg * 4;
+        std::vector<uint8_t> a(pwb), b(pwb); std::vector<uint32_t> ca(F * nseg), cb(F * nseg);
+        const float t1 = run<0, true, QL_THREADS, 1>(dm, mstride, n, F, vt, sd, df, fstride, fwmax, sb, sc, nseg, lds);
+        CK(hipMemcpy(a.data(), sb, pwb, hipMemcpyDeviceToHost)); CK(hipMemcpy(ca.data(), sc, scb, hipMemcpyDeviceToHost));
+        CK(hipMemset(sb, 0xEE, pwb)); CK(hipMemset(sc, 0xEE, scb));
+        const float t2 = run<0, true, QL_THREADS, 2>(dm, mstride, n, F, vt, sd, df, fstride, fwmax, sb, sc, nseg, lds);
+        CK(hipMemcpy(b.data(), sb, pwb, hipMemcpyDeviceToHost)); CK(hipMemcpy(cb.data(), sc, scb, hipMemcpyDeviceToHost));
+        size_t diff = 0; for (size_t i = 0; i < pwb; ++i) diff += a[i] != b[i];
+        size_t dc = 0; for (size_t i = 0; i < ca.size(); ++i) dc += ca[i] != cb[i];
+        printf("k_query_f64 %.1f us, k_query_r64 %.1f us: %zu differing pass bytes, %zu differing segment counts\n", t1, t2, diff, dc);
+        printf("%-60s %8.1f us\n", "[r64] full kernel (bench thresholds)", run<0, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+        printf("%-60s %8.1f us\n", "[r64] no staging (barrier kept)", run<8, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+        printf("%-60s %8.1f us\n", "[r64] no staging, no barrier (pure passes)", run<8 | 32, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+        printf("%-60s %8.1f us\n", "[r64] no hashing", run<16, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+        printf("%-60s %8.1f us\n", "[f64] full kernel", run<0, true, QL_THREADS, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+        return 0;
     }
 #define RUNP(AB, TH, PARTS, what) printf("%-60s %8.1f us\n", "[fp64 mod] " what, run<AB, true, TH, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
     {   // k_query_p4: 4 pixels per lane, two workgroups per CU; same pass bytes (its segments are 256 pixels, so the counts are compared as sums)
