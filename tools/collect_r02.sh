@@ -7,6 +7,7 @@ if [ -z "${SKIP_MICRO:-}" ]; then       # unchanged since the query kernel was l
 ./build/bench_query > $O/bench_query.txt 2>&1
 fi
 ./build/bench_insert > $O/bench_insert.txt 2>&1
+R64=1 ./build/bench_query > $O/bench_query_r64.txt 2>&1
 BIG=1 ./build/bench_insert > $O/bench_insert_2160p.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --no-cpu-baseline --rebuild-hash-table > $O/bench_rebuild_hash_table.json 2>> $O/bench_default.err

@@ -100,8 +100,8 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, "k.hip")
         with open(src, "w") as f:
-            f.write('#include "rbf_kernels_i64.h"\nusing namespace rbf;\n'
-                    'template __global__ void rbf::k_query_f64<0>(uint64_t, uint32_t, const FrameTable, Seeds, const uint32_t *, uint64_t, uint32_t, uint32_t *, uint64_t, uint64_t *, uint4 *);\n'
+            f.write('#include "rbf_kernels_i64.h"\n#include "rbf_kernels_r64.h"\nusing namespace rbf;\n'
+                    'template __global__ void rbf::k_query_r64<0>(uint64_t, uint32_t, const FrameTable, Seeds, const uint32_t *, uint64_t, uint32_t, uint32_t *, uint64_t, uint64_t *, uint4 *);\n'
                     'template __global__ void rbf::k_insert_tab<0>(const uint8_t *, uint64_t, uint64_t, const FrameTable, const uint4 *, uint32_t *, uint64_t, uint32_t, const SliceTable, uint32_t, uint32_t);\n')
         out = os.path.join(tmp, "k.s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
@@ -109,20 +109,20 @@ def main():
     model = {"source": "tools/make_issue_model.py: ISA histogram of the floor(k*) = 2 hot block x per-opcode issue cost from profiles/r02_opbench.txt (ch=8, 4 waves per SIMD)",
              "clock_ghz": CLOCK_GHZ, "simds": SIMDS}
     # ---- query: the 8-pixel straight-line block with 24 LDS reads
-    blk = hot_block(asm, "k_query_f64", want_ds_reads=24)
+    blk = hot_block(asm, "k_query_r64", want_ds_reads=24)
     rows, other = histogram(blk, cost)
     px = 8.0
     pixel_frames = 29 * 1920 * 1080
     total_cyc = sum(c * cyc for c, cyc in rows.values())
     nvalu = sum(c for c, _ in rows.values())
     bound_ms = pixel_frames / 64.0 * (total_cyc / px) / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
-    model["k_query_lds"] = {"kernel": "k_query_f64<0>", "block": "frame pass, floor(k*) = 2, 8 pixels per lane",
+    model["k_query_lds"] = {"kernel": "k_query_r64<0>", "block": "frame pass, floor(k*) = 2, 8 pixels per lane",
                             "valu_per_pixel_frame": round(nvalu / px, 2), "valu_cycles_per_pixel_frame": round(total_cyc / px, 2),
                             "other_per_pixel_frame": {k: round(v / px, 2) for k, v in other.items()},
                             "table": [{"class": k, "per_pixel_frame": round(c / px, 3), "cycles_each": cyc} for k, (c, cyc) in rows.items()],
                             "issue_bound_ms": round(bound_ms, 4),
-                            "note": "frame passes only (29 x 2 073 600 pixel-frames); hashing, staging and barriers are on top"}
-    print("k_query_f64 frame pass: %.1f VALU and %.1f VALU cycles per (pixel, frame); launch issue bound %.1f us" % (nvalu / px, total_cyc / px, bound_ms * 1e3))
+                            "note": "frame passes only (29 x 2 073 600 pixel-frames), including the 10 staging instructions a wave issues per frame; hashing, ranks and barriers are on top"}
+    print("k_query_r64 frame pass: %.1f VALU and %.1f VALU cycles per (pixel, frame); launch issue bound %.1f us" % (nvalu / px, total_cyc / px, bound_ms * 1e3))
     for k, (c, cyc) in sorted(rows.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         print("    %-40s %6.2f per pixel-frame x %5.2f cycles" % (k, c / px, cyc))
     print("    other per pixel-frame:", {k: round(v / px, 2) for k, v in other.items()})

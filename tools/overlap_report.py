@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("k_query_f64", "k_insert_tab", "k_insert_positions", "k_insert_records", "k_residual_mask_gop", "k_compact_witness",
+    for key in ("k_query_r64", "k_query_f64t", "k_query_f64", "k_insert_tab", "k_insert_positions", "k_insert_records", "k_residual_mask_gop", "k_compact_witness",
                 "k_filter_reduce", "k_finish_ones", "k_hash_table", "k_pack"):
         if key in name:
             return key
@@ -24,7 +24,7 @@ def main(path):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    q = [r for r in rows if r[2] == "k_query_f64" or r[2] == "k_query_f64t"] or rows       # the bench's own time span
+    q = [r for r in rows if r[2].startswith("k_query_")] or rows       # the bench's own time span
     t0, t1 = q[0][0], max(r[1] for r in q)
     lo, hi = t0 + (t1 - t0) // 10, t1 - (t1 - t0) // 10
     rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
