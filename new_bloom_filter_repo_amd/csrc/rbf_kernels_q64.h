@@ -17,7 +17,8 @@
 //    and the round-2 git history have them): issuing the DMA share of wave group g in front of pixel part g of the frame
 //    pass (2 / 4 parts: 100 - 108 us vs 101), storing the verdicts one barrier late (+7 us), counting passes with popc +
 //    a wave reduction instead of ballots (+4 us), staging through registers -- one plain 16-byte load per pipeline slot,
-//    the ds_write_b128 a slot later -- instead of LDS-DMA (125 us: it needs four more VGPRs than there are), and a
+//    the ds_write_b128 a slot later -- instead of LDS-DMA (125 us: it needs four more VGPRs than there are; k_query_r64,
+//    rbf_kernels_r64.h, frees them with activation ranks and IS the default FP64 query kernel now: 92 us), and a
 //    4-pixels-per-lane re-cut at 8 waves per SIMD (k_query_p4 below, 112 us).
 //  * The next frame's geometry (scalar loads; -1/m comes from the host in FrameDev::M) is fetched one frame ahead.
 #pragma once
