@@ -443,6 +443,59 @@ def test_shared_hash_table_across_contexts(oracle):
     ctxs[1].close(); ctxs[2].close()
 
 
+def test_shared_hash_table_from_concurrent_threads(oracle):
+    """Four host threads, each with its own context and stream, start coding the same geometry at the same moment (ctypes
+    releases the GIL inside the library): exactly one of them builds the shared pixel-index hash table, the others must
+    wait for it on the device -- every thread's filters and witnesses are checked against the oracle, several rounds, with
+    the contexts torn down in between so that the table is also freed and rebuilt."""
+    import threading
+    from new_bloom_filter_repo_amd.gop import GopCoder
+    from new_bloom_filter_repo_amd.synthetic import next_frame
+    rng = np.random.default_rng(321)
+    W, H, n = 704, 396, 704 * 396
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8)]
+    for p in (0.0889, 0.12, 0.05):
+        frames.append(next_frame(rng, frames[-1], p))
+    frames = np.stack(frames)
+    want = []
+    for f in range(len(frames) - 1):
+        mask = oracle.residual_mask(np.ascontiguousarray(frames[f][..., 0]), np.ascontiguousarray(frames[f + 1][..., 0]), 0.0).reshape(-1)
+        bm, wit, p, _, _ = oracle.compress(mask)
+        want.append((oracle.optimal_params(n, p), bm, np.array(wit, dtype=np.uint8)))
+    errors = []
+
+    def worker(barrier, tid):
+        try:
+            ctx = nat.Context(0)
+            coder = GopCoder(ctx, W, H, len(frames))
+            coder.load_frames(frames)
+            barrier.wait()
+            for _ in range(3):
+                coder.encode()
+                for f, r in enumerate(coder.results()):
+                    (k, l), bm, wit = want[f]
+                    assert (r["k"], r["l"]) == (k, l), (tid, f)
+                    assert np.array_equal(unpack(r["filter"], l), bm), (tid, f)
+                    assert r["witness_bits"] == len(wit) and np.array_equal(unpack(r["witness"], len(wit)), wit), (tid, f)
+            coder.close()
+            ctx.close()
+        except BaseException as e:                             # noqa: BLE001 -- reported by the main thread
+            errors.append((tid, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    for _ in range(3):                                          # table built, shared, freed; three times
+        barrier = threading.Barrier(4)
+        threads = [threading.Thread(target=worker, args=(barrier, t)) for t in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+
+
 def test_key_length_boundary_at_ten_million(eng, oracle):
     """Indices around 10^7 (7- and 8-character keys in the same wave) through every kernel family: the LDS kernels'
     fixed-length and shared-prefix hash paths must hand over to the generic one exactly at the boundary."""
