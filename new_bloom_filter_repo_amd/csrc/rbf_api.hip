@@ -604,6 +604,22 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     return p;
 }
 
+// The FrameTable k_query_r64 / k_query_r64t read (rbf_kernels_r64.h): M as in `qtab` (bits of -1/m); T = the coded frames'
+// thresholds SORTED (entry j = j-th smallest, ~0 past the last one); floor_k |= c << 8 with c = coded thresholds below the frame's own.
+static FrameTable rank_table(const FrameTable &tab, const FrameTable &qtab, uint32_t nframes)
+{
+    FrameTable rtab = qtab;
+    uint64_t sorted[MAX_BATCH];
+    uint32_t coded = 0;
+    for (uint32_t f = 0; f < nframes; ++f) if (tab.f[f].m) sorted[coded++] = tab.f[f].T;
+    std::sort(sorted, sorted + coded);
+    for (uint32_t f = 0; f < nframes; ++f) {
+        rtab.f[f].T = f < coded ? sorted[f] : ~0ull;
+        if (tab.f[f].m) rtab.f[f].floor_k = tab.f[f].floor_k | ((uint32_t)(std::lower_bound(sorted, sorted + coded, tab.f[f].T) - sorted) << 8);
+    }
+    return rtab;
+}
+
 static int allow_big_lds(const void *fn)
 {
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
@@ -808,13 +824,22 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         FrameTable qtab = tab;
         for (uint32_t f = 0; f < nframes; ++f)
             if (qtab.f[f].m) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
-        auto kern = k_query_f64t<0>;
-        if (int r = allow_big_lds((const void *)kern)) return r;
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
-        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                           n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
-                           ctx->seg_cnt, pl.nseg, ctx->pass_words);
+        if (!ctx->query_dma) {
+            const FrameTable rtab = rank_table(tab, qtab, nframes);
+            if (int r = allow_big_lds((const void *)k_query_r64t<0>)) return r;
+            const size_t lds_bytes = pl.query_lds_bytes > 2 * MAX_BATCH * 8 + 16 ? pl.query_lds_bytes : (size_t)2 * MAX_BATCH * 8 + 16;   // room for the thresholds' copy
+            hipLaunchKernelGGL(k_query_r64t<0>, dim3((uint32_t)bx), dim3(QL_THREADS), lds_bytes, ctx->stream,
+                               n, nframes, rtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
+                               ctx->seg_cnt, pl.nseg, ctx->pass_words);
+        } else {
+            auto kern = k_query_f64t<0>;
+            if (int r = allow_big_lds((const void *)kern)) return r;
+            hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
+                               n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
+                               ctx->seg_cnt, pl.nseg, ctx->pass_words);
+        }
     } else if (pl.query_kind == 1 && pl.f64_mod) {
         // k_query_f64 reads -1/m (IEEE double, computed here on the host) from the table's M field instead of the Barrett constant
         FrameTable qtab = tab;
@@ -841,17 +866,7 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
                                n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                                ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
         } else if (!ctx->query_dma) {
-            // k_query_r64's table: T = the coded frames' thresholds SORTED (entry j = j-th smallest, ~0 past the last),
-            // floor_k |= c << 8 with c = number of coded thresholds below the frame's own (rbf_kernels_r64.h)
-            FrameTable rtab = qtab;
-            uint64_t sorted[MAX_BATCH];
-            uint32_t coded = 0;
-            for (uint32_t f = 0; f < nframes; ++f) if (tab.f[f].m) sorted[coded++] = tab.f[f].T;
-            std::sort(sorted, sorted + coded);
-            for (uint32_t f = 0; f < nframes; ++f) {
-                rtab.f[f].T = f < coded ? sorted[f] : ~0ull;
-                if (tab.f[f].m) rtab.f[f].floor_k = tab.f[f].floor_k | ((uint32_t)(std::lower_bound(sorted, sorted + coded, tab.f[f].T) - sorted) << 8);
-            }
+            const FrameTable rtab = rank_table(tab, qtab, nframes);
             if (int r = allow_big_lds((const void *)k_query_r64<0>)) return r;
             hipLaunchKernelGGL(k_query_r64<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                                n, nframes, rtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,

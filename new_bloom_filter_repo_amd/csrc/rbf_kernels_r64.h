@@ -19,6 +19,7 @@
 // LDS layout with the SAFE dwords -- is k_query_f64's.
 #pragma once
 #include "rbf_kernels_q64.h"
+#include <type_traits>
 
 namespace rbf {
 
@@ -321,6 +322,192 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_r64(
         if (!more) break;
         cf = nf;
         cur ^= 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_query_r64t -- k_query_f64t (rbf_kernels_q64.h: filters that do not fit LDS twice, walked in tiles of one maximal LDS
+// buffer) with the same two changes: activation ranks, and the next frame's first tile staged through registers.
+// Needs at least 2 KiB + 16 bytes of dynamic LDS (the thresholds' copy), whatever the tile size.
+// ------------------------------------------------------------------------------------------------------------------
+template <int AB = 0>
+__global__ __launch_bounds__(QL_THREADS) void k_query_r64t(
+    uint64_t n, uint32_t nframes, const FrameTable tab /* as for k_query_r64: M = bits of -1/m, T = sorted thresholds, floor_k = floor(k*) | c << 8 */, Seeds seeds,
+    const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t tile_words /* multiple of 4; tile_words + 4 dwords of LDS */,
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // ONE buffer of tile_words dwords + the SAFE dword (kept 0): measured, the LDS-DMA of a tile does not hide under the
+    // probes of another one (it adds, see k_query_f64), while every (frame, tile) stage costs ~3 500 cycles of barriers and
+    // DMA issue on top of its probes -- so the tiles are as large as LDS allows and there are as few stages as possible
+    // (2160p: 2 per frame; double-buffered 76 KB tiles, 4 per frame, were 2.4x slower).
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    const bool live = seg < nseg;
+
+    // the hashes stay 64-bit integers here (6 registers per pixel instead of 8: this kernel also keeps pos0, step and fail
+    // per pixel) and are converted to the FP64 reduction's (double, low dword) form once per frame, not per tile
+    uint64_t h1[QL_P], h2[QL_P];
+    uint32_t rank_lo = 0, rank_hi = 0;                            // activation ranks, one byte per pixel (rbf_kernels_r64.h)
+    uint32_t validmask = 0;
+    const uint64_t i0 = seg * QL_SEG_PIXELS + (uint64_t)lane * QL_P;
+    {
+        uint64_t ha[QL_P];
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
+            if (live && i0 + it < n) validmask |= 1u << it;
+        }
+        if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) {
+                const bool act = (validmask >> it) & 1u;
+                const Hash3 h = hash3_index((uint32_t)(i0 + it), act, seeds);
+                h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
+            }
+        }
+        // ranks by binary search over an LDS copy of the sorted thresholds (the tile buffer is still free)
+        uint64_t *tl = reinterpret_cast<uint64_t *>(lds);
+        if (threadIdx.x < 2u * MAX_BATCH) tl[threadIdx.x] = threadIdx.x < nframes ? tab.f[threadIdx.x < nframes ? threadIdx.x : 0u].T : ~0ull;
+        __syncthreads();
+        uint32_t top = 1;
+        while (2u * top <= nframes) top *= 2u;
+        top = __builtin_amdgcn_readfirstlane(top);
+        uint32_t r[QL_P];
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) r[it] = 0;
+        for (uint32_t step_ = top; step_; step_ >>= 1) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) {
+                const uint64_t t = tl[r[it] + step_ - 1u];
+                r[it] |= t <= ha[it] ? step_ : 0u;
+            }
+        }
+        rank_lo = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        rank_hi = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        __syncthreads();                          // everyone has read the thresholds before the first tile lands on them
+    }
+    if (threadIdx.x < 4u) lds[tile_words + threadIdx.x] = 0u;    // SAFE (after the search: with tiny tiles the thresholds lay over it)
+    // invalid positions (past the end of the frame, or a dead wave) must fail: their verdict bits are forced afterwards
+    uint32_t invalid_byte = 0;                                    // bit 7-j: pixel j is not a position of the frame
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) invalid_byte |= ((validmask >> it) & 1u) ? 0u : (0x80u >> it);
+    uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
+
+    for (uint32_t g = 0; g < nframes; ++g) {
+        if (tab.f[g].m == 0) {
+            if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
+            if (live) pass_bytes[((uint64_t)g * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = 0;
+        }
+    }
+    auto next_active = [&](uint32_t k) -> uint32_t { while (k < nframes && tab.f[k].m == 0) ++k; return k; };
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    auto stage_dma = [&](uint32_t f, uint32_t fwords, uint32_t t) {                     // tile t of frame f -> LDS
+        const uint32_t w0 = t * tile_words;
+        const uint32_t words = fwords - w0 < tile_words ? fwords - w0 : tile_words;
+        if (!(AB & 8)) dma_row(lds_base, image + (uint64_t)f * image_stride_words32 + w0, words, wave, lane, nwaves);
+    };
+    uint32_t f = __builtin_amdgcn_readfirstlane(next_active(0));
+    if (f >= nframes) return;
+    uint32_t fwords = __builtin_amdgcn_readfirstlane(filter_words(tab.f[f].m));
+    uint32_t ntiles = (fwords + tile_words - 1) / tile_words;
+    const uint32_t fbase = vgpr_copy(__builtin_amdgcn_readfirstlane(lds_addr_of(lds)));
+
+    // Software-pipelined over the frames as k_query_f64t, but the NEXT frame's first tile is staged THROUGH REGISTERS inside the
+    // reductions of that frame (three 16-byte pieces in flight per lane, issued before pixel 0 / 2 / 4 / 6 and written two pixels
+    // later): a global_load_lds holds its wave ~200 cycles and a wave has up to ten of them per tile -- time it could not spend on
+    // the reductions the DMA was supposed to hide under.  The other tiles of a frame have nothing to overlap with and stay DMA.
+    uint32_t pos0[QL_P], step[QL_P], fail[QL_P];
+    uint32_t notact = 0, m_v = 0, fk = 0;
+    struct {
+        const uint8_t *row; uint32_t lds_base, last, off0; uint4 a, b, c;
+        __device__ __forceinline__ uint32_t off(int i) const { return min(off0 + (uint32_t)i * (QL_WAVES * 1024u), last); }   // clamped: see RowStager
+        __device__ __forceinline__ uint4 load(int i) const { return *reinterpret_cast<const uint4 *>(row + off(i)); }
+        __device__ __forceinline__ void store(int i, const uint4 &v) const
+        { *reinterpret_cast<__attribute__((address_space(3))) r64_u32x4 *>((uintptr_t)(lds_base + off(i))) = r64_u32x4{v.x, v.y, v.z, v.w}; }
+        __device__ __forceinline__ void at(int it)          // up to ten pieces per wave (160 KB of LDS / 16 waves)
+        {
+            if (it == 0) { a = load(0); b = load(1); c = load(2); }
+            else if (it == 2) { store(0, a); store(1, b); store(2, c); a = load(3); b = load(4); c = load(5); }
+            else if (it == 4) { store(3, a); store(4, b); store(5, c); a = load(6); b = load(7); c = load(8); }
+            else if (it == 6) { store(6, a); store(7, b); store(8, c); a = load(9); }
+            else if (it == 8) { store(9, a); }
+        }
+    } st;
+    st.off0 = wave * 1024u + lane * 16u;
+    st.lds_base = lds_base;
+    auto frame_setup = [&](uint32_t ff, uint32_t ff_words, auto staged) {   // geometry scalars + the two reductions of every pixel, once per frame
+        const FrameDev fd = tab.f[ff];
+        const uint32_t m_s = __builtin_amdgcn_readfirstlane(fd.m);
+        const uint32_t fkc = __builtin_amdgcn_readfirstlane(fd.floor_k);
+        fk = fkc & 0xFFu;
+        const uint32_t c_v = vgpr_copy((fkc >> 8) & 0xFFu);
+        m_v = vgpr_copy(m_s);
+        // (__builtin_amdgcn_readfirstlane returns int: every half goes through uint32_t, or the low one sign-extends into the high one)
+        const uint32_t nhi = __builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32)), nlo = __builtin_amdgcn_readfirstlane((uint32_t)fd.M);
+        const double ninv = __builtin_bit_cast(double, ((uint64_t)nhi << 32) | nlo);
+        if (decltype(staged)::value) {
+            const uint32_t words = ff_words < tile_words ? ff_words : tile_words;             // tile 0
+            st.row = reinterpret_cast<const uint8_t *>(image + (uint64_t)ff * image_stride_words32);
+            st.last = ((words + 3u) & ~3u) * 4u - 16u;
+        }
+        notact = 0;
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            if (decltype(staged)::value && !(AB & 8)) st.at(it);
+            // opaque copies: with the setup inlined before the loop and at its end, the compiler would otherwise keep the
+            // 16 converted doubles (frame-invariant) live across the whole loop -- 32 registers, 174 dwords of spills
+            uint64_t a1 = h1[it], a2 = h2[it];
+            asm volatile("" : "+v"(a1), "+v"(a2));
+            pos0[it] = mod_m_f64((double)a1, (uint32_t)a1, ninv, m_v);
+            step[it] = mod_m_f64((double)a2, (uint32_t)a2, ninv, m_v);
+            const uint32_t rk = ((it < 4 ? rank_lo : rank_hi) >> (8 * (it & 3))) & 0xFFu;
+            notact |= (rk <= c_v) ? 0u : (1u << it);
+            fail[it] = 0;
+        }
+        if (decltype(staged)::value && !(AB & 8)) st.at(8);
+    };
+    frame_setup(f, fwords, std::false_type{});
+    if (!(AB & 32)) __syncthreads();              // the SAFE dword is in place
+    stage_dma(f, fwords, 0);
+    while (true) {
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            if (t) {
+                if (!(AB & 32)) __syncthreads();  // the previous tile's probes are done
+                stage_dma(f, fwords, t);
+            }
+            if (!(AB & 32)) {
+                dma_wait_all();                   // my share has landed ...
+                __syncthreads();                  // ... and everyone's
+            }
+            const uint32_t w0 = t * tile_words;
+            switch (fk) {
+            case 1: tile_part_f64<1, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
+            case 2: tile_part_f64<2, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
+            case 3: tile_part_f64<3, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
+            default: tile_part_f64<-1, AB>(pos0, step, notact, fbase, w0, tile_words, m_v, fk, fail); break;
+            }
+        }
+        uint32_t pbf = 0, npass = 0;
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) pbf = __builtin_amdgcn_alignbit(pbf, fail[it], 31);
+        const uint32_t fnext = __builtin_amdgcn_readfirstlane(next_active(f + 1));
+        const uint32_t fwords_next = fnext < nframes ? __builtin_amdgcn_readfirstlane(filter_words(tab.f[fnext].m)) : 0u;
+        if (fnext < nframes && !(AB & 32)) __syncthreads();       // this frame's last probes are done: the buffer is free for the next frame's first tile
+        // ---- verdicts of the frame
+        const uint32_t pb = ~(pbf | invalid_byte) & 0xFFu;
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) npass += __popcll(__ballot(((pb >> (7 - it)) & 1u) != 0));
+        if (!(AB & 64) && live) {
+            pass_bytes[((uint64_t)f * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)pb;
+            if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
+        }
+        if (fnext >= nframes) break;
+        f = fnext;
+        fwords = fwords_next;
+        ntiles = (fwords + tile_words - 1) / tile_words;
+        frame_setup(f, fwords, std::true_type{});                 // ... which is staged in here
     }
 }
 

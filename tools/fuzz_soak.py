@@ -21,7 +21,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int.from_bytes(os.urandom(4), "little")
 rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
-KNOBS = [0, 0, 0, 2, 1, 4 << 16, 32 << 16, 4, 8, 16, 32, 64, (64 << 16) | 32, 16 | 64, (32 << 16) | (1 << 14), (32 << 16) | 128, (8 << 16) | (1 << 14), 8 << 16, 1 << 15, 1 << 13, 0, 0]   # default (x3), single buffer, generic, tiled 1 KiB / 8 KiB, generic mask bits,
+KNOBS = [0, 0, 0, 2, 1, 4 << 16, 32 << 16, 4, 8, 16, 32, 64, (64 << 16) | 32, 16 | 64, (32 << 16) | (1 << 14), (32 << 16) | 128, (8 << 16) | (1 << 14), 8 << 16, 1 << 15, 1 << 13, (16 << 16) | (1 << 13), 0, 0]   # default (x3), single buffer, generic, tiled 1 KiB / 8 KiB, generic mask bits,
 #         Barrett only, hash table rebuilt per batch, hash in insert, k_query_p4, 16 KiB tiles + hash in insert, rebuilt table + p4,
 #         8 KiB tiles with hashed position records, 8 KiB tiles with the tiled k_insert_tab, 2 KiB tiles hashed / gathered records, no table rewrite, k_query_f64 (DMA) instead of k_query_r64, default x2  (rbf.h: rbf_ctx_force_generic)
 unpack = lambda a, nb: np.unpackbits(np.asarray(a, dtype=np.uint8))[:nb]
