@@ -58,7 +58,7 @@ def main(path):
         else:
             active.discard(i)
     span = rows[-1][1] - rows[0][0]
-    print("kernels %d, span %.3f ms, sum of durations %.3f ms, busy (union) %.3f ms, idle %.3f ms" % (len(rows), span / 1e6, total / 1e6, busy / 1e6, (span - busy) / 1e6))
+    print("kernels %d, span %.3f ms, sum of durations %.3f ms, busy (union) %.3f ms, idle %.3f ms" % (len(rows), span / 1e6, total / 1e6, busy / 1e6, max(0, span - busy) / 1e6))
     print("time with N kernels resident: " + ", ".join("%d: %.1f %%" % (d, 100.0 * v / span) for d, v in sorted(depth_time.items())))
     print("%-22s %10s %12s %12s" % ("kernel", "launches", "avg us", "shared %"))
     cnt = defaultdict(int)
