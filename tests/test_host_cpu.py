@@ -270,3 +270,27 @@ def test_fp64_reduction_is_exact(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe, "3000"], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("OK "), out.stdout[-2000:]
+
+
+def test_activation_rank_is_equivalent_to_the_threshold_compare():
+    """k_query_r64 keeps, per pixel, rank = #{coded thresholds t_j <= h_act} (one byte) instead of the 64-bit activation hash,
+    and tests rank <= c_f with c_f = #{t_j < T_f} (rbf_kernels_r64.h; the host side is rank_table() in rbf_api.hip).  Restated
+    here in Python integers: for any multiset of thresholds -- repeated values, 0, 2^64 - 1 -- and any hash,
+    (h_act < T_f) == (rank <= c_f) for every frame f."""
+    import bisect
+    import random
+    rnd = random.Random(2026)
+    special = [0, 1, 2 ** 63, 2 ** 64 - 2, 2 ** 64 - 1]
+    for _ in range(300):
+        nfr = rnd.randint(1, 128)
+        ts = [rnd.choice(special) if rnd.random() < 0.15 else rnd.getrandbits(64) for _ in range(nfr)]
+        if rnd.random() < 0.5:                                   # repeated thresholds
+            ts = [ts[rnd.randrange(max(1, nfr // 3))] for _ in range(nfr)]
+        srt = sorted(ts)
+        c = [bisect.bisect_left(srt, t) for t in ts]             # std::lower_bound in rank_table()
+        hashes = [rnd.getrandbits(64) for _ in range(40)] + special + [t for t in ts[:8]] + [max(0, t - 1) for t in ts[:8]]
+        for h in hashes:
+            rank = bisect.bisect_right(srt, h)                   # the kernel's branch-free upper_bound
+            assert rank <= 128
+            for f in range(nfr):
+                assert (h < ts[f]) == (rank <= c[f]), (h, ts[f], rank, c[f])
