@@ -606,8 +606,10 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
 
 // The FrameTable k_query_r64 / k_query_r64t read (rbf_kernels_r64.h): M as in `qtab` (bits of -1/m); T = the coded frames'
 // thresholds SORTED (entry j = j-th smallest, ~0 past the last one); floor_k |= c << 8 with c = coded thresholds below the frame's own.
-static FrameTable rank_table(const FrameTable &tab, const FrameTable &qtab, uint32_t nframes)
+static FrameTable rank_table(const FrameTable &tab, const FrameTable &qtab, uint32_t nframes, uint32_t *any_passthrough)
 {
+    *any_passthrough = 0;
+    for (uint32_t f = 0; f < nframes; ++f) if (!tab.f[f].m) *any_passthrough = 1;
     FrameTable rtab = qtab;
     uint64_t sorted[MAX_BATCH];
     uint32_t coded = 0;
@@ -827,12 +829,13 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
         if (!ctx->query_dma) {
-            const FrameTable rtab = rank_table(tab, qtab, nframes);
+            uint32_t passthrough;
+            const FrameTable rtab = rank_table(tab, qtab, nframes, &passthrough);
             if (int r = allow_big_lds((const void *)k_query_r64t<0>)) return r;
             const size_t lds_bytes = pl.query_lds_bytes > 2 * MAX_BATCH * 8 + 16 ? pl.query_lds_bytes : (size_t)2 * MAX_BATCH * 8 + 16;   // room for the thresholds' copy
             hipLaunchKernelGGL(k_query_r64t<0>, dim3((uint32_t)bx), dim3(QL_THREADS), lds_bytes, ctx->stream,
                                n, nframes, rtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
-                               ctx->seg_cnt, pl.nseg, ctx->pass_words);
+                               ctx->seg_cnt, pl.nseg, ctx->pass_words, passthrough);
         } else {
             auto kern = k_query_f64t<0>;
             if (int r = allow_big_lds((const void *)kern)) return r;
@@ -866,11 +869,12 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
                                n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                                ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
         } else if (!ctx->query_dma) {
-            const FrameTable rtab = rank_table(tab, qtab, nframes);
+            uint32_t passthrough;
+            const FrameTable rtab = rank_table(tab, qtab, nframes, &passthrough);
             if (int r = allow_big_lds((const void *)k_query_r64<0>)) return r;
             hipLaunchKernelGGL(k_query_r64<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                                n, nframes, rtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
-                               ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
+                               ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out, passthrough);
         } else
         hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                            n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,

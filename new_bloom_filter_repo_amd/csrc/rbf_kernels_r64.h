@@ -180,7 +180,8 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_r64(
     uint64_t n, uint32_t nframes, const FrameTable tab /* see the header comment */, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t fwords_max,
     uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words,
-    uint4 *__restrict__ table_out /* nullable: write the hash table of the frame geometry for the NEXT batch's insert kernel */)
+    uint4 *__restrict__ table_out /* nullable: write the hash table of the frame geometry for the NEXT batch's insert kernel */,
+    uint32_t any_passthrough /* some frame has m == 0 */)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // two buffers; each ends with 4 dwords that the staging never touches, the first of which stays 0 (SAFE)
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_r64(
     const bool whole_wave = __builtin_amdgcn_readfirstlane((uint32_t)__all(validmask == 0xFFu)) != 0u;   // every lane owns 8 positions inside the frame
     uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
 
-    // passthrough frames (m == 0): nothing passes
+    // passthrough frames (m == 0): nothing passes.  Only walked when the host saw one: 29 dependent scalar loads otherwise (~2 us).
+    if (any_passthrough)
     for (uint32_t g = 0; g < nframes; ++g) {
         if (tab.f[g].m == 0) {
             if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
@@ -334,7 +336,7 @@ template <int AB = 0>
 __global__ __launch_bounds__(QL_THREADS) void k_query_r64t(
     uint64_t n, uint32_t nframes, const FrameTable tab /* as for k_query_r64: M = bits of -1/m, T = sorted thresholds, floor_k = floor(k*) | c << 8 */, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t tile_words /* multiple of 4; tile_words + 4 dwords of LDS */,
-    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words)
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words, uint32_t any_passthrough /* some frame has m == 0 */)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // ONE buffer of tile_words dwords + the SAFE dword (kept 0): measured, the LDS-DMA of a tile does not hide under the
@@ -395,6 +397,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_r64t(
     for (int it = 0; it < QL_P; ++it) invalid_byte |= ((validmask >> it) & 1u) ? 0u : (0x80u >> it);
     uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
 
+    if (any_passthrough)
     for (uint32_t g = 0; g < nframes; ++g) {
         if (tab.f[g].m == 0) {
             if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;

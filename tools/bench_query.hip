@@ -34,7 +34,7 @@ static float run(const uint64_t *masks, uint64_t mstride, uint64_t n, uint32_t F
         }
     }
     auto launch = [&](dim3 g, dim3 b, size_t sh, hipStream_t st, uint64_t n_, uint32_t F_, const FrameTable &t_, Seeds s_, const uint32_t *f_, uint64_t fs_, uint32_t fw_, uint32_t *sc_, uint64_t ns_, uint64_t *pw_) {
-        if constexpr (MODK == 2) k_query_r64<AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out);
+        if constexpr (MODK == 2) k_query_r64<AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out, (AB & 128) ? 1u : 0u);
         else if constexpr (MODK == 1) k_query_f64<AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_, g_table_out);
         else k_query_lds<DB, true, AB><<<g, b, sh, st>>>(n_, F_, t_, s_, f_, fs_, fw_, sc_, ns_, pw_);
     };
@@ -127,6 +127,8 @@ int main()
         printf("%-60s %8.1f us\n", "[r64] full kernel (bench thresholds)", run<0, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
         printf("%-60s %8.1f us\n", "[r64] no staging (barrier kept)", run<8, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
         printf("%-60s %8.1f us\n", "[r64] no staging, no barrier (pure passes)", run<8 | 32, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+        printf("%-60s %8.1f us\n", "[r64] WITH the passthrough-frame loop (a frame with m = 0 in the batch)", run<128, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
+        printf("%-60s %8.1f us\n", "[r64] full kernel again", run<0, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
         printf("%-60s %8.1f us\n", "[r64] no hashing", run<16, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
         printf("%-60s %8.1f us\n", "[f64] full kernel", run<0, true, QL_THREADS, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
         return 0;

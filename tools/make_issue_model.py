@@ -101,7 +101,7 @@ def main():
         src = os.path.join(tmp, "k.hip")
         with open(src, "w") as f:
             f.write('#include "rbf_kernels_i64.h"\n#include "rbf_kernels_r64.h"\nusing namespace rbf;\n'
-                    'template __global__ void rbf::k_query_r64<0>(uint64_t, uint32_t, const FrameTable, Seeds, const uint32_t *, uint64_t, uint32_t, uint32_t *, uint64_t, uint64_t *, uint4 *);\n'
+                    'template __global__ void rbf::k_query_r64<0>(uint64_t, uint32_t, const FrameTable, Seeds, const uint32_t *, uint64_t, uint32_t, uint32_t *, uint64_t, uint64_t *, uint4 *, uint32_t);\n'
                     'template __global__ void rbf::k_insert_tab<0>(const uint8_t *, uint64_t, uint64_t, const FrameTable, const uint4 *, uint32_t *, uint64_t, uint32_t, const SliceTable, uint32_t, uint32_t);\n')
         out = os.path.join(tmp, "k.s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
