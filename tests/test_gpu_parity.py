@@ -496,6 +496,51 @@ def test_shared_hash_table_from_concurrent_threads(oracle):
         assert not errors, errors
 
 
+@pytest.mark.parametrize("force", [0, 1 << 13, 16 << 16], ids=["default", "dma_query", "tiles_4KiB"])
+def test_long_gop_129_inter_frames_vs_oracle(oracle, force):
+    """A GOP of 130 frames = 129 inter-frames: the library splits it into batches of MAX_BATCH = 128 + 1.  The first batch fills
+    every per-batch table to the brim -- 128 thresholds for the activation ranks (binary search from step 64, ranks up to 128),
+    128 geometries in the kernel arguments, 2 insert slices per frame -- with repeated densities (equal thresholds) and unchanged
+    frames (m = 0) in it.  448x256 luma frames: m ~ 33-36 kbit, inside the FP64 reduction's range."""
+    from new_bloom_filter_repo_amd.gop import GopCoder
+    from new_bloom_filter_repo_amd.synthetic import next_frame
+    rng = np.random.default_rng(1300)
+    W, H, F = 448, 256, 130
+    n = W * H
+    ps = [0.0889, 0.0889, 0.12, 0.0, 0.05, 0.3, 0.2, 0.01, 0.0889, 0.15]
+    frames = [rng.integers(0, 256, (H, W), dtype=np.uint8)]
+    for t in range(F - 1):
+        p = ps[t % len(ps)]
+        frames.append(next_frame(rng, frames[-1][..., None].repeat(3, axis=2), p)[..., 0].copy() if p else frames[-1].copy())
+    frames = np.stack(frames)
+    ctx = nat.Context(0)
+    ctx.force_generic(force)
+    eng = BloomEngine(ctx)
+    coder = GopCoder(ctx, W, H, F, channels=1)
+    coder.load_frames(frames)
+    coder.encode()
+    coded = 0
+    for f, r in enumerate(coder.results()):
+        want = oracle.residual_mask(frames[f], frames[f + 1], 0.0).reshape(-1)
+        assert np.array_equal(unpack(r["mask"], n), want), f
+        bm, wit, p, _, _ = oracle.compress(want)
+        if len(wit) == 0:
+            assert r["l"] == 0 and r["witness_bits"] == 0, f
+            continue
+        coded += 1
+        k, l = oracle.optimal_params(n, p)
+        assert (r["k"], r["l"]) == (k, l), f
+        assert np.array_equal(unpack(r["filter"], l), bm), f
+        assert r["witness_bits"] == len(wit) and np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8)), f
+        if f % 16 == 0:
+            dec = eng.decode(n, [P.filter_params(k, l)], [r["filter"]], [r["witness"]])
+            assert np.array_equal(unpack(dec[0], n), want), f
+    assert coded >= 100
+    coder.close()
+    eng.close()
+    ctx.close()
+
+
 def test_key_length_boundary_at_ten_million(eng, oracle):
     """Indices around 10^7 (7- and 8-character keys in the same wave) through every kernel family: the LDS kernels'
     fixed-length and shared-prefix hash paths must hand over to the generic one exactly at the boundary."""
