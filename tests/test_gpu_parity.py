@@ -501,11 +501,12 @@ def test_long_gop_129_inter_frames_vs_oracle(oracle, force):
     """A GOP of 130 frames = 129 inter-frames: the library splits it into batches of MAX_BATCH = 128 + 1.  The first batch fills
     every per-batch table to the brim -- 128 thresholds for the activation ranks (binary search from step 64, ranks up to 128),
     128 geometries in the kernel arguments, 2 insert slices per frame -- with repeated densities (equal thresholds) and unchanged
-    frames (m = 0) in it.  448x256 luma frames: m ~ 33-36 kbit, inside the FP64 reduction's range."""
+    frames (m = 0) in it.  960x544 luma frames keep every coded filter inside the FP64 kernels' range (m >= 2^15, asserted),
+    from k* = 0.17 (floor 0) to k* = 5.6 (floor 5: the runtime-k pass)."""
     from new_bloom_filter_repo_amd.gop import GopCoder
     from new_bloom_filter_repo_amd.synthetic import next_frame
     rng = np.random.default_rng(1300)
-    W, H, F = 448, 256, 130
+    W, H, F = 960, 544, 130
     n = W * H
     ps = [0.0889, 0.0889, 0.12, 0.0, 0.05, 0.3, 0.2, 0.01, 0.0889, 0.15]
     frames = [rng.integers(0, 256, (H, W), dtype=np.uint8)]
@@ -536,6 +537,7 @@ def test_long_gop_129_inter_frames_vs_oracle(oracle, force):
             dec = eng.decode(n, [P.filter_params(k, l)], [r["filter"]], [r["witness"]])
             assert np.array_equal(unpack(dec[0], n), want), f
     assert coded >= 100
+    assert min(r["l"] for r in coder.results() if r["l"]) >= 1 << 15       # else the batch would have taken the Barrett kernels
     coder.close()
     eng.close()
     ctx.close()
