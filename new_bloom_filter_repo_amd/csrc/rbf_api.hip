@@ -810,7 +810,8 @@ static int ensure_image(rbf_ctx *ctx, const Plan &pl, uint32_t nframes)
 
 // image_ready: the probe image of this batch has already been written (k_filter_reduce does it on the encode side)
 static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nframes, const FrameTable &tab, const Seeds &sd,
-                        const void *filters_dev, uint64_t filter_stride_bytes, bool image_ready, bool table_for_next = false)
+                        const void *filters_dev, uint64_t filter_stride_bytes, bool image_ready, bool table_for_next = false,
+                        bool quiet_passthrough = false /* frames with m == 0 are another launch's: do not write their (empty) outputs */)
 {
     if ((pl.query_kind == 1 || pl.query_kind == 3) && pl.f64_mod) {
         if (int r = ensure_image(ctx, pl, nframes)) return r;
@@ -831,6 +832,7 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         if (!ctx->query_dma) {
             uint32_t passthrough;
             const FrameTable rtab = rank_table(tab, qtab, nframes, &passthrough);
+            if (quiet_passthrough) passthrough = 0;
             if (int r = allow_big_lds((const void *)k_query_r64t<0>)) return r;
             const size_t lds_bytes = pl.query_lds_bytes > 2 * MAX_BATCH * 8 + 16 ? pl.query_lds_bytes : (size_t)2 * MAX_BATCH * 8 + 16;   // room for the thresholds' copy
             hipLaunchKernelGGL(k_query_r64t<0>, dim3((uint32_t)bx), dim3(QL_THREADS), lds_bytes, ctx->stream,
@@ -871,6 +873,7 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         } else if (!ctx->query_dma) {
             uint32_t passthrough;
             const FrameTable rtab = rank_table(tab, qtab, nframes, &passthrough);
+            if (quiet_passthrough) passthrough = 0;
             if (int r = allow_big_lds((const void *)k_query_r64<0>)) return r;
             hipLaunchKernelGGL(k_query_r64<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                                n, nframes, rtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
@@ -906,12 +909,14 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
 }
 
 // one chunk of at most MAX_BATCH frames (the geometry table rides in the kernel arguments)
-static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
-                        uint64_t n, uint32_t nframes, const rbf_filter_params *params,
-                        const rbf_seeds *seeds,
-                        void *filters_dev, uint64_t filter_stride_bytes,
-                        void *witnesses_dev, uint64_t witness_stride_bytes,
-                        uint64_t *stats_dev, bool outputs_zeroed, const uint64_t *ones_host /* nullable: set bits of every mask */)
+// `quiet_passthrough` / `compact`: see encode_chunk (a batch split over the two kernel families runs this twice)
+static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
+                             uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                             const rbf_seeds *seeds,
+                             void *filters_dev, uint64_t filter_stride_bytes,
+                             void *witnesses_dev, uint64_t witness_stride_bytes,
+                             uint64_t *stats_dev, bool outputs_zeroed, const uint64_t *ones_host /* nullable: set bits of every mask */,
+                             bool quiet_passthrough, bool compact)
 {
     uint64_t nrecords = 0;
     if (ones_host) for (uint32_t f = 0; f < nframes; ++f) if (params[f].m) nrecords += ones_host[f];
@@ -1046,9 +1051,9 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
         }
     }
     // ---- query: pass word of every 64 positions + per-segment pass counts
-    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, want_image, pl.insert_tab)) return r;
+    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, want_image, pl.insert_tab, quiet_passthrough)) return r;
     // ---- witness: pext(mask, pass) of every word lands at its bit offset (scan fused in)
-    {
+    if (compact) {
         const uint64_t words = pl.nseg * pl.words_per_seg;
         uint64_t bx = (words + WG_THREADS * CW_CHUNKS - 1) / (WG_THREADS * CW_CHUNKS);
         if (bx < 1) bx = 1;
@@ -1059,6 +1064,43 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;
+}
+
+// One chunk of at most MAX_BATCH frames.  The FP64 kernels (hash-table insert, k_query_r64 / r64t) need EVERY coded filter of
+// their launch inside F64MOD_M_MIN <= m <= F64MOD_M_MAX; a single nearly static frame (1080p: < ~0.2 % changed pixels) used to
+// send its whole batch to the round-1 Barrett kernels.  A mixed batch is now coded in two passes over disjoint frame sets --
+// first the out-of-range frames (Barrett kernels; they also write the empty outputs of every frame that is not theirs), then
+// the in-range ones (FP64 kernels, told to leave the others' outputs alone) -- followed by one compaction over all frames.
+// Only when both passes cut the frame into the same segments (pass bytes and segment counts are shared with the compaction).
+static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
+                        uint64_t n, uint32_t nframes, const rbf_filter_params *params,
+                        const rbf_seeds *seeds,
+                        void *filters_dev, uint64_t filter_stride_bytes,
+                        void *witnesses_dev, uint64_t witness_stride_bytes,
+                        uint64_t *stats_dev, bool outputs_zeroed, const uint64_t *ones_host)
+{
+    uint32_t in_range = 0, out_of_range = 0;
+    for (uint32_t f = 0; f < nframes; ++f)
+        if (params[f].m) ++((params[f].m >= F64MOD_M_MIN && params[f].m <= F64MOD_M_MAX) ? in_range : out_of_range);
+    if (in_range && out_of_range && !ctx->force_generic && !ctx->barrett_only && !ctx->query_dma && !ctx->no_hash_table && !ctx->single_buffer) {
+        rbf_filter_params small[MAX_BATCH], big[MAX_BATCH];
+        for (uint32_t f = 0; f < nframes; ++f) {
+            small[f] = big[f] = params[f];
+            const bool fp64 = params[f].m >= F64MOD_M_MIN && params[f].m <= F64MOD_M_MAX;
+            (fp64 ? small[f] : big[f]).m = 0;
+        }
+        const Plan ps = make_plan(ctx, small, nframes, n, false), pb = make_plan(ctx, big, nframes, n, ones_host != nullptr);
+        const bool fp64_query = (pb.query_kind == 1 || pb.query_kind == 3) && pb.f64_mod && !pb.query_p4;
+        if (fp64_query && pb.insert_tab && ps.nseg == pb.nseg && ps.words_per_seg == pb.words_per_seg) {
+            if (int r = encode_chunk_pass(ctx, masks_dev, mask_stride_bytes, n, nframes, small, seeds, filters_dev, filter_stride_bytes,
+                                          witnesses_dev, witness_stride_bytes, stats_dev, outputs_zeroed, nullptr, false, false))
+                return r;
+            return encode_chunk_pass(ctx, masks_dev, mask_stride_bytes, n, nframes, big, seeds, filters_dev, filter_stride_bytes,
+                                     witnesses_dev, witness_stride_bytes, stats_dev, true, ones_host, true, true);
+        }
+    }
+    return encode_chunk_pass(ctx, masks_dev, mask_stride_bytes, n, nframes, params, seeds, filters_dev, filter_stride_bytes,
+                             witnesses_dev, witness_stride_bytes, stats_dev, outputs_zeroed, ones_host, false, true);
 }
 
 static int encode_batch_impl(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,

@@ -543,6 +543,50 @@ def test_long_gop_129_inter_frames_vs_oracle(oracle, force):
     ctx.close()
 
 
+@pytest.mark.parametrize("force", [0, 32 << 16, 1 << 13, 8, 1 << 14 | 32 << 16], ids=["default", "tiles_8KiB", "dma_query_no_split", "barrett_only_no_split", "tiles_hashed_records"])
+def test_mixed_batch_is_split_over_the_kernel_families(oracle, force):
+    """A GOP whose filters straddle the FP64 kernels' range (2^15 <= m < 2^23): busy frames next to nearly static ones (a few
+    hundred changed pixels: m of a few thousand bits) and unchanged ones.  rbf_encode_gop codes such a batch in two passes --
+    Barrett kernels for the small filters, FP64 kernels for the rest, one compaction -- and every frame must still match the
+    oracle, whichever frame comes first, also when a knob rules the split out."""
+    from new_bloom_filter_repo_amd.gop import GopCoder
+    from new_bloom_filter_repo_amd.synthetic import next_frame
+    rng = np.random.default_rng(5150)
+    W, H, n = 640, 360, 640 * 360
+    for order in ((0.0889, 0.002, 0.05, 0.0, 0.0005, 0.12, 0.001), (0.0008, 0.0889, 0.0, 0.2, 0.003)):
+        frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8)]
+        for p in order:
+            frames.append(next_frame(rng, frames[-1], p) if p else frames[-1].copy())
+        frames = np.stack(frames)
+        ctx = nat.Context(0)
+        ctx.force_generic(force)
+        eng = BloomEngine(ctx)
+        coder = GopCoder(ctx, W, H, len(frames))
+        coder.load_frames(frames)
+        for _ in range(2):
+            coder.encode()
+            small = big = 0
+            for f, r in enumerate(coder.results()):
+                want = oracle.residual_mask(np.ascontiguousarray(frames[f][..., 0]), np.ascontiguousarray(frames[f + 1][..., 0]), 0.0).reshape(-1)
+                assert np.array_equal(unpack(r["mask"], n), want), f
+                bm, wit, p, _, _ = oracle.compress(want)
+                if len(wit) == 0:
+                    assert r["l"] == 0 and r["witness_bits"] == 0, f
+                    continue
+                k, l = oracle.optimal_params(n, p)
+                small += l < (1 << 15)
+                big += l >= (1 << 15)
+                assert (r["k"], r["l"]) == (k, l), f
+                assert np.array_equal(unpack(r["filter"], l), bm), f
+                assert r["witness_bits"] == len(wit) and np.array_equal(unpack(r["witness"], len(wit)), np.array(wit, dtype=np.uint8)), f
+                dec = eng.decode(n, [P.filter_params(k, l)], [r["filter"]], [r["witness"]])
+                assert np.array_equal(unpack(dec[0], n), want), f
+            assert small >= 2 and big >= 2
+        coder.close()
+        eng.close()
+        ctx.close()
+
+
 def test_key_length_boundary_at_ten_million(eng, oracle):
     """Indices around 10^7 (7- and 8-character keys in the same wave) through every kernel family: the LDS kernels'
     fixed-length and shared-prefix hash paths must hand over to the generic one exactly at the boundary."""
