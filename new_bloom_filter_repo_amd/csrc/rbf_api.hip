@@ -1312,7 +1312,32 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * wps * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
-    if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, false)) return r;
+    // mixed batch (see encode_chunk): the query runs twice over disjoint frame sets, the scan and the expansion once
+    bool split = false;
+    {
+        uint32_t in_range = 0, out_of_range = 0;
+        for (uint32_t f = 0; f < nframes; ++f)
+            if (params[f].m) ++((params[f].m >= F64MOD_M_MIN && params[f].m <= F64MOD_M_MAX) ? in_range : out_of_range);
+        if (in_range && out_of_range && !ctx->force_generic && !ctx->barrett_only && !ctx->query_dma && !ctx->single_buffer) {
+            rbf_filter_params small[MAX_BATCH], big[MAX_BATCH];
+            for (uint32_t f = 0; f < nframes; ++f) {
+                small[f] = big[f] = params[f];
+                const bool fp64 = params[f].m >= F64MOD_M_MIN && params[f].m <= F64MOD_M_MAX;
+                (fp64 ? small[f] : big[f]).m = 0;
+            }
+            const Plan ps = make_plan(ctx, small, nframes, n), pb = make_plan(ctx, big, nframes, n);
+            if ((pb.query_kind == 1 || pb.query_kind == 3) && pb.f64_mod && !pb.query_p4 && ps.nseg == pl.nseg && pb.nseg == pl.nseg &&
+                ps.words_per_seg == wps && pb.words_per_seg == wps) {
+                FrameTable ts, tb;
+                if (int r = fill_table(small, nframes, &ts)) return r;
+                if (int r = fill_table(big, nframes, &tb)) return r;
+                if (int r = launch_query(ctx, ps, n, nframes, ts, sd, filters_dev, filter_stride_bytes, false)) return r;
+                if (int r = launch_query(ctx, pb, n, nframes, tb, sd, filters_dev, filter_stride_bytes, false, false, true)) return r;
+                split = true;
+            }
+        }
+    }
+    if (!split) if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, false)) return r;
     {
         LaunchTimer t(ctx, RBF_K_SCAN);
         hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, pl.nseg,

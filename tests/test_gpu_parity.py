@@ -582,6 +582,12 @@ def test_mixed_batch_is_split_over_the_kernel_families(oracle, force):
                 dec = eng.decode(n, [P.filter_params(k, l)], [r["filter"]], [r["witness"]])
                 assert np.array_equal(unpack(dec[0], n), want), f
             assert small >= 2 and big >= 2
+            # ... and ONE decode call over all coded frames (the decoder splits its query the same way)
+            res = [r for r in coder.results() if r["l"]]
+            masks = [np.unpackbits(r["mask"])[:n] for r in res]
+            dec = eng.decode(n, [P.filter_params(r["k"], r["l"]) for r in res], [r["filter"] for r in res], [r["witness"] for r in res])
+            for j, want in enumerate(masks):
+                assert np.array_equal(unpack(dec[j], n), want), j
         coder.close()
         eng.close()
         ctx.close()
