@@ -562,7 +562,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_tiled(
 // seg_off[segment] + (passes of the segment's earlier words) in the pre-zeroed packed witness.
 // ------------------------------------------------------------------------------------------
 constexpr int CW_CHUNKS = 1;                      // chunks of WG_THREADS words per workgroup (8 measured slower: 25 vs 20 us -- parallelism wins)
-static_assert(CW_CHUNKS == 1, "the multi-chunk walk below is kept for reference only: no test covers it, and 2 chunks no longer reproduce the oracle (round 2)");
+static_assert(CW_CHUNKS == 1, "only the one-chunk configuration is covered by the tests (a 2-chunk build did not get through bench.py in round 2)");
 
 __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
