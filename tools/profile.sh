@@ -14,6 +14,9 @@ rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_default" -o 
 # ... and one pipeline alone: every kernel has the chip to itself (this is what the counters describe)
 BENCH="python $ROOT/bench.py --streams 1 --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-verify $*"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+# ... and the same without the sole holder's rewrite of the shared hash table (force bit 15): the condition of bench.py's own
+# "alone" figures, which are taken while the other pipelines' contexts still hold the table
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_norewrite" -o stats -- $BENCH --force-bits 32768 > "$OUT/stats_norewrite.log" 2>&1
 PMC1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_ANY"
 PMC2="SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
 rocprofv3 --output-format csv --pmc $PMC1 --kernel-trace -d "$OUT/pmc1" -o pmc -- $BENCH > "$OUT/pmc1.log" 2>&1

@@ -18,7 +18,9 @@ def short(name):
 
 for f in sorted(glob.glob(os.path.join(root, "stats*", "**", "*kernel_stats.csv"), recursive=True)):
     print("== kernel stats:", os.path.relpath(f, root),
-          "(default command: 4 GOP pipelines, kernels overlap)" if "stats_default" in f else "(--streams 1: kernels run alone)")
+          "(default command: 4 GOP pipelines, kernels overlap)" if "stats_default" in f else
+          "(--streams 1 --force-bits 32768: alone, the query kernel does not rewrite the shared hash table -- bench.py's `alone` condition)" if "stats_norewrite" in f else
+          "(--streams 1: kernels run alone; the sole holder's query kernel also rewrites the 66 MB hash table)")
     for row in csv.DictReader(open(f)):
         print("  %-60s calls %5s  avg %10.1f ns  total %12s ns  %5s%%" % (
             short(row.get("Name", "")), row.get("Calls"), float(row.get("AverageNs", 0)), row.get("TotalDurationNs"), row.get("Percentage")))
