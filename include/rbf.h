@@ -38,7 +38,7 @@ extern "C" {
 #define RBF_EIO      (-5)   /* a HIP runtime call failed; see rbf_last_error() */
 #define RBF_ERANGE  (-34)
 
-#define RBF_ABI_VERSION 1
+#define RBF_ABI_VERSION 2
 
 typedef struct rbf_ctx rbf_ctx;
 
@@ -125,6 +125,10 @@ int rbf_timing_enable(rbf_ctx *ctx, int on);
  *               rewritten in every batch, which keeps it in the Infinity Cache)
  *   bits 16..31 LDS tile cap in units of 64 dwords (0 = all of LDS) */
 int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
+/* Further testing / tuning knobs (the bit mask above is full).  RBF_OPT_QUERY_R64 (value 0 / 1): 1 = k_query_r64, the round-2 FP64
+ * query kernel, where k_query_s64 (round 3: pass written in rows, frame geometry in LDS, wave priorities) would run. */
+#define RBF_OPT_QUERY_R64 1
+int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value);
 int rbf_timing_reset(rbf_ctx *ctx);
 int rbf_timing_read(rbf_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
 

@@ -18,6 +18,7 @@ RBF_ERANGE = -34
 K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE, K_PACK, K_HASHTAB = range(13)
 KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack", "hashtab"]
 STATS_PER_FRAME = 4
+OPT_QUERY_R64 = 1                      # rbf_ctx_option keys (include/rbf.h)
 
 
 class FilterParams(ctypes.Structure):
@@ -51,6 +52,7 @@ _PROTOS = {
     "rbf_timing_enable": (_int, [_vp, _int]),
     "rbf_timing_reset": (_int, [_vp]),
     "rbf_ctx_force_generic": (_int, [_vp, _int]),
+    "rbf_ctx_option": (_int, [_vp, _int, ctypes.c_int64]),
     "rbf_timing_read": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
     "rbf_optimal_params": (_int, [_u64, _u64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
     "rbf_activation_threshold": (_int, [ctypes.c_double, ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),
@@ -202,6 +204,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def option(self, option, value):
+        """rbf_ctx_option: further tuning knobs (OPT_QUERY_R64 = 1: the round-2 query kernel instead of k_query_s64)."""
+        check(lib().rbf_ctx_option(self.handle, int(option), int(value)))
 
     def force_generic(self, on):
         """Testing knob: never use the LDS-resident fast-path kernels."""

@@ -3,6 +3,7 @@
 #include "../../include/rbf.h"
 #include "rbf_kernels_i64.h"
 #include "rbf_kernels_r64.h"
+#include "rbf_kernels_s64.h"
 #include "rbf_kernels_noise.h"
 #include "rbf_kernels_pack.h"
 
@@ -59,6 +60,7 @@ struct rbf_ctx {
     int hash_positions = 0;          // 1 = k_insert_positions hashes the set positions itself whatever the table size
     int no_table_rewrite = 0;        // 1 = the query kernel never rewrites the hash table, sole holder or not
     int query_dma = 0;               // 1 = k_query_f64 (LDS-DMA staging, 64-bit activation hashes) instead of k_query_r64
+    int query_r64 = 0;               // 1 = k_query_r64 (round 2) where k_query_s64 would run (rbf_ctx_option RBF_OPT_QUERY_R64)
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
@@ -360,6 +362,15 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     return RBF_OK;
 }
 
+int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value)
+{
+    if (!ctx) return fail(RBF_EINVAL, "null context");
+    switch (option) {
+    case RBF_OPT_QUERY_R64: ctx->query_r64 = value ? 1 : 0; return RBF_OK;
+    default: return fail(RBF_EINVAL, "unknown option %d", option);
+    }
+}
+
 int rbf_timing_reset(rbf_ctx *ctx)
 {
     if (int r = set_device(ctx)) return r;
@@ -622,6 +633,35 @@ static FrameTable rank_table(const FrameTable &tab, const FrameTable &qtab, uint
     return rtab;
 }
 
+// The FrameTable k_query_s64 reads (rbf_kernels_s64.h): COMPACTED over the coded frames -- entry j = j-th coded frame: m, M = bits of
+// -1/m, floor_k = floor(k*) | c << 8 | frame index << 16 (c = coded thresholds below the frame's own), T = j-th smallest threshold.
+// `empty`: bit f = frame f is not coded.
+static FrameTable query_table_s64(const FrameTable &tab, uint32_t nframes, uint32_t *nactive, uint64_t (&empty)[2])
+{
+    FrameTable q;
+    memset(&q, 0, sizeof q);
+    empty[0] = empty[1] = 0;
+    uint64_t sorted[MAX_BATCH];
+    uint32_t coded = 0;
+    for (uint32_t f = 0; f < nframes; ++f) {
+        if (tab.f[f].m) sorted[coded++] = tab.f[f].T;
+        else empty[f >> 6] |= 1ull << (f & 63);
+    }
+    std::sort(sorted, sorted + coded);
+    uint32_t j = 0;
+    for (uint32_t f = 0; f < nframes; ++f) {
+        if (!tab.f[f].m) continue;
+        const double ninv = -1.0 / (double)tab.f[f].m;
+        q.f[j].m = tab.f[f].m;
+        memcpy(&q.f[j].M, &ninv, 8);
+        q.f[j].floor_k = tab.f[f].floor_k | ((uint32_t)(std::lower_bound(sorted, sorted + coded, tab.f[f].T) - sorted) << 8) | (f << 16);
+        q.f[j].T = sorted[j];
+        ++j;
+    }
+    *nactive = coded;
+    return q;
+}
+
 static int allow_big_lds(const void *fn)
 {
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
@@ -870,6 +910,15 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
             hipLaunchKernelGGL(k_query_p4<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                                n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                                ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
+        } else if (!ctx->query_dma && !ctx->query_r64 && pl.query_lds_bytes + S64_GEO_BYTES <= LDS_LIMIT && pl.double_buffer) {
+            // k_query_s64 (default): compacted table, geometry in LDS behind the two image buffers
+            uint32_t nactive; uint64_t empty[2];
+            const FrameTable stab = query_table_s64(tab, nframes, &nactive, empty);
+            if (quiet_passthrough) empty[0] = empty[1] = 0;
+            if (int r = allow_big_lds((const void *)k_query_s64<0>)) return r;
+            hipLaunchKernelGGL(k_query_s64<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes + S64_GEO_BYTES, ctx->stream,
+                               n, nactive, stab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+                               ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out, empty[0], empty[1]);
         } else if (!ctx->query_dma) {
             uint32_t passthrough;
             const FrameTable rtab = rank_table(tab, qtab, nframes, &passthrough);

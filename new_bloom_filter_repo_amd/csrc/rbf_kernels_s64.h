@@ -1,0 +1,420 @@
+// rbf_kernels_s64.h -- k_query_s64: the frames-inner FP64 query kernel of round 3 (default for filters of 2^15 <= m < 2^23 bits that
+// fit LDS twice: BASELINE config 2).  Same outputs as k_query_r64 / k_query_f64 (pass bytes in numpy.packbits order + per-segment
+// pass counts; reference semantics improved_video_compressor.py:116-138, :245-253) and the same arithmetic (hashes once per launch
+// as (RN(h), low dword), h mod m through one v_fma_f64, probe image, activation ranks -- rbf_kernels_q64.h / rbf_kernels_r64.h).
+//
+// What changed, and the measurement behind each change (profiles/r03_query_ablation.txt):
+//
+//  1. THE FRAME GEOMETRY IS READ FROM LDS, NOT FROM THE KERNEL-ARGUMENT SEGMENT.  k_query_r64's frame loop fetched `tab.f[k]` (m, floor_k,
+//     -1/m) with scalar loads once per frame.  The kernarg segment is host-coherent memory: a scalar load that misses the scalar cache
+//     is a round trip over the fabric, every 64-byte line of the table (2.7 frames) missed once per scalar cache, the loads of
+//     next_active() and prepare() are dependent, and all 16 waves of a workgroup wait for them at the same point.  That -- not VALU
+//     issue, not LDS bank conflicts, not the schedule of the probes -- is what the ~2.1 us per frame of the round-2 kernel were made
+//     of: with the staging and the barrier removed its time did not move when the reductions (86 of 231 VALU instructions per
+//     frame), the LDS probes or the pass counting were taken out (70.9 / 69.4 / 71.3 / 68.8 us), nor when the pass was re-scheduled
+//     for ILP or with 15 % fewer instructions.  Here the host hands over a COMPACTED table (entry j = j-th coded frame), the first
+//     `nactive` threads copy it into LDS with one vector load each -- one round trip per launch -- and the loop reads its frame's
+//     16 bytes with a broadcast ds_read_b128.  No next_active(), no scalar load in the loop.
+//  2. The pass is written in ROWS of independent instructions (frame_pass_rows) and the remainder of the FP64 reduction is taken as
+//     an exact signed 32-bit number (one v_mad_u64_u32 instead of v_mad_u32_u24 + v_bfe_i32): 214 instead of 231 VALU and 270 instead
+//     of 314 instructions per wave and frame, no hazard s_nops, one s_waitcnt per pixel pair instead of six.
+//  3. Two staging slots instead of three (8 VGPRs), pass counts from the finished verdict byte (4 ballots per frame instead of 8),
+//     verdict / count addresses advanced by one add per frame.
+#pragma once
+#include "rbf_kernels_r64.h"
+
+namespace rbf {
+
+constexpr uint32_t S64_GEO_BYTES = MAX_BATCH * 16;                 // LDS behind the two image buffers: 16 bytes of geometry per coded frame
+
+// Two register slots (8 VGPRs) for the next frame's image: a 16-byte piece is loaded in one pixel pair and written to LDS in the
+// next.  Pieces per wave: at most five (a buffer of <= 80 KB over 16 waves x 1 KiB).  Branch-free (clamped offsets) for the
+// reason given at RowStager (rbf_kernels_r64.h).
+struct RowStager2 {
+    const uint8_t *row;             // next frame's image row (uniform)
+    uint32_t lds_base;              // byte address of the destination buffer (uniform)
+    uint32_t last;                  // row bytes - 16 (uniform): the clamp
+    uint32_t off0;                  // wave * 1024 + lane * 16
+    uint4 a, b;
+
+    __device__ __forceinline__ uint32_t off(int i) const { return min(off0 + (uint32_t)i * (QL_WAVES * 1024u), last); }
+    __device__ __forceinline__ uint4 load(int i) const { return *reinterpret_cast<const uint4 *>(row + off(i)); }
+    __device__ __forceinline__ void store(int i, const uint4 &v) const
+    {
+        *reinterpret_cast<__attribute__((address_space(3))) r64_u32x4 *>((uintptr_t)(lds_base + off(i))) = r64_u32x4{v.x, v.y, v.z, v.w};   // ds_write_b128
+    }
+    template <int AB>
+    __device__ __forceinline__ void at(int g)
+    {
+        if (AB & 8) return;
+        if (g == 0) { a = load(0); b = load(1); }
+        else if (g == 1) { store(0, a); store(1, b); a = load(2); b = load(3); }
+        else if (g == 2) { store(2, a); store(3, b); a = load(4); }
+        else if (g == 3) { store(4, a); }
+    }
+};
+
+// The compare half and the select half of rank_select (rbf_kernels_r64.h) as separate instructions with the lane mask in an SGPR
+// pair, so that the two pixels of a pair do not serialise on VCC.
+template <int B>
+__device__ __forceinline__ uint64_t rank_le(uint32_t ranks, uint32_t c)
+{
+    uint64_t mask;
+    if constexpr (B == 0) asm("v_cmp_le_u32_sdwa %0, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD" : "=s"(mask) : "v"(ranks), "v"(c));
+    else if constexpr (B == 1) asm("v_cmp_le_u32_sdwa %0, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD" : "=s"(mask) : "v"(ranks), "v"(c));
+    else if constexpr (B == 2) asm("v_cmp_le_u32_sdwa %0, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(mask) : "v"(ranks), "v"(c));
+    else asm("v_cmp_le_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:DWORD" : "=s"(mask) : "v"(ranks), "v"(c));
+    return mask;
+}
+__device__ __forceinline__ uint32_t select_by(uint64_t mask, uint32_t if_clear, uint32_t if_set)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+
+#define RBF_ROW() __builtin_amdgcn_sched_barrier(0)
+
+// The two reductions of the two pixels of pair g, as rows of four: x = {pos0, step} of pixel 2g, {pos0, step} of pixel 2g + 1.
+// Needs no filter image, so the kernel runs pair 0's IN FRONT of the frame's barrier.
+template <int AB>
+__device__ __forceinline__ void rows_reduce4(int g, const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
+                                             uint32_t m /* VGPR */, double ninv, uint32_t (&x)[4])
+{
+    const int i0 = 2 * g, i1 = 2 * g + 1;
+    if (AB & 1) { x[0] = hl1[i0] & 0x7FFFFu; x[1] = hl2[i0] & 0x3FFFFu; x[2] = hl1[i1] & 0x7FFFFu; x[3] = hl2[i1] & 0x3FFFFu; RBF_ROW(); return; }
+    const double t0 = __builtin_fma(hd1[i0], ninv, 0x1.8p52), t1 = __builtin_fma(hd2[i0], ninv, 0x1.8p52);
+    const double t2 = __builtin_fma(hd1[i1], ninv, 0x1.8p52), t3 = __builtin_fma(hd2[i1], ninv, 0x1.8p52);
+    RBF_ROW();
+    // r_est = h - q_est * m as an exact SIGNED 32-bit number (mod_m_f64, rbf_kernels_q64.h, derives the same value modulo 2^24 and
+    // sign-extends it): the low dword of t is -q_est mod 2^32 (1.5 * 2^52 has no low bits), hl is h mod 2^32, and
+    // |r_est| <= 0.75 m < 2^23.  One multiply-add; then the same fold of a negative r_est back into [0, m).
+    const uint32_t s0 = (uint32_t)__builtin_bit_cast(uint64_t, t0) * m + hl1[i0], s1 = (uint32_t)__builtin_bit_cast(uint64_t, t1) * m + hl2[i0];
+    const uint32_t s2 = (uint32_t)__builtin_bit_cast(uint64_t, t2) * m + hl1[i1], s3 = (uint32_t)__builtin_bit_cast(uint64_t, t3) * m + hl2[i1];
+    RBF_ROW();
+    const uint32_t q0 = s0 + m, q1 = s1 + m, q2 = s2 + m, q3 = s3 + m;
+    RBF_ROW();
+    x[0] = min(s0, q0); x[1] = min(s1, q1); x[2] = min(s2, q2); x[3] = min(s3, q3);
+    RBF_ROW();
+}
+
+// One frame's pass over a lane's 8 pixels, in pixel PAIRS, written in ROWS: a row holds the same instruction of up to four independent
+// chains (the two reductions of the two pixels; for the steps: two chains + the address arithmetic of the probes they feed), rows
+// are pinned with sched_barrier.  Per pair g:  reductions(g) | combine(g - 1) | steps + addresses + reads(g) | stager(g): the reads
+// of pair g - 1 fly under the reductions of pair g.  `x` arrives holding pair 0's reductions (computed in front of the barrier);
+// `after_first_reads()` runs once pair 0's reads are in flight (the kernel puts the previous frame's outputs there).
+// AB (ablation mask, tools/bench_query3.hip only; 0 in the library): 1 = no reductions, 2 = no LDS probes, 4 = no pass counting.
+template <int FK, int AB, typename STAGER, typename HOOK>
+__device__ __forceinline__ void frame_pass_rows(
+    const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
+    uint32_t rank_lo, uint32_t rank_hi, uint32_t c /* VGPR */, uint32_t lds_base_bytes /* VGPR */, uint32_t safe_pos /* VGPR */, uint32_t m /* VGPR */, double ninv,
+    uint32_t (&x)[4], uint32_t &pbf, STAGER &st, HOOK &&after_first_reads)
+{
+    static_assert(FK >= 1, "at least one deterministic probe");
+    constexpr int NP = FK + 1, NG = QL_P / 2;
+    uint32_t pos[2][2][NP], wrd[2][2][NP];                         // [pair parity][pixel of the pair][probe]
+    uint32_t five = 5u;                                            // opaque: written with a literal 5 the compiler folds shift, shift, add into shift, and, add
+    asm volatile("" : "+s"(five));
+    auto lds_word = [&](uint32_t addr) -> uint32_t {
+        return (AB & 2) ? addr * 0x9E3779B1u : *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
+    };
+    auto steps_and_reads = [&](int g, const uint32_t (&x)[4]) {    // positions of the pair's probes; every read is issued as soon as its address exists
+        const int par = g & 1;
+        uint32_t pa = x[0], pb_ = x[2];
+        const uint32_t sa = x[1], sb = x[3];
+#pragma unroll
+        for (int j = 0; j < FK; ++j) {
+            pos[par][0][j] = pa; pos[par][1][j] = pb_;
+            const uint32_t wa = pa >> five, wb = pb_ >> five;
+            const uint32_t ua = pa + sa, ub = pb_ + sb;
+            RBF_ROW();
+            const uint32_t aa = (wa << 2) + lds_base_bytes, ab = (wb << 2) + lds_base_bytes;
+            const uint32_t va = ua - m, vb = ub - m;
+            RBF_ROW();
+            wrd[par][0][j] = lds_word(aa); wrd[par][1][j] = lds_word(ab);
+            pa = min(ua, va); pb_ = min(ub, vb);
+            RBF_ROW();
+        }
+        const int i0 = 2 * g, i1 = 2 * g + 1;
+        const uint32_t rk0 = i0 < 4 ? rank_lo : rank_hi, rk1 = i1 < 4 ? rank_lo : rank_hi;
+        uint64_t k0, k1;                                           // the pair's activation masks: rank byte <= c
+        if ((i0 & 3) == 0) { k0 = rank_le<0>(rk0, c); k1 = rank_le<1>(rk1, c); }
+        else { k0 = rank_le<2>(rk0, c); k1 = rank_le<3>(rk1, c); }
+        RBF_ROW();
+        pos[par][0][FK] = select_by(k0, safe_pos, pa); pos[par][1][FK] = select_by(k1, safe_pos, pb_);   // the activated extra probe, or SAFE
+        RBF_ROW();
+        const uint32_t wa = pos[par][0][FK] >> five, wb = pos[par][1][FK] >> five;
+        RBF_ROW();
+        const uint32_t aa = (wa << 2) + lds_base_bytes, ab = (wb << 2) + lds_base_bytes;
+        RBF_ROW();
+        wrd[par][0][FK] = lds_word(aa); wrd[par][1][FK] = lds_word(ab);
+        RBF_ROW();
+    };
+    auto combine2 = [&](int g) {                                   // verdicts of pair g: the sign bit of `fail` says "some probed filter bit is 0"
+        const int par = g & 1;
+        uint32_t f0 = 0u, f1 = 0u;
+        if (!(AB & 2)) __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0), once: left alone the compiler waits in front of each of the six words
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f0 = (wrd[par][0][j] << (pos[par][0][j] & 31u)) | f0;
+            f1 = (wrd[par][1][j] << (pos[par][1][j] & 31u)) | f1;
+            RBF_ROW();
+        }
+        pbf = __builtin_amdgcn_alignbit(pbf, f0, 31);             // (pbf << 1) | (fail >> 31)
+        RBF_ROW();
+        pbf = __builtin_amdgcn_alignbit(pbf, f1, 31);
+        RBF_ROW();
+    };
+    // Wave priority falls as the wave advances (3, 2, 1, 0 over the four pairs; 0 until the next barrier).  The SIMD's arbiter serves the
+    // highest priority first and, among equals, the OLDEST wave: left alone the four waves of a SIMD run their passes almost one after
+    // the other (timeline: the oldest wave's pass takes 2 400 cycles, the youngest's 4 200) and the youngest finishes alone, at the
+    // one instruction per ~5 cycles a single wave can issue, while fifteen waves stand at the barrier.  With the priority tied to
+    // progress the waves behind are served first and all four finish together.
+    if (!(AB & 2048)) __builtin_amdgcn_s_setprio(3);
+    steps_and_reads(0, x);
+    st.template at<AB>(0);
+    RBF_ROW();
+    after_first_reads();
+    RBF_ROW();
+#pragma unroll
+    for (int g = 1; g < NG; ++g) {
+        if (!(AB & 2048)) { if (g == 1) __builtin_amdgcn_s_setprio(2); else if (g == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        rows_reduce4<AB>(g, hd1, hl1, hd2, hl2, m, ninv, x);      // the reads of pair g - 1 fly under these rows
+        combine2(g - 1);
+        steps_and_reads(g, x);
+        st.template at<AB>(g);
+        RBF_ROW();
+    }
+    combine2(NG - 1);
+}
+
+// Any floor(k*) and partial waves (positions past the end of the frame must fail): pixel by pixel, probes in a loop.
+template <int AB, typename STAGER>
+__device__ __forceinline__ void frame_pass_plain(
+    const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
+    uint32_t rank_lo, uint32_t rank_hi, uint32_t c, uint32_t validmask, uint32_t lds_base_bytes, uint32_t safe_pos, uint32_t m, double ninv,
+    uint32_t fk, uint32_t &pbf, STAGER &st)
+{
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) {
+        if ((it & 1) == 0) st.template at<AB>(it >> 1);
+        uint32_t pos = mod_m_f64(hd1[it], hl1[it], ninv, m);
+        const uint32_t step = mod_m_f64(hd2[it], hl2[it], ninv, m);
+        uint32_t fail = ~(validmask << (31 - it)) & 0x80000000u;
+        for (uint32_t j = 0; j < fk; ++j) {
+            fail = (probe_image_word<0>(lds_base_bytes, pos) << (pos & 31u)) | fail;
+            const uint32_t s2 = pos + step;
+            pos = min(s2, s2 - m);
+        }
+        const uint32_t rk = ((it < 4 ? rank_lo : rank_hi) >> (8 * (it & 3))) & 0xFFu;
+        const uint32_t pc = rk <= c ? pos : safe_pos;
+        fail = (probe_image_word<0>(lds_base_bytes, pc) << (pc & 31u)) | fail;
+        pbf = __builtin_amdgcn_alignbit(pbf, fail, 31);
+    }
+}
+
+// FrameTable as this kernel reads it (host: query_table_s64, rbf_api.hip) -- COMPACTED over the coded frames of the batch:
+//   f[j].m, f[j].M = bits of -1.0 / m        of the j-th coded frame,
+//   f[j].floor_k = floor(k*) | c << 8 | frame index << 16        (c = coded thresholds below the frame's own, rbf_kernels_r64.h),
+//   f[j].T = j-th smallest threshold of the coded frames.
+// `empty_lo / empty_hi`: bit f set = frame f of the batch is not coded (m == 0) and this launch writes its (empty) outputs.
+// Dynamic LDS: two image buffers of ((fwords_max + 3) & ~3) + 4 dwords, then S64_GEO_BYTES.
+// AB bits: 2048 = no wave priorities, 8 = no staging, 16 = no hashing, 32 = no barrier (wrong results), 64 = no output, 256 = frame geometry by scalar loads from
+// the kernel-argument segment in every frame (what k_query_r64 does), 1 / 2 / 4 as in frame_pass_rows.
+template <int AB = 0>
+__global__ __launch_bounds__(QL_THREADS) void k_query_s64(
+    uint64_t n, uint32_t nactive, const FrameTable tab, Seeds seeds,
+    const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t fwords_max,
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words,
+    uint4 *__restrict__ table_out /* nullable: write the pixel-index hash table for the NEXT batch's insert kernel */,
+    uint64_t empty_lo, uint64_t empty_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // two buffers; each ends with 4 dwords that the staging never touches, the first of which stays 0 (SAFE); then the geometry
+    const uint32_t bufwords = ((fwords_max + 3u) & ~3u) + 4u;
+    const uint32_t safe_pos = ((fwords_max + 3u) & ~3u) << 5;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t seg = (uint64_t)blockIdx.x * QL_WAVES + wave;
+    const bool live = seg < nseg;
+    if (threadIdx.x < 8u) lds[(threadIdx.x >> 2) * bufwords + (bufwords - 4u) + (threadIdx.x & 3u)] = 0u;   // visible after the first barrier
+    uint4 *geo = reinterpret_cast<uint4 *>(lds + 2u * bufwords);
+    uint64_t *tl = reinterpret_cast<uint64_t *>(lds + bufwords);  // sorted thresholds: buffer 1 is free until the first pass stages into it
+    // ONE vector load per thread from the kernel-argument segment (host-coherent memory: a round trip over the fabric) -- the only
+    // time the table is read.  Issued here, consumed behind the hashing.
+    FrameDev fd_mine{};
+    if (threadIdx.x < 2u * MAX_BATCH) fd_mine = tab.f[threadIdx.x < nactive ? threadIdx.x : 0u];
+
+    // ---- frame-independent part: the hashes of my 8 consecutive pixel indices as (double, low dword), and the activation ranks
+    static_assert(QL_P == 8, "a lane's verdicts fill one byte; hash3_run8 hashes runs of 8; two rank registers");
+    double hd1[QL_P], hd2[QL_P];
+    uint32_t hl1[QL_P], hl2[QL_P];
+    uint32_t rank_lo = 0, rank_hi = 0;                             // byte it & 3 of (it < 4 ? lo : hi)
+    uint32_t validmask = 0;
+    const uint64_t i0 = seg * QL_SEG_PIXELS + (uint64_t)lane * QL_P;
+    {
+        uint64_t h1[QL_P], h2[QL_P], ha[QL_P];
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
+            if (live && i0 + it < n) validmask |= 1u << it;
+        }
+        if (AB & 16) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) { h1[it] = (i0 + it) * P1; h2[it] = (i0 + it) * P2 + seeds.h2; ha[it] = (i0 + it) * P3; }
+        } else if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) {                  // mixed key lengths in this wave: index by index
+                const bool act = (validmask >> it) & 1u;
+                const Hash3 h = hash3_index((uint32_t)(i0 + it), act, seeds);
+                h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            hd1[it] = (double)h1[it]; hl1[it] = (uint32_t)h1[it];
+            hd2[it] = (double)h2[it]; hl2[it] = (uint32_t)h2[it];
+        }
+        if (table_out && live) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) hash_table_store(table_out, seg, lane, it, h1[it], h2[it], ha[it]);
+        }
+        if (threadIdx.x < 2u * MAX_BATCH) {
+            tl[threadIdx.x] = threadIdx.x < nactive ? fd_mine.T : ~0ull;
+            if (threadIdx.x < nactive) geo[threadIdx.x] = make_uint4(fd_mine.m, fd_mine.floor_k, (uint32_t)fd_mine.M, (uint32_t)(fd_mine.M >> 32));
+        }
+        // ranks = upper_bound of h_act in the sorted thresholds: branch-free binary search over the LDS copy (rbf_kernels_r64.h)
+        __syncthreads();
+        uint32_t top = 1;                                         // largest power of two <= nactive
+        while (2u * top <= nactive) top *= 2u;
+        top = __builtin_amdgcn_readfirstlane(top);
+        uint32_t r[QL_P];
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) r[it] = 0;
+        for (uint32_t step = top; step; step >>= 1) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) {
+                const uint64_t t = tl[r[it] + step - 1u];
+                r[it] |= t <= ha[it] ? step : 0u;
+            }
+        }
+        rank_lo = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        rank_hi = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+    }
+    const bool whole_wave = __builtin_amdgcn_readfirstlane((uint32_t)__all(validmask == 0xFFu)) != 0u;   // every lane owns 8 positions inside the frame
+    uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
+
+    // frames that are not coded: nothing passes (only the frames the host names; none in the common case)
+    for (uint32_t half = 0; half < 2; ++half) {
+        uint64_t bits = half ? empty_hi : empty_lo;
+        while (bits) {
+            const uint32_t g = half * 64u + (uint32_t)__builtin_ctzll(bits);
+            bits &= bits - 1;
+            if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
+            if (live) pass_bytes[((uint64_t)g * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = 0;
+        }
+    }
+    if (nactive == 0) return;
+
+    // Geometry of the j-th coded frame: one broadcast LDS read, moved to SGPRs (AB & 256: the round-2 way, scalar loads from the
+    // kernarg segment).  Two frames are held: the current one and the next one (whose image the stager fetches).
+    struct Geo { uint32_t m, fkc, ninv_lo, ninv_hi; };
+    auto geometry_issue = [&](uint32_t j) -> uint4 { return (AB & 256) ? make_uint4(0, 0, 0, 0) : geo[j]; };
+    auto geometry_take = [&](uint32_t j, const uint4 &v) -> Geo {
+        if (AB & 256) {
+            const FrameDev fd = tab.f[j];
+            return Geo{(uint32_t)__builtin_amdgcn_readfirstlane(fd.m), (uint32_t)__builtin_amdgcn_readfirstlane(fd.floor_k),
+                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)fd.M), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(fd.M >> 32))};
+        }
+        return Geo{(uint32_t)__builtin_amdgcn_readfirstlane(v.x), (uint32_t)__builtin_amdgcn_readfirstlane(v.y),
+                   (uint32_t)__builtin_amdgcn_readfirstlane(v.z), (uint32_t)__builtin_amdgcn_readfirstlane(v.w)};
+    };
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    RowStager2 st;
+    st.a = st.b = make_uint4(0, 0, 0, 0);
+    st.off0 = wave * 1024u + lane * 16u;
+    auto aim = [&](const Geo &g, uint32_t buf) {                  // point the stager at the image row of the frame with geometry g -> buffer buf (all scalar)
+        const uint32_t fw = filter_words(g.m);
+        st.row = reinterpret_cast<const uint8_t *>(image + (uint64_t)(g.fkc >> 16) * image_stride_words32);
+        st.lds_base = lds0 + buf * bufwords * 4u;
+        st.last = ((fw + 3u) & ~3u) * 4u - 16u;
+    };
+    Geo cg = geometry_take(0, geometry_issue(0));
+    // the first frame's image: staged in one go (once per launch)
+    aim(cg, 0u);
+    st.template at<AB>(0); st.template at<AB>(1); st.template at<AB>(2); st.template at<AB>(3);
+    uint32_t cur = 0;
+    const uint32_t safe_v = vgpr_copy(safe_pos);
+    // where my verdict byte / my wave's count of frame f go: base + f * stride
+    uint8_t *const pb_lane = pass_bytes + seg * (QL_SEG_PIXELS / 8) + lane;
+    const uint64_t pb_stride = nseg * (QL_SEG_PIXELS / 8);
+    uint32_t *const cnt_wave = seg_cnt + seg;
+
+    // timeline probe (tools/bench_query3.hip only, AB & 1024): wave 0 and the last wave of the first workgroups stamp the shader clock
+    const bool tl_on = (AB & 1024) && blockIdx.x < TL_WGS && (wave == 0 || wave == QL_WAVES - 1) && g_query_timeline;
+    uint64_t *tlog = (AB & 1024) && g_query_timeline ? g_query_timeline + ((uint64_t)(blockIdx.x % TL_WGS) * 2 + (wave ? 1 : 0)) * MAX_BATCH * TL_PHASES : nullptr;
+    auto stamp = [&](uint32_t slot, uint32_t phase) {
+        if ((AB & 1024) && tl_on && lane == 0) tlog[slot * TL_PHASES + phase] = __builtin_readcyclecounter();
+    };
+
+    // The outputs of a frame -- its verdict byte and the wave's pass count (popc of the byte per lane, 0..8, then one ballot per bit
+    // of that count: 4 compares per frame instead of one per pixel) -- leave DURING THE NEXT FRAME'S PASS, once its first reads are
+    // in flight: behind the pass they were ~500 cycles of latency (ballots -> scalar adds -> address -> store) that the last wave
+    // of a SIMD ran alone while the other fifteen already stood at the barrier (timeline: profiles/r03_query_timeline.txt).
+    uint32_t out_pb = 0, out_f = 0;                                // verdict byte and frame index waiting to be written
+    bool out_pending = false;
+    auto flush = [&]() {
+        if (!out_pending) return;
+        uint32_t npass = 0;
+        if (!(AB & 4)) {
+            const uint32_t cnt = __popc(out_pb);
+            npass = __popcll(__ballot((cnt & 1u) != 0)) + 2u * __popcll(__ballot((cnt & 2u) != 0)) + 4u * __popcll(__ballot((cnt & 4u) != 0)) + 8u * __popcll(__ballot((cnt & 8u) != 0));
+        }
+        if (!(AB & 64) && live) {
+            pb_lane[(uint64_t)out_f * pb_stride] = (uint8_t)out_pb;
+            if (lane == 0) cnt_wave[(uint64_t)out_f * nseg] = npass;
+        }
+    };
+
+    for (uint32_t j = 0; j < nactive; ++j) {
+        // ---- in front of the barrier: whatever of frame j needs no filter image -- the next frame's geometry, the first pair's reductions
+        stamp(j, 0);
+        const uint32_t jn = j + 1 < nactive ? j + 1 : j;          // no next frame: this one is restaged into the buffer nobody reads any more
+        const uint4 ngv = geometry_issue(jn);                      // (the LDS read flies under the reductions)
+        const uint32_t m_v = vgpr_copy(cg.m);
+        const double ninv = __builtin_bit_cast(double, ((uint64_t)cg.ninv_hi << 32) | cg.ninv_lo);
+        const uint32_t fk = cg.fkc & 0xFFu, f = cg.fkc >> 16;
+        const uint32_t c_v = vgpr_copy((cg.fkc >> 8) & 0xFFu);
+        const bool rows = whole_wave && fk >= 1u && fk <= 4u;     // else: other floor(k*), or the frame's last segments (positions past the end)
+        uint32_t x[4] = {0, 0, 0, 0};
+        if (rows) rows_reduce4<AB>(0, hd1, hl1, hd2, hl2, m_v, ninv, x);
+        const Geo ng = geometry_take(jn, ngv);
+        stamp(j, 1);
+        if (!(AB & 32)) __syncthreads();          // everyone's writes of buffer cur have landed; nobody probes buffer cur^1 any more
+        stamp(j, 2);
+        aim(ng, cur ^ 1u);
+        const uint32_t fbase = vgpr_copy(lds0 + cur * bufwords * 4u);
+        uint32_t pbf = 0;
+        if (rows) {
+            switch (fk) {
+            case 1: frame_pass_rows<1, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush); break;
+            case 2: frame_pass_rows<2, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush); break;
+            case 3: frame_pass_rows<3, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush); break;
+            default: frame_pass_rows<4, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush); break;
+            }
+        } else {
+            flush();
+            frame_pass_plain<AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, validmask, fbase, safe_v, m_v, ninv, fk, pbf, st);
+        }
+        stamp(j, 3);
+        out_pb = ~pbf & 0xFFu; out_f = f; out_pending = true;
+        cg = ng;
+        cur ^= 1u;
+        stamp(j, 4);
+        stamp(j, 5);
+    }
+    flush();
+}
+
+#undef RBF_ROW
+
+}  // namespace rbf

@@ -133,6 +133,42 @@ int main()
         printf("%-60s %8.1f us\n", "[f64] full kernel", run<0, true, QL_THREADS, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
         return 0;
     }
+    if (getenv("R3")) {   // round 3: schedule variants of k_query_r64's frame pass (rbf_kernels_r64.h), each checked against k_query_f64
+        FrameTable vt = tab;
+        for (uint32_t f = 0; f < F; ++f) vt.f[f].T = 0x1000000000000000ull * ((f * 7) % 13 + 1) + f % 3;
+        const size_t pwb = (size_t)F * nseg * QL_P * 8, scb = (size_t)F * nseg * 4;
+        std::vector<uint8_t> a(pwb), b(pwb); std::vector<uint32_t> ca(F * nseg), cb(F * nseg);
+        run<0, true, QL_THREADS, 1>(dm, mstride, n, F, vt, sd, df, fstride, fwmax, sb, sc, nseg, lds);
+        CK(hipMemcpy(a.data(), sb, pwb, hipMemcpyDeviceToHost)); CK(hipMemcpy(ca.data(), sc, scb, hipMemcpyDeviceToHost));
+        auto check = [&](const char *name, float t) {
+            CK(hipMemcpy(b.data(), sb, pwb, hipMemcpyDeviceToHost)); CK(hipMemcpy(cb.data(), sc, scb, hipMemcpyDeviceToHost));
+            size_t diff = 0; for (size_t i = 0; i < pwb; ++i) diff += a[i] != b[i];
+            size_t dc = 0; for (size_t i = 0; i < ca.size(); ++i) dc += ca[i] != cb[i];
+            printf("%-58s %8.1f us (varied thresholds)   vs k_query_f64: %zu differing pass bytes, %zu differing segment counts\n", name, t, diff, dc);
+            CK(hipMemset(sb, 0xEE, pwb)); CK(hipMemset(sc, 0xEE, scb));
+        };
+#define R3V(V, name) do { \
+        CK(hipMemset(sb, 0xEE, pwb)); CK(hipMemset(sc, 0xEE, scb)); \
+        check(name, run<(V), true, QL_THREADS, 2>(dm, mstride, n, F, vt, sd, df, fstride, fwmax, sb, sc, nseg, lds)); \
+        const float tf = run<(V), true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds); \
+        const float ts = run<(V) | 8, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds); \
+        const float tp = run<(V) | 8 | 32, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds); \
+        const float tn = run<(V) | 8 | 32 | 4, true, QL_THREADS, 2>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds); \
+        printf("    %-54s full %6.1f | no staging %6.1f | pure passes %6.1f | pure, no ballots %6.1f us\n", name, tf, ts, tp, tn); } while (0)
+        for (int rep = 0; rep < 2; ++rep) {
+        R3V(0, "r64 base (group schedule, 3-slot stager)");
+        R3V(R64_STAGER2, "2-slot stager");
+        R3V(R64_PIXEL_PIPE, "pixel pipeline depth 2");
+        R3V(R64_PIXEL_PIPE | R64_STAGER2, "pixel pipeline depth 2, 2-slot stager");
+        R3V(R64_PIXEL_PIPE | R64_PIPE_DEPTH3 | R64_STAGER2, "pixel pipeline depth 3, 2-slot stager");
+        R3V(R64_LOADS_FIRST | R64_STAGER2, "group schedule, loads first, 2-slot stager");
+        R3V(R64_PLANE_BALLOT, "base + bit-plane ballots");
+        R3V(R64_PIXEL_PIPE | R64_PLANE_BALLOT, "pixel pipeline depth 2 + bit-plane ballots");
+        R3V(R64_PIXEL_PIPE | R64_PIPE_DEPTH3 | R64_STAGER2 | R64_PLANE_BALLOT, "pixel pipeline depth 3, 2-slot + bit-plane ballots");
+        R3V(R64_LOADS_FIRST | R64_STAGER2 | R64_PLANE_BALLOT, "loads first, 2-slot + bit-plane ballots");
+        }
+        return 0;
+    }
 #define RUNP(AB, TH, PARTS, what) printf("%-60s %8.1f us\n", "[fp64 mod] " what, run<AB, true, TH, 1>(dm, mstride, n, F, tab, sd, df, fstride, fwmax, sb, sc, nseg, lds));
     {   // k_query_p4: 4 pixels per lane, two workgroups per CU; same pass bytes (its segments are 256 pixels, so the counts are compared as sums)
         const size_t pwb = (size_t)F * nseg * QL_P * 8;
