@@ -9,8 +9,11 @@ resident inputs total ~750 MB, well past the 256 MiB Infinity Cache: the mask ke
 With N > 1 every rank encodes its own GOPs (independent frames shard; weak scaling) and the step compacts
 its per-frame (filter, witness, stats) rows into one exact-size record on the device and gathers it to
 rank 0 over RCCL inside the step (asynchronously, overlapping the next step's kernels).
-`--clip-frames F --keyframe-interval I` instead runs BASELINE configs[2]/[4] as written: ONE clip of F frames
-sharded by frame over the ranks (strong scaling), see clip_main().
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks ITSELF (one process per GPU, RCCL over
+127.0.0.1); under `python -m torch.distributed.run --nproc-per-node N` it joins the launcher's ranks instead.
+After the weak-scaling headline the same process group runs BASELINE configs[2] and [4] as written -- ONE clip of 300 frames
+(keyframe every 30; 8-bit, then 16-bit) sharded by frame over the ranks (strong scaling, run_clip()) -- and adds them to the
+line as `clip300` / `clip300_uint16` (with and without the gather to rank 0); `--clip-frames F` runs only that mode.
 
 Prints ONE JSON line on rank 0.  After the timed region every pipeline's 29 frames are compared with the
 CPU oracle (`verified_vs_oracle`).  `roofline` prices the dominant kernel (query) at its ALGORITHMIC bytes
@@ -61,7 +64,47 @@ def parse_args():
     ap.add_argument("--exact-steps", action="store_true", help="time exactly --steps steps even if that is shorter than %.0f ms" % (MIN_REGION_S * 1e3))
     ap.add_argument("--clip-frames", type=int, default=0, help="strong-scaling mode: one clip of this many frames sharded by frame over the ranks (BASELINE config 3: 300)")
     ap.add_argument("--keyframe-interval", type=int, default=30, help="clip mode: frame t is a keyframe iff t %% interval == 0")
+    ap.add_argument("--spawn", action="store_true", help="start the rank processes through bench.py's own launcher even for --gpus 1 (smoke-tests the N>1 launch path)")
+    ap.add_argument("--no-clips", action="store_true", help="skip the clip300 / clip300_uint16 legs (BASELINE configs 3 and 5) behind the weak-scaling headline")
+    ap.add_argument("--clip-leg-frames", type=int, default=300, help="frames of the clip legs of the default run")
+    ap.add_argument("--clip-steps", type=int, default=10, help="timed passes over the clip in the clip legs")
     return ap.parse_args()
+
+
+def launch_ranks(nranks, cmd, stdout0=None):
+    """Start `cmd` once per rank (one process per GPU: RANK = LOCAL_RANK = r, WORLD_SIZE = nranks, rendezvous on a free port of
+    127.0.0.1) and wait.  Rank 0 inherits stdout (or gets `stdout0`), so its ONE JSON line is the launcher's output; the other
+    ranks' stdout (RCCL banners) goes to stderr.  A rank that dies takes the others down (exact PIDs) and its exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                    # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RBF_BENCH_LAUNCHER="self-spawned")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=stdout0 if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:                    # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher environment: this script again, once per GPU."""
+    sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
 
 def init_dist(args):
@@ -72,10 +115,10 @@ def init_dist(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: only %d GPU(s) visible" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -87,13 +130,19 @@ def init_dist(args):
         # GOP pipelines' streams exist.  Measured (tools/dist_overhead.py): streams created between an
         # eager communicator init and its first collective end up serialised with each other
         # (260 instead of 222 us/step); created after it, or before a lazy init, they overlap.
-        dist.barrier()
+        # ... and that collective counts the ranks RCCL really connected (reported as `rccl_ranks`)
+        ones = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(ones)
         torch.cuda.synchronize(device)
+        if int(ones.item()) != world:
+            raise SystemExit("RCCL saw %d ranks, expected %d" % (int(ones.item()), world))
     return world, rank, local_rank, device, use_dist
 
 
 def main():
     args = parse_args()
+    if (args.gpus > 1 or args.spawn) and "RANK" not in os.environ:
+        return spawn_ranks(args)
     if args.clip_frames:
         return clip_main(args)
     import torch
@@ -280,7 +329,9 @@ def main():
                                  "one pixel-index hash table per (device, frame size, seeds), shared by the pipelines' contexts; built once, before the timed region" if args.streams > 1 else
                                  "built once; rewritten in every step by the query kernel (sole holder: keeps the table in the Infinity Cache for the next insert)",
                    "stages": "residual mask -> host params -> insert -> query+witness",
-                   "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by gloo world-2 tests and an nccl world-1 test"},
+                   "launcher": os.environ.get("RBF_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process"),
+                   "rccl_ranks": world if use_dist else 0,
+                   "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by gloo world-2 tests (incl. the self-spawn launcher) and nccl world-1 tests"},
     }
     if short:
         out["requested_region"] = short           # the exactly---steps region, too short to be the headline
@@ -328,6 +379,17 @@ def main():
             out["verified_vs_oracle"] = verify_all(host_gops, res_all, n, ncoders if not args.shared_gop else 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, n, args.cpu_frames)
+    # ---- BASELINE configs[2] and [4] in the same process group: one 300-frame clip sharded by frame (strong scaling), 8- and 16-bit
+    if og is not None:
+        og.close()
+    if not args.no_clips:
+        del coders, coder, arenas, ctxs, ctx, og, slots, probe
+        torch.cuda.empty_cache()
+        env = (world, rank, local_rank, device, use_dist)
+        c8 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 8, args.clip_steps, 2)
+        c16 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 16, args.clip_steps, 2)
+        if rank == 0:
+            out["clip300"], out["clip300_uint16"] = c8, c16
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -500,23 +562,24 @@ def clip_pieces(start, stop, interval):
     return pieces
 
 
-def clip_main(args):
-    """One clip of --clip-frames frames, keyframe every --keyframe-interval: the inter-frames shard over the ranks by
-    CONTIGUOUS FRAME RANGE with one halo frame (dist.shard_range / halo_start), every rank codes its runs with
-    rbf_encode_gop, packs each run's record on the device and the records travel to rank 0 in one exact-size
-    gather per step (lengths first, then payloads; rank 0's own records stay out of the collective).
-    A step = the whole clip once.  Strong scaling: total work is fixed as N grows."""
+def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
+    """One clip of T frames (W x H YUV444, `bits` per sample), keyframe every I: the inter-frames shard over the ranks by
+    CONTIGUOUS FRAME RANGE with one halo frame (dist.shard_range / halo_start), every rank codes its runs with rbf_encode_gop and
+    packs each run's record on the device; with N > 1 the records travel to rank 0 in one exact-size gather per pass (sizes
+    all-gathered together with an error flag, then one point-to-point message per peer; rank 0's own records stay out of the
+    collective).  A pass = the whole clip once; timed with and (N > 1) without the gather.  Strong scaling: total work is fixed
+    as N grows.  Returns the result dict on rank 0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
-    world, rank, local_rank, device, use_dist = init_dist(args)
+    world, rank, local_rank, device, use_dist = env
     from new_bloom_filter_repo_amd import _native as nat
     from new_bloom_filter_repo_amd.dist import shard_range, halo_start, gather_device_records, unpack_device_record
     from new_bloom_filter_repo_amd.gop import GopCoder, torch_allocator
     from new_bloom_filter_repo_amd.synthetic import make_clip_shard, P_KSTAR_2_3
 
-    W, H, T, I = args.width, args.height, args.clip_frames, args.keyframe_interval
+    W, H = args.width, args.height
     n = W * H
-    dtype = np.uint8 if args.bits == 8 else np.uint16
+    dtype = np.uint8 if bits == 8 else np.uint16
     start, stop = shard_range(T, world, rank)
     first = halo_start(start, I)
     density = args.density or P_KSTAR_2_3
@@ -524,11 +587,15 @@ def clip_main(args):
     pieces = clip_pieces(start, stop, I)
     total_pairs = sum(max(0, min(T, (g + 1) * I) - g * I - 1) for g in range((T + I - 1) // I))
     my_pairs = sum(c - 1 for _, c in pieces)
+    max_pieces = max(len(clip_pieces(*shard_range(T, world, r), I)) for r in range(world))     # every rank can compute every rank's count
 
     nstreams = max(1, min(args.streams, len(pieces) or 1))
     streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
     ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
-    frame_bytes = n * 3 * (args.bits // 8)
+    if args.force_bits:
+        for c in ctxs:
+            c.force_generic(args.force_bits)
+    frame_bytes = n * 3 * (bits // 8)
     frames_t = torch.from_numpy(shard.reshape(-1).view(np.uint8)).to(device)       # the shard (+ halo), resident in HBM
 
     class View:                                   # a run's frames inside the shard buffer
@@ -536,21 +603,21 @@ def clip_main(args):
             self.ptr, self.nbytes = frames_t.data_ptr() + off, nbytes
     coders, records = [], []
     for i, (f0, cnt) in enumerate(pieces):
-        c = GopCoder(ctxs[i % nstreams], W, H, cnt, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
+        c = GopCoder(ctxs[i % nstreams], W, H, cnt, channels=3, sample_bytes=bits // 8, allocator=torch_allocator(device),
                      frames_block=View((f0 - first) * frame_bytes, cnt * frame_bytes))
         coders.append(c)
         records.append(c._out_alloc(int(nat.lib().rbf_record_max_bytes(cnt - 1, n))))
-    use_gather = use_dist and not args.no_gather
+    can_gather = use_dist and not args.no_gather
 
-    def step():
+    def step(gather):
         for i, c in enumerate(coders):
             with torch.cuda.stream(streams[i % nstreams]):
                 c.encode()
                 c.pack(records[i])
-        if use_gather:
+        if gather:
             for s in streams:
                 torch.cuda.current_stream(device).wait_stream(s)
-            return gather_device_records([r.tensor for r in records], device)
+            return gather_device_records([r.tensor for r in records], device, max_records=max_pieces)
         return None
 
     def barrier():
@@ -558,22 +625,28 @@ def clip_main(args):
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(max(1, args.warmup)):
-        got = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        got = step()
-    torch.cuda.synchronize(device)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    def timed(gather):
+        got = None
+        for _ in range(max(1, warmup)):
+            got = step(gather)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            got = step(gather)
+        torch.cuda.synchronize(device)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+        return elapsed, got
+
+    elapsed_plain, _ = timed(False)
+    elapsed_gather, got = timed(True) if can_gather else (None, None)
 
     verified = None
-    if not args.no_verify:
+    if verify and not args.no_verify:
         # every rank checks ITS frames against the CPU oracle from the host frames; rank 0 also parses what it received
         host = [[shard[f0 - first + j] for j in range(cnt)] for f0, cnt in pieces]
         res_all = [c.results() for c in coders]
@@ -582,26 +655,53 @@ def clip_main(args):
         if use_dist:
             dist.all_reduce(cnt_t)
         verified = {"frames": int(cnt_t.item()), "of": total_pairs, "fields": "mask, k, l, filter, witness"}
+        if verified["frames"] != total_pairs:
+            raise SystemExit("clip: %d of %d inter-frames verified" % (verified["frames"], total_pairs))
         if rank == 0 and got is not None:
             parsed = sum(len(unpack_device_record(b, n)) for b in got)
             verified["records_parsed_on_rank0"] = parsed
+            verified["bytes_gathered_on_rank0"] = int(sum(b.numel() for b in got))
             if parsed != total_pairs:
                 raise SystemExit("rank 0 received %d frame records, expected %d" % (parsed, total_pairs))
+    out = None
     if rank == 0:
-        value = total_pairs * n * args.steps / elapsed / 1e6
-        out = {"metric": "Mpixels/s Bloom insert+query, 1080p residuals", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-               "config": {"workload": "%dx%d YUV444 %d-bit synthetic clip of %d frames, keyframe every %d (%d inter-frames/step over %d GPU%s), k*=2.3, threshold 0"
-                                      % (W, H, args.bits, T, I, total_pairs, world, "s" if world > 1 else ""),
-                          "sharding": "contiguous frame ranges + 1 halo frame (dist.shard_range)", "inter_frames_rank0": my_pairs,
-                          "gather_to_rank0": bool(use_gather), "gather": "exact-size: all_gather of lengths, then grouped send/recv of payloads; rank 0's own records are not sent",
-                          "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only)"},
+        e = elapsed_gather if elapsed_gather is not None else elapsed_plain
+        out = {"value": round(total_pairs * n * steps / e / 1e6, 2), "unit": "Mpixel/s", "ms_per_pass": round(e / steps * 1e3, 4),
+               "gather_to_rank0": elapsed_gather is not None,
+               "without_gather": {"value": round(total_pairs * n * steps / elapsed_plain / 1e6, 2), "ms_per_pass": round(elapsed_plain / steps * 1e3, 4)},
+               "passes": steps, "scaling": "strong", "n_gpus": world,
+               "workload": "%dx%d YUV444 %d-bit synthetic clip of %d frames, keyframe every %d (%d inter-frames/pass over %d GPU%s), k*=2.3, threshold 0"
+                           % (W, H, bits, T, I, total_pairs, world, "s" if world > 1 else ""),
+               "sharding": "contiguous frame ranges + 1 halo frame (dist.shard_range)", "inter_frames_rank0": my_pairs,
                "verified_vs_oracle": verified}
+    # release the clip before the next leg
+    for c in coders:
+        c.close()
+    for c in ctxs:
+        c.close()
+    del coders, records, frames_t, ctxs
+    torch.cuda.empty_cache()
+    return out
+
+
+def clip_main(args):
+    """`--clip-frames F`: only the strong-scaling clip mode (BASELINE configs[2]; `--bits 16` = configs[4]), its own JSON line."""
+    import torch.distributed as dist
+    env = init_dist(args)
+    world, rank, use_dist = env[0], env[1], env[4]
+    r = run_clip(args, env, args.clip_frames, args.keyframe_interval, args.bits, args.steps, args.warmup)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out = {"metric": "Mpixels/s Bloom insert+query, 1080p residuals", "value": r["value"], "unit": "Mpixel/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_pass"], "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": r["workload"], "sharding": r["sharding"], "inter_frames_rank0": r["inter_frames_rank0"],
+                          "gather_to_rank0": r["gather_to_rank0"], "without_gather": r["without_gather"],
+                          "gather": "exact-size: all_gather of lengths + error flag, then grouped send/recv of payloads; rank 0's own records are not sent",
+                          "launcher": os.environ.get("RBF_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process"), "rccl_ranks": world if use_dist else 0},
+               "verified_vs_oracle": r["verified_vs_oracle"]}
         print(json.dumps(out), flush=True)
 
 

@@ -93,8 +93,10 @@ class OutboxGather:
     bytes of its slots as ONE point-to-point message while `dst` posts one receive per peer (batch_isend_irecv =
     ncclGroupStart/End on RCCL; over xGMI every peer has its own link into `dst`).  Nothing is padded to a common
     size, so a record cannot overflow a slot, and the records of `dst` itself never enter a collective.  Two
-    outboxes alternate so that packing never waits for a transfer; on CPU (gloo, tests) the same bookkeeping runs
-    without streams.
+    outboxes alternate so that packing never waits for a transfer; the exchange itself (two small host reads: the
+    used sizes, then everybody's sizes) runs on a helper thread, so the launching thread is never blocked by it; a
+    damaged record raises on EVERY rank, after the size collective.  On CPU (gloo, tests) the same bookkeeping runs
+    without streams (and, by default, without the thread).
 
         slot = og.begin(k)      # on pipeline k's stream: where this step's record goes (int64 tensor)
         ... enqueue the writes into `slot` on pipeline k's stream ...
@@ -103,7 +105,7 @@ class OutboxGather:
         og.received(ob, rank)   # on dst: the records last received from `rank` in outbox `ob` (list of uint8 tensors)
     """
 
-    def __init__(self, slot_words, steps_per_gather, device, streams=None, group=None, dst=0):
+    def __init__(self, slot_words, steps_per_gather, device, streams=None, group=None, dst=0, threaded=None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist, self.group, self.dst = torch, dist, group, dst
@@ -122,12 +124,60 @@ class OutboxGather:
         self.bytes_sent = 0
         self.streams = list(streams) if streams else []
         self.comm = torch.cuda.Stream(device) if self.cuda else None
-        self.events = [torch.cuda.Event() for _ in self.streams] if self.cuda else []
+        # The exchange reads the used sizes on the host (device -> host copy, then the all-gathered sizes): two blocking reads.
+        # They run on a HELPER THREAD, so the thread that launches the pipelines' kernels never waits for a transfer it does not
+        # need (round 2 did both reads inline: a pipeline drain every `steps_per_gather` steps).  The helper executes the
+        # exchanges strictly in submission order -- every rank submits the same sequence, so the collectives match up.
+        self.threaded = bool(self.cuda if threaded is None else threaded)
+        self.error = None
+        self._posted = [None, None]     # per outbox: threading.Event set once its exchange has been posted (or failed)
+        self._jobs = None
+        if self.threaded:
+            import queue
+            import threading
+            self._jobs = queue.Queue()
+            self._worker = threading.Thread(target=self._run, name="rbf-outbox-gather", daemon=True)
+            self._worker.start()
 
     def _where(self):
         return self.s % self.G, (self.s // self.G) % 2
 
+    def _peer(self, r):
+        """Global rank of group rank r (P2POp wants global ranks)."""
+        return r if self.group is None else self._dist.get_global_rank(self.group, r)
+
+    def _run(self):
+        if self.cuda:
+            self._torch.cuda.set_device(self.device)          # the current device is per thread
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            ob, count, ready, posted = job
+            try:
+                if self.error is None:
+                    self._post(ob, count, ready)
+            except BaseException as e:                          # surfaced by the next begin() / flush() of the owning thread
+                self.error = e
+            finally:
+                posted.set()
+
+    def _settle(self, ob):
+        """Wait (host) until outbox ob's last exchange has been posted; re-raise what the helper thread caught."""
+        ev = self._posted[ob]
+        if ev is not None:
+            ev.wait()
+        if self.error is not None:
+            raise self.error
+
+    def close(self):
+        if self._jobs is not None:
+            self._jobs.put(None)
+            self._worker.join()
+            self._jobs = None
+
     def _wait(self, ob):
+        self._settle(ob)
         if self.pend[ob] is not None:
             works, _keep, ev = self.pend[ob]
             for w in works:
@@ -148,6 +198,7 @@ class OutboxGather:
         return self.out[ob][j]
 
     def _wait_stream(self, ob, stream):
+        self._settle(ob)
         if self.pend[ob] is not None:
             works, _keep, ev = self.pend[ob]
             for w in works:
@@ -156,8 +207,6 @@ class OutboxGather:
                 stream.wait_event(ev)
 
     def end(self, k=0):
-        if self.cuda and self.streams:
-            self.events[k].record(self.streams[k])
         j, ob = self._where()
         self.s += 1
         self.filled[ob] = j + 1
@@ -166,36 +215,44 @@ class OutboxGather:
 
     def _exchange(self, ob, count):
         torch, dist = self._torch, self._dist
-        heads = self.out[ob][:count, :4].cpu().numpy().view(np.uint64)          # (the only host synchronisation: this stream)
-        used = []
+        heads = self.out[ob][:count, :4].cpu().numpy().view(np.uint64)          # blocks this (helper) thread only
+        used, damaged = [], 0
         for h in heads:
             if int(h[0]) != RECORD_MAGIC or int(h[3]) != 0 or int(h[2]) > self.slot_words * 8:
-                raise ValueError("a packed record in the outbox is damaged: %s" % h.tolist())
-            used.append((int(h[2]) + 7) // 8 * 8)
-        mine = torch.zeros(self.G, dtype=torch.int64, device=self.device)
+                damaged = 1
+                used.append(0)
+            else:
+                used.append((int(h[2]) + 7) // 8 * 8)
+        # sizes + an error flag travel together: a rank with a damaged record must not leave the others hanging in the collective
+        mine = torch.zeros(self.G + 1, dtype=torch.int64, device=self.device)
         mine[:count] = torch.tensor(used, dtype=torch.int64, device=self.device)
-        sizes = [torch.zeros(self.G, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+        mine[self.G] = damaged
+        sizes = [torch.zeros(self.G + 1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
         dist.all_gather(sizes, mine, group=self.group)
         sizes = [[int(x) for x in t.cpu().tolist()] for t in sizes]
+        bad = [r for r in range(self.world) if sizes[r][self.G]]
+        if bad:
+            raise ValueError("a packed record in the outbox of rank(s) %s is damaged" % bad)      # on EVERY rank, after the collective
+        sizes = [t[:self.G] for t in sizes]
         ops, keep = [], []
         if self.rank == self.dst:
             self.sizes[ob] = sizes
             for r in range(self.world):
                 if r != self.dst and sum(sizes[r]):
-                    ops.append(dist.P2POp(dist.irecv, self.inbox[ob][r][:sum(sizes[r])], r, self.group))
+                    ops.append(dist.P2POp(dist.irecv, self.inbox[ob][r][:sum(sizes[r])], self._peer(r), self.group))
         elif sum(used):
             payload = torch.cat([self.out[ob][j, :u // 8].view(torch.uint8) for j, u in enumerate(used)])
             keep.append(payload)
-            ops.append(dist.P2POp(dist.isend, payload, self.dst, self.group))
+            ops.append(dist.P2POp(dist.isend, payload, self._peer(self.dst), self.group))
             self.bytes_sent += int(payload.numel())
         works = dist.batch_isend_irecv(ops) if ops else []
         return works, keep
 
-    def _send(self, ob):
-        count = self.filled[ob]
+    def _post(self, ob, count, ready):
+        """Exchange `count` slots of outbox ob: on the comm stream behind `ready` (the writers' events).  Helper thread (or inline)."""
         if self.cuda:
             with self._torch.cuda.stream(self.comm):
-                for ev in self.events:
+                for ev in ready:
                     self.comm.wait_event(ev)
                 works, keep = self._exchange(ob, count)
                 ev = self._torch.cuda.Event()
@@ -204,6 +261,25 @@ class OutboxGather:
         else:
             works, keep = self._exchange(ob, count)
             self.pend[ob] = (works, keep, None)
+
+    def _send(self, ob):
+        count = self.filled[ob]
+        # the writers' events are re-recorded by later steps: hand the exchange its own snapshot
+        ready = []
+        if self.cuda:
+            for k, _ in enumerate(self.streams):
+                ev = self._torch.cuda.Event()
+                ev.record(self.streams[k])
+                ready.append(ev)
+        if self.threaded:
+            import threading
+            posted = threading.Event()
+            self.pend[ob] = None
+            self._posted[ob] = posted
+            self._jobs.put((ob, count, ready, posted))
+        else:
+            self._posted[ob] = None
+            self._post(ob, count, ready)
         self.sent += 1
 
     def flush(self):
@@ -215,6 +291,8 @@ class OutboxGather:
             self._wait(ob)
         if self.cuda:
             self.comm.synchronize()
+        if self.error is not None:
+            raise self.error
 
     def received(self, ob, rank):
         """On dst: the records of the last exchange of outbox `ob` that came from `rank`, as a list of uint8 tensors of
@@ -257,7 +335,7 @@ def gather_records(records, dst=0, group=None, device=None):
     return merged
 
 
-def gather_device_records(records, device, dst=0, group=None):
+def gather_device_records(records, device, dst=0, group=None, max_records=None):
     """Exact-size gather of device-packed records (GopCoder.pack) to `dst`, RCCL has no gatherv:
     every rank reads the used size of its records from their headers (one small D2H), the sizes are
     all-gathered, then every rank but `dst` sends the used bytes of its records as ONE message and `dst`
@@ -271,32 +349,41 @@ def gather_device_records(records, device, dst=0, group=None):
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    damaged = 0
     if records:
         heads = torch.stack([r[:4] for r in records]).cpu().numpy().view(np.uint64)
-        if any(int(h[0]) != RECORD_MAGIC or int(h[3]) != 0 for h in heads):
-            raise ValueError("a record to gather is damaged or truncated")
-        used = [(int(h[2]) + 7) // 8 * 8 for h in heads]
+        damaged = int(any(int(h[0]) != RECORD_MAGIC or int(h[3]) != 0 for h in heads))
+        used = [0 if damaged else (int(h[2]) + 7) // 8 * 8 for h in heads]
     else:
         used = []
-    maxrec = torch.tensor([len(used)], dtype=torch.int64, device=device)
-    dist.all_reduce(maxrec, op=dist.ReduceOp.MAX, group=group)
-    maxrec = int(maxrec.item())
-    mine = torch.zeros(maxrec, dtype=torch.int64, device=device)
+    if max_records is None:                                        # callers that know the largest record count of any rank skip this round
+        maxrec = torch.tensor([len(used)], dtype=torch.int64, device=device)
+        dist.all_reduce(maxrec, op=dist.ReduceOp.MAX, group=group)
+        max_records = int(maxrec.item())
+    if len(used) > max_records:
+        raise ValueError("%d records, but max_records = %d" % (len(used), max_records))
+    mine = torch.zeros(max_records + 1, dtype=torch.int64, device=device)
     if used:
         mine[:len(used)] = torch.tensor(used, dtype=torch.int64, device=device)
-    sizes = [torch.zeros(maxrec, dtype=torch.int64, device=device) for _ in range(world)]
+    mine[max_records] = damaged                                   # sizes + error flag in ONE collective: nobody is left hanging
+    sizes = [torch.zeros(max_records + 1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(sizes, mine, group=group)
-    sizes = [[int(x) for x in s.cpu().tolist() if int(x)] for s in sizes]
+    sizes = [[int(x) for x in s.cpu().tolist()] for s in sizes]
+    bad = [r for r in range(world) if sizes[r][max_records]]
+    if bad:
+        raise ValueError("a record to gather is damaged or truncated on rank(s) %s" % bad)
+    sizes = [[x for x in s[:max_records] if x] for s in sizes]
     own = [r[:u // 8].view(torch.uint8) for r, u in zip(records, used)]
     ops, inbox = [], {}
     if rank == dst:
         for r in range(world):
             if r != dst and sum(sizes[r]):
                 inbox[r] = torch.empty(sum(sizes[r]), dtype=torch.uint8, device=device)
-                ops.append(dist.P2POp(dist.irecv, inbox[r], r, group))
+                ops.append(dist.P2POp(dist.irecv, inbox[r], peer(r), group))
     elif used:
         payload = torch.cat(own)
-        ops.append(dist.P2POp(dist.isend, payload, dst, group))
+        ops.append(dist.P2POp(dist.isend, payload, peer(dst), group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()

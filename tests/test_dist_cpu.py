@@ -235,3 +235,68 @@ def test_clip_pieces_cover_every_inter_frame():
                     assert all((t % I) != 0 for t in range(f0 + 1, f0 + cnt))
                     coded += list(range(f0 + 1, f0 + cnt))
             assert coded == [t for t in range(T) if t % I], (T, I, world)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's own launcher (`python bench.py --gpus N` without torch.distributed.run): the rank processes it starts
+# must find each other.  The workers here are gloo stand-ins for bench.py's ranks (no GPU in this tier).
+# ---------------------------------------------------------------------------------------------------------------
+SPAWN_WORKER = r'''
+import json, os, sys, time
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+assert os.environ["RBF_BENCH_LAUNCHER"] == "self-spawned"
+mode = sys.argv[1]
+if mode == "fail" and rank == 1:
+    sys.exit(3)
+if mode == "fail":
+    time.sleep(120)                                # would hang in a collective: the launcher has to take it down
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ones = torch.ones(1, dtype=torch.int64)
+dist.all_reduce(ones)
+print("banner of rank %d" % rank, flush=True)      # only rank 0's stdout is the launcher's stdout
+if rank == 0:
+    print(json.dumps({"ranks_seen": int(ones.item()), "n_gpus": world}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_tests", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launcher_starts_the_ranks_and_keeps_one_stdout(tmp_path):
+    import json
+    import time
+    bench = _load_bench()
+    worker = tmp_path / "worker.py"
+    worker.write_text(SPAWN_WORKER)
+    out_path = tmp_path / "rank0.out"
+    with open(out_path, "w") as f:
+        rc = bench.launch_ranks(2, [sys.executable, str(worker), "ok"], stdout0=f)
+    assert rc == 0
+    lines = out_path.read_text().splitlines()
+    assert "banner of rank 0" in lines and all("banner of rank 1" not in ln for ln in lines)     # (gloo prints its own lines too)
+    assert json.loads(lines[-1]) == {"ranks_seen": 2, "n_gpus": 2}
+    # a rank that dies takes the others down and its exit code becomes the launcher's
+    t0 = time.time()
+    with open(out_path, "w") as f:
+        rc = bench.launch_ranks(2, [sys.executable, str(worker), "fail"], stdout0=f)
+    assert rc == 3 and time.time() - t0 < 60
+
+
+def test_bench_gpus_without_launcher_goes_through_the_spawner(monkeypatch):
+    """main() with --gpus 2 and no RANK in the environment must call the launcher with this script's own command line."""
+    bench = _load_bench()
+    seen = {}
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.setattr(bench, "launch_ranks", lambda n, cmd, stdout0=None: seen.update(n=n, cmd=cmd) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen["n"] == 2 and seen["cmd"][1].endswith("bench.py") and seen["cmd"][2:] == ["--gpus", "2", "--steps", "3"]

@@ -97,9 +97,23 @@ def test_rccl_world1_gathers_records_the_gpu_packed():
 def test_bench_force_dist_weak_mode():
     os.environ["MASTER_PORT"] = str(38000 + os.getpid() % 2000)
     res = run([sys.executable, "bench.py", "--force-dist", "--steps", "12", "--warmup", "2", "--width", "640", "--height", "360", "--frames", "8",
-               "--gather-every", "4", "--no-cpu-baseline", "--exact-steps"], timeout=900)
+               "--gather-every", "4", "--no-cpu-baseline", "--exact-steps", "--clip-leg-frames", "40", "--keyframe-interval", "10", "--clip-steps", "2"], timeout=900)
     assert res["config"]["gather_to_rank0"] and res["verified_vs_oracle"]["frames"] == 7 * 4 and res["value"] > 0
-    assert res["config"]["gathered_records_parsed_on_rank0"] >= 4
+    assert res["config"]["gathered_records_parsed_on_rank0"] >= 4 and res["config"]["rccl_ranks"] == 1
+    # the clip legs ride in the same line (BASELINE configs 3 and 5), with and without the gather
+    for key in ("clip300", "clip300_uint16"):
+        leg = res[key]
+        assert leg["scaling"] == "strong" and leg["gather_to_rank0"] and leg["value"] > 0 and leg["without_gather"]["value"] > 0
+        assert leg["verified_vs_oracle"]["frames"] == 36 == leg["verified_vs_oracle"]["of"] == leg["verified_vs_oracle"]["records_parsed_on_rank0"]
+        assert leg["verified_vs_oracle"]["bytes_gathered_on_rank0"] > 0
+
+
+def test_bench_own_launcher_world1():
+    """`python bench.py --gpus N` starts its ranks itself: the same launch path at N = 1 (--spawn), RCCL initialised in the child."""
+    res = run([sys.executable, "bench.py", "--spawn", "--force-dist", "--steps", "8", "--warmup", "2", "--width", "640", "--height", "360", "--frames", "6",
+               "--gather-every", "4", "--no-cpu-baseline", "--exact-steps", "--no-clips"], timeout=900)
+    assert res["config"]["launcher"] == "self-spawned" and res["config"]["rccl_ranks"] == 1 and res["n_gpus"] == 1
+    assert res["verified_vs_oracle"]["frames"] == 5 * 4
 
 
 def test_bench_clip_mode_strong_scaling_world1():
@@ -111,3 +125,15 @@ def test_bench_clip_mode_strong_scaling_world1():
     res = run([sys.executable, "bench.py", "--clip-frames", "21", "--keyframe-interval", "10", "--steps", "2", "--warmup", "1",
                "--width", "640", "--height", "360", "--bits", "16"], timeout=900)
     assert res["verified_vs_oracle"]["frames"] == 18
+
+
+def test_bench_config3_at_size_world1():
+    """BASELINE config 3 at its stated size (1920x1080, 300 frames, keyframe every 30) through RCCL at world 1: all 290 inter-frames
+    against the oracle, 290 records parsed on rank 0; config 5's single-GPU half (16-bit) at 60 frames."""
+    os.environ["MASTER_PORT"] = str(42000 + os.getpid() % 2000)
+    res = run([sys.executable, "bench.py", "--force-dist", "--clip-frames", "300", "--keyframe-interval", "30", "--steps", "3", "--warmup", "1"], timeout=900)
+    v = res["verified_vs_oracle"]
+    assert v["frames"] == 290 == v["of"] == v["records_parsed_on_rank0"] and res["config"]["gather_to_rank0"]
+    res = run([sys.executable, "bench.py", "--force-dist", "--clip-frames", "60", "--keyframe-interval", "30", "--steps", "3", "--warmup", "1", "--bits", "16"], timeout=900)
+    v = res["verified_vs_oracle"]
+    assert v["frames"] == 58 == v["of"] == v["records_parsed_on_rank0"]
