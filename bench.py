@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--bits", type=int, default=8, choices=(8, 16))
     ap.add_argument("--density", type=float, default=0.0, help="fraction of changed pixels per inter-frame (0 = 0.08889, i.e. k*=2.3; SURVEY 8d density sweep)")
     ap.add_argument("--streams", type=int, default=4, help="GOP pipelines in flight per GPU (each its own HIP stream, context and GOP)")
+    ap.add_argument("--interleaved", action="store_true", help="keep the GOPs as interleaved YUV444 frames (round 1/2 layout: the mask kernel reads 3x its algorithmic bytes) instead of dense Y planes")
+    ap.add_argument("--gops-per-pipeline", type=int, default=0, help="resident GOPs a pipeline rotates over (0 = auto: 3 with planar Y, 1 interleaved -- ~750 MB of resident input either way)")
     ap.add_argument("--shared-gop", action="store_true", help="diagnostic: all pipelines read the SAME resident GOP (the round-1 setup; inputs then fit the Infinity Cache)")
     ap.add_argument("--lds-tile-kib", type=int, default=0, help="cap the LDS filter tile (KiB) -> tiled kernels; 0 = auto (BASELINE config 4 sweep)")
     ap.add_argument("--gather-every", type=int, default=16, help="N>1: steps whose records travel in one RCCL gather")
@@ -170,21 +172,28 @@ def main():
             c.force_generic(((args.lds_tile_kib * 1024 // 256) << 16) | (1 if args.generic_kernels else 0) | (16 if args.rebuild_hash_table else 0) | args.force_bits)      # tile unit: 64 dwords
     ctx = ctxs[0]
     arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
+    planar = not args.interleaved
+    if args.shared_gop and planar:
+        raise SystemExit("--shared-gop is a diagnostic of the interleaved layout: add --interleaved")
+    G_res = args.gops_per_pipeline or (3 if planar else 1)      # resident GOPs per pipeline: the inputs stay ~750 MB, well past the Infinity Cache
     coders = []
     for k in range(ncoders):
         coders.append(GopCoder(ctxs[k], W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
-                               out_allocator=arenas[k], frames_block=coders[0].frames if (k and args.shared_gop) else None))
+                               out_allocator=arenas[k], frames_block=coders[0].frames if (k and args.shared_gop) else None,
+                               planar_luma=planar, keep_interleaved=not planar, resident_gops=G_res))
     coder = coders[0]
     density = args.density or P_KSTAR_2_3
-    host_gops = []
+    host_gops = []                                # [pipeline][resident gop] -> (F, H, W, 3) host frames
     for k in range(ncoders):
         if k and args.shared_gop:
             host_gops.append(host_gops[0])
             continue
-        host_gops.append(np.stack(make_gop(1000 * 2 + 64 * rank + k, W, H, F, p=density, dtype=dtype)))
-        coders[k].load_frames(host_gops[k])
+        host_gops.append([np.stack(make_gop(1000 * 2 + 64 * rank + k + 16 * g, W, H, F, p=density, dtype=dtype)) for g in range(G_res)])
+        for g in range(G_res):
+            coders[k].load_frames(host_gops[k][g], g)
     torch.cuda.synchronize(device)
-    resident_mb = sum(g.nbytes for g in (host_gops[:1] if args.shared_gop else host_gops)) / 1e6
+    per_gop_bytes = host_gops[0][0].nbytes // (3 if planar else 1)
+    resident_mb = per_gop_bytes * G_res * (1 if args.shared_gop else ncoders) / 1e6
 
     gather = use_gather
     # N > 1: every step compacts its output rows into an exact-size record on the device
@@ -207,13 +216,14 @@ def main():
 
     def step():
         k = state["s"] % ncoders
+        g = (state["s"] // ncoders) % G_res       # a pipeline rotates over its resident GOPs
         state["s"] += 1
         with torch.cuda.stream(streams[k]):
             if not gather:
-                coders[k].encode()
+                coders[k].encode(g)
                 return
             t = og.begin(k)                       # this step's slot (waits stream-side for the outbox's previous transfer)
-            coders[k].encode()
+            coders[k].encode(g)
             coders[k].pack(slots.setdefault(t.data_ptr(), Slot(t)))
             og.end(k)                             # full outbox -> one asynchronous gather from the comm stream
 
@@ -296,18 +306,25 @@ def main():
     breakdown = None
     if not args.no_kernel_timing:
         torch.cuda.synchronize(device)
-        for _ in range(3):
-            coder.encode()
+        for i in range(3):
+            coder.encode(i % G_res)
         ctx.sync()
         ctx.timing_reset()
         ctx.timing(True)
-        for _ in range(ALONE_LAUNCHES):
-            coder.encode()
+        for i in range(ALONE_LAUNCHES):
+            coder.encode(i % G_res)
         ctx.sync()
         ctx.timing(False)
         breakdown = {k: round(v[0] / ALONE_LAUNCHES, 4) for k, v in ctx.timing_read().items() if v[1]}    # ms per step (a kernel launched in groups counts whole)
 
-    res_all = [c.results() for c in coders]
+    # every resident GOP of every pipeline once more, for the oracle comparison: [(host frames, rows)]
+    checked = []
+    for g in range(G_res):
+        for k in range(1 if args.shared_gop else ncoders):
+            coders[k].encode(g)
+        for k in range(1 if args.shared_gop else ncoders):
+            checked.append((host_gops[k][g], coders[k].results()))
+    res_all = [rows for _, rows in checked]
     res = res_all[0]
     pixels_per_step = pairs * n * world
     value = pixels_per_step * steps_timed / elapsed / 1e6
@@ -318,8 +335,10 @@ def main():
         "ms_per_step": round(elapsed / steps_timed * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "steps_timed": steps_timed, "timed_region_ms": round(elapsed * 1e3, 2),
-        "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), %s, threshold 0"
-                               % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3"),
+        "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), %s, threshold 0, %s"
+                               % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3",
+                                  "planar Y resident (the mask stage reads luma only)" if planar else "interleaved YUV444 resident"),
+                   "layout": "planar Y" if planar else "interleaved", "resident_gops_per_pipeline": G_res,
                    "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
                    "distinct_gop_per_pipeline": not args.shared_gop, "resident_input_mb_per_gpu": round(resident_mb, 1),
                    "gather": "exact-size: all_gather of the used sizes, then one grouped point-to-point message per peer; rank 0's own records are not sent" if gather else None,
@@ -374,9 +393,13 @@ def main():
         else:
             out["roofline"] = None
         if world == 1:
-            out["pcie_inclusive_mpixels_per_s"] = pcie_inclusive(torch, nat, coder, host_gops[0], pairs * n, elapsed / steps_timed)
+            out["pcie_inclusive_mpixels_per_s"] = pcie_inclusive(torch, nat, coder, host_gops[0][0], pairs * n, elapsed / steps_timed)
+            if G_res >= 2 and planar:
+                out["pcie_overlapped_mpixels_per_s"] = pcie_overlapped(torch, device, coder, streams[0], host_gops[0], pairs * n)
         if not args.no_verify:
-            out["verified_vs_oracle"] = verify_all(host_gops, res_all, n, ncoders if not args.shared_gop else 1)
+            out["verified_vs_oracle"] = verify_all([h for h, _ in checked], res_all, n, len(checked))
+            out["verified_vs_oracle"]["pipelines"] = 1 if args.shared_gop else ncoders
+            out["verified_vs_oracle"]["gops_per_pipeline"] = G_res
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, n, args.cpu_frames)
     # ---- BASELINE configs[2] and [4] in the same process group: one 300-frame clip sharded by frame (strong scaling), 8- and 16-bit
@@ -448,19 +471,53 @@ def measured_traffic(W, H, F, bits, custom_density):
 
 
 def pcie_inclusive(torch, nat, coder, gop, pixels, step_s):
-    """Throughput if every GOP first had to cross PCIe: one pinned-host -> HBM upload of the GOP (measured here)
-    plus one step, serialised.  Never the headline: `value` is measured with inputs resident in HBM."""
-    pinned = torch.from_numpy(gop.reshape(-1).view(np.uint8)).pin_memory()
+    """Throughput if every GOP first had to cross PCIe: one pinned-host -> HBM upload of the GOP (measured here; the Y planes
+    only when the coder keeps planar luma) plus one step, serialised.  Never the headline: `value` is measured with inputs
+    resident in HBM."""
+    data = np.ascontiguousarray(gop[..., 0]) if coder.planar_luma else gop
+    dst = coder.luma.ptr if coder.planar_luma else coder.frames.ptr
+    pinned = torch.from_numpy(data.reshape(-1).view(np.uint8)).pin_memory()
     best = None
     for _ in range(3):
         coder.ctx.sync()
         t0 = time.perf_counter()
-        nat.check(nat.lib().rbf_memcpy_h2d(coder.ctx.handle, coder.frames.ptr, pinned.data_ptr(), pinned.numel()))
+        nat.check(nat.lib().rbf_memcpy_h2d(coder.ctx.handle, dst, pinned.data_ptr(), pinned.numel()))
         coder.ctx.sync()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    return {"value": round(pixels / (best + step_s) / 1e6, 1), "upload_ms": round(best * 1e3, 3), "upload_gbps": round(gop.nbytes / best / 1e9, 1),
-            "note": "upload and step serialised; pinned host memory"}
+    return {"value": round(pixels / (best + step_s) / 1e6, 1), "upload_ms": round(best * 1e3, 3), "upload_gbps": round(data.nbytes / best / 1e9, 1),
+            "uploaded_mb_per_gop": round(data.nbytes / 1e6, 1), "note": "upload and step serialised; pinned host memory"}
+
+
+def pcie_overlapped(torch, device, coder, stream, gops, pixels, reps=24):
+    """The honest ceiling of a host-fed stream: the upload of GOP i+1 (Y planes, pinned host memory, its own copy stream) runs
+    UNDER the step of GOP i (two resident slots alternate).  One pipeline; whole-GOP throughput in steady state."""
+    planes = [torch.from_numpy(np.ascontiguousarray(g[..., 0]).reshape(-1).view(np.uint8)).pin_memory() for g in gops[:2]]
+    nbytes = planes[0].numel()
+    slot = [coder.luma.tensor.view(torch.uint8)[i * nbytes:(i + 1) * nbytes] for i in range(2)]
+    copy_stream = torch.cuda.Stream(device)
+    done = [torch.cuda.Event(), torch.cuda.Event()]          # step i has finished reading its slot
+    ready = [torch.cuda.Event(), torch.cuda.Event()]         # slot holds its GOP
+
+    def run(count):
+        for i in range(count):
+            s = i & 1
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done[s])              # (recorded events only: the first two waits return at once)
+                slot[s].copy_(planes[s], non_blocking=True)
+                ready[s].record(copy_stream)
+            with torch.cuda.stream(stream):
+                stream.wait_event(ready[s])
+                coder.encode(s)
+                done[s].record(stream)
+    run(4)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run(reps)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(pixels / dt / 1e6, 1), "ms_per_gop": round(dt * 1e3, 3), "upload_gbps": round(nbytes / dt / 1e9, 1),
+            "note": "upload of the next GOP's Y planes on a copy stream under the current GOP's step; one pipeline, pinned host memory"}
 
 
 def _oracle_frame(args):
@@ -595,16 +652,19 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
     if args.force_bits:
         for c in ctxs:
             c.force_generic(args.force_bits)
-    frame_bytes = n * 3 * (bits // 8)
-    frames_t = torch.from_numpy(shard.reshape(-1).view(np.uint8)).to(device)       # the shard (+ halo), resident in HBM
+    planar = not args.interleaved
+    frame_bytes = n * (1 if planar else 3) * (bits // 8)
+    resident = np.ascontiguousarray(shard[..., 0]) if planar else shard       # planar: only the Y planes of the shard (+ halo) are resident in HBM
+    frames_t = torch.from_numpy(resident.reshape(-1).view(np.uint8)).to(device)
 
     class View:                                   # a run's frames inside the shard buffer
         def __init__(self, off, nbytes):
             self.ptr, self.nbytes = frames_t.data_ptr() + off, nbytes
     coders, records = [], []
     for i, (f0, cnt) in enumerate(pieces):
+        view = View((f0 - first) * frame_bytes, cnt * frame_bytes)
         c = GopCoder(ctxs[i % nstreams], W, H, cnt, channels=3, sample_bytes=bits // 8, allocator=torch_allocator(device),
-                     frames_block=View((f0 - first) * frame_bytes, cnt * frame_bytes))
+                     frames_block=None if planar else view, planar_luma=planar, keep_interleaved=False, luma_block=view if planar else None)
         coders.append(c)
         records.append(c._out_alloc(int(nat.lib().rbf_record_max_bytes(cnt - 1, n))))
     can_gather = use_dist and not args.no_gather
@@ -673,7 +733,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
                "workload": "%dx%d YUV444 %d-bit synthetic clip of %d frames, keyframe every %d (%d inter-frames/pass over %d GPU%s), k*=2.3, threshold 0"
                            % (W, H, bits, T, I, total_pairs, world, "s" if world > 1 else ""),
                "sharding": "contiguous frame ranges + 1 halo frame (dist.shard_range)", "inter_frames_rank0": my_pairs,
-               "verified_vs_oracle": verified}
+               "layout": "planar Y" if planar else "interleaved", "verified_vs_oracle": verified}
     # release the clip before the next leg
     for c in coders:
         c.close()

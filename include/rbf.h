@@ -171,6 +171,17 @@ int rbf_bgr_to_gray_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
                           uint32_t width, uint32_t height, uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
                           uint32_t sample_bytes, void *gray_dev);
 
+/* ---- A1, planar luma -------------------------------------------------------------------------- */
+/* luma_dev[f][y*width + x] = sample 0 of pixel (x, y) of frame f: the dense Y planes of a YUV GOP (the reference reads
+ * frame[:, :, 0], improved_video_compressor.py:788-791; its YUVFrame wrapper keeps the same plane as a contiguous copy,
+ * fixed_video_compressor.py:292-296).  The residual masks only ever look at luma, so a coder that keeps this block resident
+ * (rbf_encode_gop / rbf_residual_mask_batch with pixel_stride_bytes = sample_bytes, frame_stride_bytes = width*height*sample_bytes)
+ * moves one third of the bytes of the interleaved frames through the mask stage; the interleaved frames are then only touched
+ * by the changed-value gather.  One-time pass at upload. */
+int rbf_extract_luma_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes, uint32_t nframes,
+                           uint32_t width, uint32_t height, uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                           uint32_t sample_bytes, void *luma_dev);
+
 /* ---- A1, adaptive threshold  (VideoFrameCompressor._estimate_noise_level, :727-744) -------- */
 /* For each of nframes luma planes (addressed as above): smoothed = 5x5 median with replicated
  * borders (cv2.medianBlur(frame, 5), :738), noise = frame - smoothed (:741).

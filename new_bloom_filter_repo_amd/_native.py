@@ -65,6 +65,7 @@ _PROTOS = {
                                 _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _u64]),
     "rbf_gather_values_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _u32, _vp, _u64, _vp, _u64, _vp, _vp]),
     "rbf_bgr_to_gray_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _vp]),
+    "rbf_extract_luma_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _vp]),
     "rbf_noise_moments_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _vp, _vp]),
     "rbf_bloom_encode_batch": (_int, [_vp, _vp, _u64, _u64, _u32, ctypes.POINTER(FilterParams), ctypes.POINTER(Seeds),
                                       _vp, _u64, _vp, _u64, _vp]),

@@ -1245,6 +1245,33 @@ int rbf_bgr_to_gray_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
     return RBF_OK;
 }
 
+int rbf_extract_luma_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes, uint32_t nframes,
+                           uint32_t width, uint32_t height, uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                           uint32_t sample_bytes, void *luma_dev)
+{
+    if (int r = set_device(ctx)) return r;
+    if (!frames_dev || !luma_dev) return fail(RBF_EINVAL, "null device pointer");
+    if (nframes == 0 || nframes > 65535) return fail(RBF_EINVAL, "frame count %u out of range 1..65535", nframes);
+    if (width == 0 || height == 0) return fail(RBF_EINVAL, "empty frame %ux%u", width, height);
+    if (sample_bytes != 1 && sample_bytes != 2) return fail(RBF_EINVAL, "sample_bytes must be 1 or 2, got %u", sample_bytes);
+    if (pixel_stride_bytes < sample_bytes || pixel_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "pixel stride %u incompatible with %u-byte samples", pixel_stride_bytes, sample_bytes);
+    if (row_pitch_bytes < (uint64_t)width * pixel_stride_bytes || row_pitch_bytes % sample_bytes) return fail(RBF_EINVAL, "row pitch too small or misaligned");
+    if (frame_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "frame stride misaligned");
+    const uint64_t n = (uint64_t)width * height;
+    uint64_t bx = (n + 256 * 4 - 1) / (256 * 4);
+    if (bx < 1) bx = 1;
+    if (bx > 8192) bx = 8192;
+    LaunchTimer t(ctx, RBF_K_MASK);
+    if (sample_bytes == 1)
+        hipLaunchKernelGGL(k_extract_luma<uint8_t>, dim3((uint32_t)bx, nframes), dim3(256), 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
+                           width, n, row_pitch_bytes, pixel_stride_bytes, (uint8_t *)luma_dev);
+    else
+        hipLaunchKernelGGL(k_extract_luma<uint16_t>, dim3((uint32_t)bx, nframes), dim3(256), 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
+                           width, n, row_pitch_bytes, pixel_stride_bytes, (uint16_t *)luma_dev);
+    HIP_TRY(hipGetLastError());
+    return RBF_OK;
+}
+
 int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
                    uint32_t nframes, uint32_t width, uint32_t height,
                    uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,

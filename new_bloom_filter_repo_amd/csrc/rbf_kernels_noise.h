@@ -128,4 +128,22 @@ __global__ __launch_bounds__(256) void k_bgr_to_gray(
     }
 }
 
+// Sample 0 of every pixel (the luma of a YUV frame, improved_video_compressor.py:788-791 / the `y_plane` of
+// fixed_video_compressor.py:292-296) into a dense plane: what the planar mask kernel reads.  One lane per pixel.
+template <typename SAMPLE>
+__global__ __launch_bounds__(256) void k_extract_luma(
+    const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t width, uint64_t n, uint64_t row_pitch, uint32_t pixel_stride,
+    SAMPLE *__restrict__ luma /* [nframes][n] */)
+{
+    const uint8_t *src = frames + (uint64_t)blockIdx.y * frame_stride;
+    SAMPLE *dst = luma + (uint64_t)blockIdx.y * n;
+    const bool flat = row_pitch == (uint64_t)width * pixel_stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t off;
+        if (flat) off = i * pixel_stride;
+        else { const uint64_t y = i / width; off = y * row_pitch + (i - y * width) * pixel_stride; }
+        dst[i] = *(const SAMPLE *)(src + off);
+    }
+}
+
 }  // namespace rbf

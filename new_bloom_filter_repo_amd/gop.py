@@ -59,11 +59,17 @@ class GopCoder:
     """Encodes the nframes-1 inter-frame residual masks of one GOP of (H, W, C) frames."""
 
     def __init__(self, ctx, width, height, nframes, channels=3, sample_bytes=1, seeds=P.SEEDS_VIDEO,
-                 allocator=None, threshold=0.0, out_allocator=None, frames_block=None, adaptive=None):
+                 allocator=None, threshold=0.0, out_allocator=None, frames_block=None, adaptive=None,
+                 planar_luma=False, keep_interleaved=True, resident_gops=1, luma_block=None):
         """allocator: device memory source (default: library-owned); out_allocator: separate source for
         the output record (filters, witnesses, stats); frames_block: share another coder's frame buffer.
         threshold=None with adaptive=(noise_tolerance, min_thr, max_thr): per-frame noise-adaptive
-        thresholds (improved_video_compressor.py:746-766) -- lossy, like the reference's default."""
+        thresholds (improved_video_compressor.py:746-766) -- lossy, like the reference's default.
+        planar_luma: keep the GOP's Y planes as one dense block (the reference's YUVFrame carries the same plane,
+        fixed_video_compressor.py:292-296) and run the mask stage on it: a third of the interleaved bytes.  The
+        interleaved frames are then needed by gather_values() only (keep_interleaved=False: luma alone is resident,
+        3x more GOPs per byte of HBM).  resident_gops: room for that many GOPs of frames; encode(gop=g) codes the g-th.
+        luma_block: share an existing block of Y planes (like frames_block)."""
         from .engine import threshold_floor
         self.ctx, self.W, self.H, self.F, self.C, self.sb = ctx, width, height, nframes, channels, sample_bytes
         self.n = width * height
@@ -85,7 +91,17 @@ class GopCoder:
         self.frame_bytes = self.n * channels * sample_bytes
         self.mask_stride, self.filter_stride, self.witness_stride = self.strides(self.n)
         oalloc = self._out_alloc = out_allocator or alloc
-        self.frames = frames_block if frames_block is not None else alloc(self.frame_bytes * nframes)
+        self.planar_luma, self.keep_interleaved, self.resident_gops = bool(planar_luma), bool(keep_interleaved), int(resident_gops)
+        if self.planar_luma and self.adaptive is not None:
+            raise ValueError("noise-adaptive thresholds read the interleaved frames: planar_luma needs an explicit threshold")
+        self.luma_bytes = self.n * sample_bytes
+        self.luma = (luma_block if luma_block is not None else alloc(self.luma_bytes * nframes * self.resident_gops)) if self.planar_luma else None
+        if frames_block is not None:
+            self.frames = frames_block
+        elif self.planar_luma and not self.keep_interleaved:
+            self.frames = None
+        else:
+            self.frames = alloc(self.frame_bytes * nframes * self.resident_gops)
         self.masks = alloc(self.mask_stride * self.pairs)
         self.ones = alloc(8 * self.pairs)
         self.filters = oalloc(self.filter_stride * self.pairs)
@@ -123,10 +139,27 @@ class GopCoder:
     def __exit__(self, *exc):
         self.close()
 
-    def load_frames(self, frames):
+    def load_frames(self, frames, gop=0):
+        """Upload one GOP of interleaved (F, H, W, C) frames into slot `gop`.  With planar_luma the Y planes are extracted on
+        the device (rbf_extract_luma_batch) when the interleaved frames are kept, else on the host (only luma crosses PCIe)."""
         frames = np.ascontiguousarray(frames)
         assert frames.nbytes == self.frame_bytes * self.F, (frames.shape, frames.dtype)
-        nat.check(nat.lib().rbf_memcpy_h2d(self.ctx.handle, self.frames.ptr, frames.ctypes.data, frames.nbytes))
+        assert 0 <= gop < self.resident_gops
+        if self.frames is not None:
+            dst = self.frames.ptr + gop * self.frame_bytes * self.F
+            nat.check(nat.lib().rbf_memcpy_h2d(self.ctx.handle, dst, frames.ctypes.data, frames.nbytes))
+            if self.planar_luma:
+                nat.check(nat.lib().rbf_extract_luma_batch(self.ctx.handle, dst, self.frame_bytes, self.F, self.W, self.H, self.W * self.C * self.sb,
+                                                           self.C * self.sb, self.sb, self.luma.ptr + gop * self.luma_bytes * self.F))
+        else:
+            self.load_luma(frames.reshape(self.F, self.H, self.W, self.C)[..., 0], gop)
+
+    def load_luma(self, planes, gop=0):
+        """Upload one GOP of dense (F, H, W) Y planes (planar_luma coders)."""
+        assert self.planar_luma and 0 <= gop < self.resident_gops
+        planes = np.ascontiguousarray(planes)
+        assert planes.nbytes == self.luma_bytes * self.F, (planes.shape, planes.dtype)
+        nat.check(nat.lib().rbf_memcpy_h2d(self.ctx.handle, self.luma.ptr + gop * self.luma_bytes * self.F, planes.ctypes.data, planes.nbytes))
 
     def _noise(self, first, count, moments_ptr, planes_ptr):
         nat.check(nat.lib().rbf_noise_moments_batch(
@@ -154,14 +187,19 @@ class GopCoder:
             floors.append(lo)
         return floors
 
-    def encode(self):
-        """Enqueue one full pass; returns after the Bloom kernels are enqueued."""
+    def encode(self, gop=0):
+        """Enqueue one full pass over resident GOP `gop`; returns after the Bloom kernels are enqueued."""
         if self.adaptive is not None:
             self.thresholds = self.adaptive_floors()
             self.thr_tab = (ctypes.c_int32 * self.pairs)(*self.thresholds)
+        self.gop = gop
+        if self.planar_luma:                          # dense Y planes: pixel stride = one sample
+            src, fstride, pitch, pstride = self.luma.ptr + gop * self.luma_bytes * self.F, self.luma_bytes, self.W * self.sb, self.sb
+        else:
+            src, fstride, pitch, pstride = self.frames.ptr + gop * self.frame_bytes * self.F, self.frame_bytes, self.W * self.C * self.sb, self.C * self.sb
         nat.check(nat.lib().rbf_encode_gop(
-            self.ctx.handle, self.frames.ptr, self.frame_bytes, self.F, self.W, self.H,
-            self.W * self.C * self.sb, self.C * self.sb, self.sb, self.thr, self.thr_tab, ctypes.byref(self.seeds),
+            self.ctx.handle, src, fstride, self.F, self.W, self.H,
+            pitch, pstride, self.sb, self.thr, self.thr_tab, ctypes.byref(self.seeds),
             self.masks.ptr, self.mask_stride, self.ones.ptr,
             self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr,
             self.params, self.k))
@@ -191,8 +229,10 @@ class GopCoder:
         if getattr(self, "_voff", None) is None:
             self._voff = self._alloc(8 * (self.pairs + 1))
             self._uncov = self._alloc(8 * self.pairs)
+        if self.frames is None:
+            raise ValueError("gather_values needs the interleaved frames (keep_interleaved=True)")
         nat.check(nat.lib().rbf_gather_values_batch(
-            self.ctx.handle, self.frames.ptr, self.frame_bytes, self.F, self.W, self.H, self.W * self.C * self.sb, self.C * self.sb,
+            self.ctx.handle, self.frames.ptr + getattr(self, "gop", 0) * self.frame_bytes * self.F, self.frame_bytes, self.F, self.W, self.H, self.W * self.C * self.sb, self.C * self.sb,
             self.sb, self.C, self.masks.ptr, self.mask_stride, self._values.ptr, total, self._voff.ptr,
             self._uncov.ptr if check_uncovered else None))
         self.ctx.sync()

@@ -152,3 +152,40 @@ def test_config5_1080p_uint16_gop_and_surface_round_trip(oracle):
         b = verify_bit_exact(originals, decoded, color_space="YUV")
         assert b["success"] and b["exact_matches"] == F and b["different_frames"] == 0, b
         comp.close()
+
+
+@pytest.mark.parametrize("dtype,size,thr", [(np.uint8, (640, 360), 0.0), (np.uint8, (1920, 1080), 0.0), (np.uint16, (640, 360), 0.0), (np.uint8, (322, 181), 3.0)],
+                         ids=["u8_360p", "u8_1080p", "u16_360p", "u8_ragged_thr3"])
+def test_planar_luma_layout_equals_interleaved_and_oracle(oracle, dtype, size, thr):
+    """The planar-Y resident layout (bench.py's default, rbf_extract_luma_batch / GopCoder(planar_luma=True)): Y planes extracted
+    on the device (interleaved frames kept: the changed-value gather still works) and on the host (luma only crosses PCIe, several
+    resident GOP slots) give the records of the interleaved layout and of the CPU oracle; the gathered values are the same."""
+    W, H = size
+    n, F = W * H, 6
+    gops = [np.stack(make_gop(500 + g, W, H, F, p=0.07, dtype=dtype)) for g in range(2)]
+    sb = np.dtype(dtype).itemsize
+    ctx = nat.Context(0)
+    inter = GopCoder(ctx, W, H, F, sample_bytes=sb, threshold=thr)
+    dev = GopCoder(ctx, W, H, F, sample_bytes=sb, threshold=thr, planar_luma=True, keep_interleaved=True)
+    host = GopCoder(ctx, W, H, F, sample_bytes=sb, threshold=thr, planar_luma=True, keep_interleaved=False, resident_gops=2)
+    for g, gop in enumerate(gops):
+        host.load_frames(gop, g)
+    for g, gop in enumerate(gops):
+        inter.load_frames(gop)
+        dev.load_frames(gop)
+        inter.encode(); dev.encode(); host.encode(g)
+        a, b, c = inter.results(), dev.results(), host.results()
+        for f in range(F - 1):
+            for key in ("ones", "k", "l", "witness_bits", "filter_ones"):
+                assert a[f][key] == b[f][key] == c[f][key], (g, f, key)
+            for key in ("mask", "filter", "witness"):
+                assert np.array_equal(a[f][key], b[f][key]) and np.array_equal(a[f][key], c[f][key]), (g, f, key)
+        if thr == 0.0:
+            check_records(c, oracle_gop(oracle, gop), n, "planar gop %d" % g)
+        va, vb = inter.gather_values(), dev.gather_values()
+        assert all(np.array_equal(x, y) for x, y in zip(va, vb))
+    with pytest.raises(ValueError):
+        host.gather_values()
+    for c in (inter, dev, host):
+        c.close()
+    ctx.close()
