@@ -111,7 +111,11 @@ int rbf_timing_enable(rbf_ctx *ctx, int on);
  *   bit 2       per-pixel threshold compare in the GOP mask kernel even for threshold 0
  *   bit 3       Barrett reductions only (never the FP64 h mod m, which is taken when every filter of a batch has 2^15 <= m < 2^23)
  *   bit 4       run k_hash_table (the pixel-index hash table the insert kernel gathers from, 32 bytes per pixel, shared by the
- *               contexts of a process) for every batch instead of once per (device, frame size, seeds)
+ *               contexts of a process) for every batch instead of once per (device, frame size, seeds).
+ *               FOOTPRINT: the table is process-global device memory -- 32 * (width*height + 512) bytes per (device, frame size,
+ *               seeds) in use, e.g. 66 MB at 1080p -- allocated by the first encode of a geometry and released when the last
+ *               context holding it is destroyed or moves to another geometry.  Geometries whose table would exceed 96 MB
+ *               (2560x1440 and up) never get one: their insert kernels hash the set positions instead.
  *   bit 5       never use that table: the insert kernel hashes the set positions itself, as in ABI build 1
  *   bit 6       the 4-pixels-per-lane FP64 query kernel (k_query_p4) instead of k_query_f64
  *   bit 7       filters of several LDS tiles are inserted by the tiled k_insert_tab even inside rbf_encode_gop (default there:

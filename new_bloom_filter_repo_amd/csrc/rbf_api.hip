@@ -190,7 +190,13 @@ static bool hash_table_acquire(rbf_ctx *ctx, uint64_t n, const rbf_seeds &seeds,
         hipLaunchKernelGGL(k_hash_table, dim3((uint32_t)((segs + HT_THREADS / WAVE - 1) / (HT_THREADS / WAVE))), dim3(HT_THREADS), 0, ctx->stream,
                            n, Seeds{seeds.h1, seeds.h2, seeds.act}, t->table);
     }
-    (void)hipEventRecord(t->ready, ctx->stream);
+    // a table whose kernel never ran must not be published to the other contexts of the process
+    if (hipGetLastError() != hipSuccess || hipEventRecord(t->ready, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipEventDestroy(t->ready); (void)hipFree(t->table); delete t;
+        return false;
+    }
     try { g_hash_tables.push_back(t); } catch (...) { (void)hipStreamSynchronize(ctx->stream); (void)hipEventDestroy(t->ready); (void)hipFree(t->table); delete t; return false; }
     ctx->hash_shared = t; ctx->hash_tab = t->table;
     *built = true;
@@ -969,7 +975,15 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
 {
     uint64_t nrecords = 0;
     if (ones_host) for (uint32_t f = 0; f < nframes; ++f) if (params[f].m) nrecords += ones_host[f];
-    const Plan pl = make_plan(ctx, params, nframes, n, ones_host && nrecords < (1ull << 32));
+    Plan pl = make_plan(ctx, params, nframes, n, ones_host && nrecords < (1ull << 32));
+    // The two-kernel insert needs 8 bytes per set mask bit.  Without that memory the batch is re-planned as if the counts
+    // were unknown (queue-sized tiles, k_insert_tab / k_insert_lds): slower, not an error.
+    if (pl.insert_two_phase &&
+        (grow((void **)&ctx->ins_records, &ctx->ins_records_cap, (size_t)(nrecords ? nrecords : 1) * 8) ||
+         grow((void **)&ctx->ins_counters, &ctx->ins_counters_cap, (size_t)MAX_BATCH * 4))) {
+        (void)hipGetLastError();
+        pl = make_plan(ctx, params, nframes, n, false);
+    }
     FrameTable tab;
     if (int r = fill_table(params, nframes, &tab)) return r;
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * pl.words_per_seg * 8)) return r;
@@ -991,12 +1005,14 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         // hash table of the pixel indices (k_hash_table): built for this batch, or kept from the last one when the
         // context was told to cache it; without device memory for it the insert kernel hashes for itself
         bool use_tab = pl.insert_tab;
-        // two-kernel insert of frames whose table (32 B per pixel) would crowd the 256 MB Infinity Cache: the set positions are
-        // hashed in the kernel instead (2160p: 72 us against 96 with the gather) and no table is built
-        const bool hashed_positions = pl.insert_two_phase && (ctx->hash_positions || ((size_t)n + QL_SEG_PIXELS) * 32 > HASH_TABLE_CACHE_BYTES);
+        // A pixel-index table (32 B per pixel, process-wide, lives until the last context of its geometry goes) that would crowd the
+        // 256 MB Infinity Cache is never built: the insert kernels hash their set positions on the spot instead (2160p, 265 MB:
+        // 72 us against 96 with the gather) -- whichever insert kernel runs, with or without the masks' set-bit counts.
+        const bool table_too_big = ((size_t)n + QL_SEG_PIXELS) * 32 > HASH_TABLE_CACHE_BYTES;
+        bool hashed_positions = use_tab && (table_too_big || (pl.insert_two_phase && ctx->hash_positions));
         if (use_tab && !hashed_positions) {
             bool built = false;
-            if (!hash_table_acquire(ctx, n, *seeds, &built)) use_tab = false;
+            if (!hash_table_acquire(ctx, n, *seeds, &built)) hashed_positions = true;        // no device memory for the table: hash instead
             else if (ctx->hash_rebuild && !built) {               // diagnostic: the table is rewritten (same values) for every batch
                 const uint64_t segs = (n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS;
                 LaunchTimer t(ctx, RBF_K_HASHTAB);
@@ -1010,13 +1026,9 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                 if (itab.f[f].m) { const double ninv = -1.0 / (double)itab.f[f].m; memcpy(&itab.f[f].M, &ninv, 8); }
         auto ikern = pl.small_m ? k_insert_lds<true> : k_insert_lds<false>;
         if (int r = allow_big_lds((const void *)ikern)) return r;
-        if (int r = allow_big_lds((const void *)k_insert_tab<0>)) return r;
-        bool two_phase = pl.insert_two_phase && use_tab;
-        if (two_phase) {
-            if (grow((void **)&ctx->ins_records, &ctx->ins_records_cap, (size_t)(nrecords ? nrecords : 1) * 8) ||
-                grow((void **)&ctx->ins_counters, &ctx->ins_counters_cap, (size_t)MAX_BATCH * 4)) two_phase = false;
-        }
-        if (pl.insert_two_phase && !two_phase) return fail(RBF_ENOMEM, "no device memory for %llu insert records", (unsigned long long)nrecords);
+        if (int r = allow_big_lds((const void *)k_insert_tab<0, false>)) return r;
+        if (int r = allow_big_lds((const void *)k_insert_tab<0, true>)) return r;
+        const bool two_phase = pl.insert_two_phase && use_tab;    // (its record memory was reserved above)
         if (two_phase) {
             // itab.floor_k / rtab.T carry the index of the frame's first record (the kernels' own use of those fields: none)
             uint64_t first = 0;
@@ -1057,9 +1069,13 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                 hipLaunchKernelGGL(k_insert_records, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
                                    (const uint2 *)ctx->ins_records, (const uint32_t *)ctx->ins_counters, rtab, ctx->partials, part_stride,
                                    pl.insert_tile_words, grp, per_tile, pl.S);
-            } else if (use_tab)
-                hipLaunchKernelGGL(k_insert_tab<0>, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
-                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, ctx->partials, part_stride,
+            } else if (use_tab && hashed_positions)
+                hipLaunchKernelGGL((k_insert_tab<0, true>), dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)nullptr, sd, ctx->partials, part_stride,
+                                   pl.insert_tile_words, grp, per_tile, pl.S);
+            else if (use_tab)
+                hipLaunchKernelGGL((k_insert_tab<0, false>), dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, sd, ctx->partials, part_stride,
                                    pl.insert_tile_words, grp, per_tile, pl.S);
             else
                 hipLaunchKernelGGL(ikern, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,

@@ -175,10 +175,10 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     if (qn) { fetch(0, qn); finish(); }
 }
 
-template <int IAB = 0>
+template <int IAB = 0, bool HASHED = false>
 __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
-    const FrameTable tab, const uint4 *__restrict__ table,
+    const FrameTable tab, const uint4 *__restrict__ table /* unused when HASHED: the set positions are hashed on the spot */, Seeds seeds,
     uint32_t *__restrict__ partials, uint64_t part_stride_words32, uint32_t tile_words /* even */,
     const SliceTable slices, uint32_t per_tile /* sum of slices.n */, uint32_t Smax /* max of slices.n: row pitch of the partials */)
 {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     const uint64_t gper = (groups + S - 1) / S;
     const uint64_t g0 = (uint64_t)s * gper;
     const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
-    insert_tab_steps<IAB, false, IL_WAVES>(masks + (uint64_t)f * mask_stride_bytes, n, fd, table, Seeds{}, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
+    insert_tab_steps<IAB, false, IL_WAVES, HASHED>(masks + (uint64_t)f * mask_stride_bytes, n, fd, table, seeds, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
                                            queues + wave * IT_QUEUE, g0, g1, lane, wave);
     __syncthreads();
     uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;

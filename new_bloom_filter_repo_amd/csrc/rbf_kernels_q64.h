@@ -28,7 +28,9 @@ namespace rbf {
 
 // ---- h mod m through the FP64 pipe (2^15 <= m < 2^23) --------------------------------------------------------
 // With hd = RN(h) as a double (frame-independent, computed once per pixel next to the hash) and ninv = -1/m:
-//     t = fma(hd, ninv, 1.5 * 2^52)  ->  t = 1.5 * 2^52 - q_est,  q_est = RN(h/m + d),  |d| <= 1.5 * 2^-52 * h/m < 2^-2
+//     t = fma(hd, ninv, 1.5 * 2^52)  ->  t = 1.5 * 2^52 - q_est,  q_est = RN(h/m + d),  |d| < 2^-3:
+//         |RN(h) - h| / m          <= 2^10 / 2^15 = 2^-5      (h < 2^64 is rounded to 53 bits: half an ulp of 2^11), plus
+//         (h/m) * |rel. error of RN(-1/m)|  <  2^49 * 2^-53 = 2^-4
 // (h/m < 2^49 because m >= 2^15; t lies in [2^52, 2^53), where doubles are integers), so q_est is floor(h/m) or
 // floor(h/m) + 1 and r_est = h - q_est * m lies in [-0.75 m, 0.75 m].  The low dword of t's mantissa is -q_est mod 2^32;
 // only r_est mod 2^24 is needed (|r_est| < 2^23 as m < 2^23), and that depends only on the low 24 bits of q_est, m
@@ -181,8 +183,8 @@ __device__ __forceinline__ void hash_table_store(uint4 *__restrict__ table, uint
 // dma_filter (rbf_kernels_lds.h) costs ~30 instructions per 1 KiB piece -- M0 saved and restored, a 64-bit address per lane,
 // the bounds test -- and a wave issues five pieces per frame: ~150 of the ~520 instructions it executes per frame went into
 // ISSUING the staging (ISA count, profiles/r02_query_isa.txt).  This form keeps the row pointer in an SGPR pair (saddr
-// addressing: the VGPR holds a 32-bit byte offset), writes M0 without restoring it (declared clobbered: nothing else in
-// these kernels uses M0) and tests bounds only on the row's last piece: 4 instructions per piece.
+// addressing: the VGPR holds a 32-bit byte offset) and tests bounds only on the row's last piece: 6 instructions per piece
+// (M0 is saved and restored inside the asm block; round 2 listed it as a clobber, which the compiler rejects as reserved).
 __device__ __forceinline__ void dma_row(uint32_t lds_byte_addr /* uniform */, const uint32_t *row /* uniform */, uint32_t words, uint32_t wave, uint32_t lane, uint32_t nwaves)
 {
     const uint32_t npieces = words >> 2;                          // whole 16-byte pieces
@@ -190,14 +192,19 @@ __device__ __forceinline__ void dma_row(uint32_t lds_byte_addr /* uniform */, co
     for (uint32_t c = wave; (c << 6) < npieces; c += nwaves) {
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr + (c << 10));
         const uint32_t off = lane_off + (c << 10);
-        if ((c << 6) + 64u <= npieces || (c << 6) + lane < npieces)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(off), "s"(row) : "memory", "m0");
+        if ((c << 6) + 64u <= npieces || (c << 6) + lane < npieces) {
+            uint32_t keep;                                        // M0 is saved and restored inside the block: it is a reserved register, not a clobber
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(off), "s"(row) : "memory");
+        }
     }
     const uint32_t tail = words & 3u;                             // 0..3 dwords left: 4-byte DMA by wave 0
     if (wave == 0 && lane < tail) {
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr + (npieces << 4));
         const uint32_t off = (npieces << 4) + (lane << 2);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(dst), "v"(off), "s"(row) : "memory", "m0");
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(off), "s"(row) : "memory");
     }
 }
 

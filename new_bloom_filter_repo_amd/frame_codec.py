@@ -123,11 +123,15 @@ class FixedVideoCompressor:
                 z = blob[off + 4:off + 4 + zlen]
                 ph, pw = struct.unpack_from("<II", blob, off + 4 + zlen)
                 off += 12 + zlen
-                planes.append(np.frombuffer(zlib.decompress(z), dtype=dtype).reshape(ph, pw))
-            if frame.ndim != 3 or frame.shape[2] < 3 or any(not np.array_equal(planes[c], frame[:, :, c]) for c in range(3)):
-                raise ValueError("keyframe record: stored YUV planes do not match the frame channels")
-            out = YUVFrame(frame)
-            out.yuv_info["format"] = fmt
+                pdata = zlib.decompress(z)
+                # the reference reads the planes as uint8 (fixed_video_compressor.py:155,163,171); planes of 16-bit frames keep the frame dtype
+                pdt = np.uint8 if len(pdata) == ph * pw else dtype
+                planes.append(np.frombuffer(pdata, dtype=pdt).reshape(ph, pw))
+            # the STORED planes come back in yuv_info, whatever their shape (a reference record may carry subsampled planes)
+            out = YUVFrame.__new__(YUVFrame)
+            out.data = frame
+            out.shape, out.dtype, out.nbytes = frame.shape, frame.dtype, frame.nbytes
+            out.yuv_info = {"format": fmt, "y_plane": planes[0], "u_plane": planes[1], "v_plane": planes[2]}
             return out
         return frame
 

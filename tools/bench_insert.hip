@@ -40,11 +40,11 @@ static float run_tab(const uint8_t *masks, uint64_t mstride, uint64_t n, uint32_
     SliceTable sl{};
     uint32_t per_tile = 0;
     for (uint32_t f = 0; f < F; ++f) { sl.n[f] = (uint8_t)S; per_tile += S; }
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(per_tile), dim3(IL_THREADS), lds, 0, masks, mstride, n, itab, table, partials, pstride, tile_words, sl, per_tile, S);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(per_tile), dim3(IL_THREADS), lds, 0, masks, mstride, n, itab, table, Seeds{}, partials, pstride, tile_words, sl, per_tile, S);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
     const int R = 10;
-    for (int r = 0; r < R; ++r) hipLaunchKernelGGL(kern, dim3(per_tile), dim3(IL_THREADS), lds, 0, masks, mstride, n, itab, table, partials, pstride, tile_words, sl, per_tile, S);
+    for (int r = 0; r < R; ++r) hipLaunchKernelGGL(kern, dim3(per_tile), dim3(IL_THREADS), lds, 0, masks, mstride, n, itab, table, Seeds{}, partials, pstride, tile_words, sl, per_tile, S);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return ms / R * 1000.f;
@@ -83,7 +83,7 @@ static int big()
         CK(hipMemset(dp, 0, pw * 4));
         for (int r = 0; r < 12; ++r) {
             if (r == 2) CK(hipEventRecord(a));
-            hipLaunchKernelGGL(kern, dim3(per_tile * tiles), dim3(IL_THREADS), lds, 0, dm, mstride, n, tab, dt, dp, pstride, tile_words, sl, per_tile, S);
+            hipLaunchKernelGGL(kern, dim3(per_tile * tiles), dim3(IL_THREADS), lds, 0, dm, mstride, n, tab, dt, Seeds{}, dp, pstride, tile_words, sl, per_tile, S);
         }
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
         CK(hipGetLastError());
