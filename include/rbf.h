@@ -132,6 +132,9 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
 /* Further testing / tuning knobs (the bit mask above is full).  RBF_OPT_QUERY_R64 (value 0 / 1): 1 = k_query_r64, the round-2 FP64
  * query kernel, where k_query_s64 (round 3: pass written in rows, frame geometry in LDS, wave priorities) would run. */
 #define RBF_OPT_QUERY_R64 1
+/* RBF_OPT_SEPARATE_FINISH (0 / 1): 1 = rbf_encode_gop always hands the ones counts out through the separate k_finish_ones launch
+ * (default: inside the GOP mask kernel whenever that kernel covers the whole frame). */
+#define RBF_OPT_SEPARATE_FINISH 2
 int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value);
 int rbf_timing_reset(rbf_ctx *ctx);
 int rbf_timing_read(rbf_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);

@@ -18,7 +18,7 @@ RBF_ERANGE = -34
 K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE, K_PACK, K_HASHTAB = range(13)
 KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack", "hashtab"]
 STATS_PER_FRAME = 4
-OPT_QUERY_R64 = 1                      # rbf_ctx_option keys (include/rbf.h)
+OPT_QUERY_R64, OPT_SEPARATE_FINISH = 1, 2    # rbf_ctx_option keys (include/rbf.h)
 
 
 class FilterParams(ctypes.Structure):

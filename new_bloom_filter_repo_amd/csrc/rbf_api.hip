@@ -62,6 +62,8 @@ struct rbf_ctx {
     int query_dma = 0;               // 1 = k_query_f64 (LDS-DMA staging, 64-bit activation hashes) instead of k_query_r64
     int query_r64 = 0;               // 1 = k_query_r64 (round 2) where k_query_s64 would run (rbf_ctx_option RBF_OPT_QUERY_R64)
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
+    uint32_t *mask_ticket = nullptr;                              // the fused tail of the GOP mask kernel: workgroups done so far (zero between launches)
+    int no_fused_finish = 0;                                      // 1 = always the separate k_finish_ones launch (rbf_ctx_option RBF_OPT_SEPARATE_FINISH)
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
     int32_t *thr_tab = nullptr;      size_t thr_tab_cap = 0;      // per-pair thresholds of the mask kernels
@@ -277,6 +279,7 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (ctx->ins_counters) (void)hipFree(ctx->ins_counters);
     if (ctx->qimage) (void)hipFree(ctx->qimage);
     if (ctx->ones_acc) (void)hipFree(ctx->ones_acc);
+    if (ctx->mask_ticket) (void)hipFree(ctx->mask_ticket);
     hash_table_release(ctx);
     if (ctx->thr_tab) (void)hipFree(ctx->thr_tab);
     if (ctx->pack_base) (void)hipFree(ctx->pack_base);
@@ -373,6 +376,7 @@ int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value)
     if (!ctx) return fail(RBF_EINVAL, "null context");
     switch (option) {
     case RBF_OPT_QUERY_R64: ctx->query_r64 = value ? 1 : 0; return RBF_OK;
+    case RBF_OPT_SEPARATE_FINISH: ctx->no_fused_finish = value ? 1 : 0; return RBF_OK;
     default: return fail(RBF_EINVAL, "unknown option %d", option);
     }
 }
@@ -735,7 +739,8 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
                               uint32_t nframes, uint32_t width, uint32_t height,
                               uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
                               uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
-                              void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev, bool finish)
+                              void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev, bool finish,
+                              const MaskFinish *gop_tail = nullptr /* rbf_encode_gop: publish + clears; fused into the mask kernel when it covers the frame */)
 {
     if (int r = set_device(ctx)) return r;
     if (!frames_dev || !masks_dev || !ones_dev) return fail(RBF_EINVAL, "null device pointer");
@@ -775,6 +780,7 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
         thr_tab = ctx->thr_tab;
     }
     const uint64_t nwords = (n + 63) / 64;
+    bool fused = false;
     // Fast path: flat frames, 16-byte aligned, whole 1024-pixel segments; the generic kernel does the rest.
     uint64_t fast_segs = 0;
     const bool flat = row_pitch_bytes == (uint64_t)width * pixel_stride_bytes;
@@ -792,10 +798,21 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
         if (chunks < 1) chunks = 1;
         const uint32_t ppc = (pairs + chunks - 1) / chunks;
         chunks = (pairs + ppc - 1) / ppc;
+        // the pass's tail (counts out, clears) rides in this launch when it is the only mask launch of the pass
+        MaskFinish fin{};
+        if (gop_tail && !ctx->no_fused_finish && fast_segs * 16 == nwords && !(((uintptr_t)gop_tail->clear_a | (uintptr_t)gop_tail->clear_b) & 15)) {
+            if (!ctx->mask_ticket) {
+                HIP_TRY(hipMalloc((void **)&ctx->mask_ticket, (MASK_TICKETS + 1) * 4));
+                HIP_TRY(hipMemsetAsync(ctx->mask_ticket, 0, (MASK_TICKETS + 1) * 4, ctx->stream));
+            }
+            fin = *gop_tail;
+            fin.enabled = 1; fin.count = pairs; fin.ticket = ctx->mask_ticket; fin.ones_out = ones_dev;
+            fused = true;
+        }
         LaunchTimer t(ctx, RBF_K_MASK);
 #define RBF_MASK_GOP(S, PB, Z) hipLaunchKernelGGL((k_residual_mask_gop<S, PB, false, Z>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
                                (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, thr_tab, (uint16_t *)masks_dev, \
-                               mask_stride_bytes / 2, acc, ppc)
+                               mask_stride_bytes / 2, acc, ppc, fin)
 #define RBF_MASK_GOP2(S, PB) do { if (thr0) RBF_MASK_GOP(S, PB, true); else RBF_MASK_GOP(S, PB, false); } while (0)
         const bool thr0 = !thr_tab && thr_floor == 0 && !(ctx->force_generic_mask_bits);     // "luma changed": no per-pixel extraction
         if (sample_bytes == 1 && pixel_stride_bytes == 1) RBF_MASK_GOP2(uint8_t, 1);
@@ -821,6 +838,9 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
                                width, n, row_pitch_bytes, pixel_stride_bytes, thr_floor, thr_tab, (uint64_t *)masks_dev, mask_stride_bytes / 8, acc, first_word);
     }
     HIP_TRY(hipGetLastError());
+    if (fused) { ctx->ones_acc_dirty = false; return RBF_OK; }
+    if (gop_tail) return launch_finish_ones(ctx, ones_dev, pairs, gop_tail->host_block, gop_tail->token, gop_tail->clear_a, (size_t)gop_tail->quads_a * 16,
+                                            gop_tail->clear_b, (size_t)gop_tail->quads_b * 16);
     if (finish) return launch_finish_ones(ctx, ones_dev, pairs, nullptr, 0, nullptr, 0, nullptr, 0);
     return RBF_OK;
 }
@@ -1299,9 +1319,8 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
                    rbf_filter_params *params_out, double *k_out)
 {
     if (!filters_dev || !witnesses_dev || !stats_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
-    if (int r = residual_mask_impl(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
-                                   pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, false))
-        return r;
+    if (int r = set_device(ctx)) return r;
+    if (nframes < 2) return fail(RBF_EINVAL, "need at least 2 frames, got %u", nframes);
     const uint32_t pairs = nframes - 1;
     const uint64_t n = (uint64_t)width * height;
     if (witness_stride_bytes % 8 || witness_stride_bytes < ((n + 63) / 64) * 8) return fail(RBF_EINVAL, "witness stride too small or misaligned");
@@ -1320,12 +1339,20 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
         }
         ctx->host_cap = pairs + 16;
     }
-    // The GPU publishes the counts straight into host memory; meanwhile the output buffers are
-    // cleared, so the only thing between the mask kernel and the Bloom kernels is the host's
-    // float64 parameter math.
+    // The GPU publishes the counts straight into host memory and clears the output buffers in the same pass -- inside the mask
+    // kernel when it covers the whole frame, else through k_finish_ones -- so the only thing between the mask kernel and the
+    // Bloom kernels is the host's float64 parameter math.
     const uint64_t token = ++ctx->publish_token;
-    if (int r = launch_finish_ones(ctx, ones_dev, pairs, ctx->ones_mapped_dev, token, witnesses_dev, (size_t)pairs * witness_stride_bytes,
-                                   stats_dev, (size_t)pairs * RBF_STATS_PER_FRAME * 8))
+    MaskFinish tail{};
+    tail.host_block = ctx->ones_mapped_dev; tail.token = token;
+    tail.clear_a = (uint4 *)witnesses_dev; tail.quads_a = (uint64_t)pairs * witness_stride_bytes / 16;
+    tail.clear_b = (uint4 *)stats_dev;     tail.quads_b = (uint64_t)pairs * RBF_STATS_PER_FRAME * 8 / 16;
+    if (((uint64_t)pairs * witness_stride_bytes) % 16) {          // (never the case for the library's own buffers) plain memset, nothing for the kernel
+        HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)pairs * witness_stride_bytes, ctx->stream));
+        tail.clear_a = nullptr; tail.quads_a = 0;
+    }
+    if (int r = residual_mask_impl(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
+                                   pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, false, &tail))
         return r;
     volatile uint64_t *flag = ctx->ones_pinned;
     for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != token; ++spins) {

@@ -802,12 +802,30 @@ __device__ __forceinline__ uint32_t lane_bits_thr0(const LanePixels<SAMPLE, PIXE
     return bits;
 }
 
+// What used to be k_finish_ones' job, folded into the mask kernel when it covers the whole frame (rbf_encode_gop on frames of whole
+// 1024-pixel segments): every workgroup clears its share of two output regions (the witness rows and the stats of the batch), and
+// the LAST workgroup to finish (a ticket) hands the counts out -- to the caller's array and into the device-visible pinned block
+// whose token the host spins on -- and re-zeroes the accumulator and the ticket.  One launch less per step, and the publish no
+// longer queues behind whatever else occupies the GPU (profiles/r02_overlap_4pipelines.txt: the 5 us k_finish_ones took 61 us
+// under overlap).
+constexpr uint32_t MASK_TICKETS = 64;           // first-level ticket counters; one more dword for the second level
+struct MaskFinish {
+    uint32_t enabled;              // 0: the caller runs k_finish_ones
+    uint32_t count;                // pairs
+    uint32_t *ticket;              // context-owned: MASK_TICKETS + 1 counters, zero between launches
+    uint64_t *ones_out;            // caller's device array
+    uint64_t *host_block;          // nullable: [token | ones...] in pinned host memory
+    uint64_t token;
+    uint4 *clear_a; uint64_t quads_a;
+    uint4 *clear_b; uint64_t quads_b;
+};
+
 template <typename SAMPLE, int PIXEL_BYTES, bool NT = false, bool THR0 = false>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t nframes, uint64_t nsegs /* of 1024 px */,
     int32_t thr_all, const int32_t *__restrict__ thr_tab /* nullable: per pair */,
     uint16_t *__restrict__ masks, uint64_t mask_stride_u16, uint64_t *__restrict__ ones,
-    uint32_t pairs_per_chunk)
+    uint32_t pairs_per_chunk, const MaskFinish fin)
 {
     // blockIdx.y = temporal chunk: frames [f0, f1] (f1 - f0 pairs); chunks overlap by one frame, which
     // buys gridDim.y times more waves in flight for ~gridDim.y/nframes extra reads
@@ -856,6 +874,53 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     __syncthreads();
     for (uint32_t i = f0 + threadIdx.x; i < f1; i += WG_THREADS)
         if (cnt[i]) atomicAdd((unsigned long long *)&ones[i], (unsigned long long)cnt[i]);
+    if (!fin.enabled) return;
+    // ---- the tail of the pass (see MaskFinish).  Only wave 0 -- whose lanes issued the workgroup's count atomics -- takes a ticket.
+    const uint64_t wg = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (uint64_t)gridDim.x * gridDim.y;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const bool wide = f1 > f0 + WAVE;              // (workgroup-uniform) more than 64 pairs in this chunk: waves 1..3 issued count atomics too
+    if (wide) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (wave != 0) {                               // waves 1..3: their share of the clears, and out
+        for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
+        for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_b; i += nwg * WG_THREADS) fin.clear_b[i] = z;
+        return;
+    }
+    // My counts must have been performed before my ticket is.  They are agent-scope atomics (carried out at the device's coherence
+    // point, not in this XCD's L2), so waiting for their acknowledgements is enough -- a __threadfence() here writes the L2 back
+    // from every workgroup and made the kernel 8x slower (25 -> 190 us).
+    if (!wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Two-level ticket: all ~2 000 workgroups of a 1080p GOP are resident at once and finish together, and returning atomics on ONE
+    // address complete one every ~6 ns -- a single counter cost the kernel 13 us.  64 first-level counters (workgroup id mod 64),
+    // whose last arrivals meet on a second-level one.
+    uint32_t is_last = 0;
+    if (lane == 0) {
+        const uint32_t idx = (uint32_t)(wg % MASK_TICKETS);
+        const uint32_t mine = (uint32_t)((nwg + MASK_TICKETS - 1 - idx) / MASK_TICKETS);      // workgroups on this counter
+        if (atomicAdd(fin.ticket + idx, 1u) == mine - 1u) {
+            __hip_atomic_store(fin.ticket + idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t groups = nwg < MASK_TICKETS ? (uint32_t)nwg : (uint32_t)MASK_TICKETS;
+            is_last = atomicAdd(fin.ticket + MASK_TICKETS, 1u) == groups - 1u ? 1u : 0u;
+        }
+    }
+    is_last = __builtin_amdgcn_readfirstlane(is_last);
+    for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
+    for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_b; i += nwg * WG_THREADS) fin.clear_b[i] = z;
+    if (!is_last) return;
+    // the last workgroup: counts out (to the caller's array and the host), accumulator and ticket back to zero
+    for (uint32_t i = lane; i < fin.count; i += WAVE) {
+        const uint64_t v = __hip_atomic_load(&ones[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the other workgroups added at the coherence point)
+        fin.ones_out[i] = v;
+        __hip_atomic_store(&ones[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fin.host_block) __hip_atomic_store(&fin.host_block[1 + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (fin.host_block) {
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(&fin.host_block[0], fin.token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane == 0) __hip_atomic_store(fin.ticket + MASK_TICKETS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace rbf

@@ -189,3 +189,39 @@ def test_planar_luma_layout_equals_interleaved_and_oracle(oracle, dtype, size, t
     for c in (inter, dev, host):
         c.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("W,H,p", [(2560, 1440, 0.01), (3840, 2160, 0.004)], ids=["1440p_sparse", "2160p_sparse"])
+def test_sparse_large_frames_single_tile_insert_hashes_instead_of_building_a_table(oracle, W, H, p):
+    """Nearly static large frames: the filter fits ONE LDS tile, so the single-tile k_insert_tab runs -- but the pixel-index
+    table of such a geometry (118 / 265 MB) is past the 96 MB cutoff, so that kernel hashes its set positions itself
+    (k_insert_tab<0, true>) and no table is ever allocated.  Records against the oracle, and decoded back."""
+    n, F = W * H, 3
+    frames = np.stack(make_gop(4100 + W, W, H, F, p=p))
+    want = oracle_gop(oracle, frames)
+    assert all(l > 0 for _, _, _, l, _, _ in want)
+    with nat.Context(0) as ctx:
+        with GopCoder(ctx, W, H, F, channels=3, sample_bytes=1) as coder:
+            coder.load_frames(frames)
+            coder.encode()
+            res = coder.results()
+            check_records(res, want, n, "%dx%d sparse" % (W, H))
+            decode_back(ctx, res, n, "%dx%d sparse" % (W, H))
+
+
+def test_fused_mask_tail_equals_separate_finish_kernel(oracle):
+    """rbf_encode_gop hands the ones counts to the host (and clears the witness rows / stats) inside the GOP mask kernel when
+    that kernel covers the whole frame (640x360 = 225 segments of 1024 pixels); RBF_OPT_SEPARATE_FINISH keeps the k_finish_ones
+    launch, and 322x181 (no whole segments at the end) takes that path by itself.  Same records, repeatedly (the ticket and the
+    accumulator must come back to zero), against the oracle."""
+    for W, H in ((640, 360), (322, 181)):
+        n, F = W * H, 7
+        frames = np.stack(make_gop(4300 + W, W, H, F, p=0.06))
+        want = oracle_gop(oracle, frames)
+        with nat.Context(0) as ctx:
+            with GopCoder(ctx, W, H, F) as coder:
+                coder.load_frames(frames)
+                for rep in range(3):
+                    ctx.option(nat.OPT_SEPARATE_FINISH, rep == 1)
+                    coder.encode()
+                    check_records(coder.results(), want, n, "%dx%d rep %d" % (W, H, rep))
