@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the default command (four GOP pipelines: kernels of neighbouring steps overlap, so per-kernel durations
 # include the co-runner) ...
-BENCH2="python $ROOT/bench.py --no-cpu-baseline --no-verify $*"      # exactly the default command, minus the CPU leg
+BENCH2="python $ROOT/bench.py --no-cpu-baseline --no-verify $*"      # exactly the default command, minus the CPU leg (callers add --no-clips)
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_default" -o stats -- $BENCH2 > "$OUT/stats_default.log" 2>&1
 # ... and one pipeline alone: every kernel has the chip to itself (this is what the counters describe)
 BENCH="python $ROOT/bench.py --streams 1 --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-verify $*"
