@@ -365,7 +365,7 @@ def main():
         if q_alone:
             achieved = alg_bytes / (q_alone * 1e-3) / 1e9
             default_shape = (W, H, F, args.bits) == (1920, 1080, 30, 8)
-            qname = "k_query_r64" if default_shape else "query kernel of this geometry (DESIGN.md 4)"
+            qname = "k_query_s64" if default_shape else "query kernel of this geometry (DESIGN.md 4)"
             rf = {"bound": "hbm", "kernel": qname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                   "avg_launch_ms": q_alone, "launches_averaged": ALONE_LAUNCHES,
@@ -441,20 +441,21 @@ def check_gathered(og, world, G, pairs, n, res_all):
 
 
 def issue_roofline(W, H, F, bits, breakdown):
-    """Companion to the HBM roofline ('expect the kernel to sit on the integer-ALU ceiling first; report
-    both'): the issue-bound kernels priced opcode by opcode -- the ISA histogram of each kernel's hot loop
-    weighted with the measured issue cost of every opcode (tools/opbench.hip) -- from the committed model file.
-    Only valid for the workload it was derived for."""
-    path = os.path.join(REPO, "profiles", "r02_issue_model.json")
+    """Companion to the HBM roofline ('expect the kernel to sit on the integer-ALU ceiling first; report both'): the VALU-issue
+    bound of the two big kernels -- their VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, committed) at the four cycles per
+    wave-instruction and SIMD of gfx950's 16-lane SIMDs.  Replayed constants, tagged with their source; only valid for the workload
+    they were collected on."""
+    path = os.path.join(REPO, "profiles", "r03_issue_model.json")
     if (W, H, F, bits) != (1920, 1080, 30, 8) or not os.path.exists(path) or not breakdown:
         return None
     with open(path) as f:
         model = json.load(f)
-    out = {"bound": "valu-issue", "source": "profiles/r02_issue_model.json (replayed constants: opcode costs from tools/opbench.hip, histograms from the ISA)"}
-    for kname, key in (("k_query_lds", "query"), ("k_insert_lds", "insert")):
+    out = {"bound": "valu-issue", "cycles_per_valu_wave_instruction": model["cycles_per_valu"],
+           "source": "profiles/r03_issue_model.json (replayed constants: SQ_INSTS_VALU per launch from profiles/r03_rocprofv3_summary.txt)"}
+    for kname, key in (("k_query_s64", "query"), ("k_insert_tab", "insert")):
         m = model.get(kname)
         if m and breakdown.get(key):
-            out[m.get("kernel", kname).split("<")[0]] = {"issue_bound_ms": m["issue_bound_ms"], "launch_ms_alone": breakdown[key], "frac": round(m["issue_bound_ms"] / breakdown[key], 3)}
+            out[kname] = {"valu_bound_ms": m["valu_bound_ms"], "launch_ms_alone": breakdown[key], "frac": round(m["valu_bound_ms"] / breakdown[key], 3)}
     return out
 
 
@@ -462,7 +463,7 @@ def measured_traffic(W, H, F, bits, custom_density):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
     collected in separate --pmc runs and corrected as MI355X_MICROARCH.md prescribes).  A replayed constant,
     tagged with its source; null for any other workload."""
-    for name in ("r02_query_traffic.json", "r01_query_traffic.json"):
+    for name in ("r03_query_traffic.json",):
         path = os.path.join(REPO, "profiles", name)
         if (W, H, F, bits) == (1920, 1080, 30, 8) and not custom_density and os.path.exists(path):
             with open(path) as f:
