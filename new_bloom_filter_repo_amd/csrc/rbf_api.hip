@@ -604,7 +604,7 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     }
     // FP64 geometries that do not fit LDS twice (or whose tile size a test caps): k_query_f64t, double-buffered tiles
     if (!ctx->force_generic && mmax > 0 && sizes_f64 && !ctx->barrett_only && !ctx->single_buffer && !(p.query_kind == 1 && p.f64_mod)) {
-        const uint32_t cap = (uint32_t)(LDS_LIMIT / 4 - 4) & ~3u;            // one buffer of tile_words + 4 dwords
+        const uint32_t cap = (uint32_t)((LDS_LIMIT - S64_GEO_BYTES) / 4 - 4) & ~3u;       // one buffer of tile_words + 4 dwords, k_query_s64t's geometry behind it
         uint32_t tw = (p.fwords_max + 3u) & ~3u;
         if (tw > cap) { const uint32_t nt = (p.fwords_max + cap - 1) / cap; tw = (((p.fwords_max + nt - 1) / nt) + 3u) & ~3u; }
         if (ctx->tile_words && (ctx->tile_words & ~3u) < tw) tw = ctx->tile_words & ~3u;
@@ -895,7 +895,17 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
             if (qtab.f[f].m) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
-        if (!ctx->query_dma) {
+        bool few_probes = true;                                   // k_query_s64t keeps a frame's probe positions in registers
+        for (uint32_t f = 0; f < nframes; ++f) if (tab.f[f].m && tab.f[f].floor_k > S64T_MAX_FK) few_probes = false;
+        if (!ctx->query_dma && !ctx->query_r64 && few_probes) {
+            uint32_t nactive; uint64_t empty[2];
+            const FrameTable stab = query_table_s64(tab, nframes, &nactive, empty);
+            if (quiet_passthrough) empty[0] = empty[1] = 0;
+            if (int r = allow_big_lds((const void *)k_query_s64t<0>)) return r;
+            hipLaunchKernelGGL(k_query_s64t<0>, dim3((uint32_t)bx), dim3(QL_THREADS), s64t_lds_bytes(pl.query_tile_words), ctx->stream,
+                               n, nactive, stab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
+                               ctx->seg_cnt, pl.nseg, ctx->pass_words, empty[0], empty[1]);
+        } else if (!ctx->query_dma) {
             uint32_t passthrough;
             const FrameTable rtab = rank_table(tab, qtab, nframes, &passthrough);
             if (quiet_passthrough) passthrough = 0;

@@ -73,6 +73,13 @@ __device__ __forceinline__ uint32_t select_by(uint64_t mask, uint32_t if_clear, 
     return r;
 }
 
+__device__ __forceinline__ uint32_t select_or_ones(uint64_t mask, uint32_t if_set)       // mask ? if_set : 0xFFFFFFFF (an inline constant: no register)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, -1, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask));
+    return r;
+}
+
 #define RBF_ROW() __builtin_amdgcn_sched_barrier(0)
 
 // The two reductions of the two pixels of pair g, as rows of four: x = {pos0, step} of pixel 2g, {pos0, step} of pixel 2g + 1.
@@ -411,6 +418,280 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
         cur ^= 1u;
         stamp(j, 4);
         stamp(j, 5);
+    }
+    flush();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_query_s64t -- the same kernel for filters that do not fit LDS twice (1440p ... 5K, m < 2^23: BASELINE config 4), walked in TILES
+// of one maximal LDS buffer as k_query_r64t does (rbf_kernels_r64.h), rebuilt on the round-3 cost model: the kernel is VALU-bound at
+// four cycles per wave-instruction, and k_query_r64t spent 116 VALU instructions per (pixel, frame) at 2160p x 8 (rocprofv3
+// SQ_INSTS_VALU, profiles/r03_rocprofv3_summary_2160p.txt): ~20 on converting its 64-bit hashes to doubles again in every frame,
+// ~22 per tile on re-stepping the probe positions.  Here the hashes stay in the (double, low dword) form for the whole launch, a
+// frame's probe positions are computed ONCE (rows of four reductions, exact 32-bit remainders) and kept -- floor(k*) + 1 registers
+// per pixel -- and a tile costs 5 instructions per probe: word index, distance to the tile's first word, unsigned min against the
+// tile length (a probe outside the tile reads the SAFE dword behind it, "bit set"), address, combine.  A pixel whose extra probe
+// is not activated gets position 2^32 - 1 for it, which is in no tile.  Verdicts accumulate as one FAIL bit per pixel across the
+// tiles.  A frame's first tile is staged through registers underneath its reductions (TileStager), the other tiles by LDS-DMA
+// between two barriers.  Only for batches whose coded frames all have floor(k*) <= S64T_MAX_FK (the kept positions are registers); the host sends
+// anything else to k_query_r64t.  Table, outputs and LDS geometry as k_query_s64; LDS: tile_words + 4 dwords, then S64_GEO_BYTES.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t S64T_MAX_FK = 2;
+// dwords before the geometry: the tile and its SAFE dwords, or the prologue's copy of the sorted thresholds where a test caps the tile below it
+__host__ __device__ constexpr uint32_t s64t_geo_word(uint32_t tile_words) { return tile_words + 4u > 4u * MAX_BATCH ? tile_words + 4u : 4u * MAX_BATCH; }
+__host__ constexpr size_t s64t_lds_bytes(uint32_t tile_words) { return (size_t)s64t_geo_word(tile_words) * 4 + S64_GEO_BYTES; }
+
+// Two register slots (8 VGPRs) that carry a frame's FIRST tile into the LDS buffer underneath the frame's reductions: up to ten
+// 16-byte pieces per lane (a 160 KB buffer over 16 waves x 1 KiB), two loaded at one step and written at the next.  Clamped offsets instead of branches, as RowStager (rbf_kernels_r64.h).
+struct TileStager {
+    const uint8_t *row;             // the tile's first byte in the image row (uniform)
+    uint32_t lds_base;              // byte address of the buffer (uniform)
+    uint32_t last;                  // tile bytes - 16 (uniform): the clamp
+    uint32_t off0;                  // wave * 1024 + lane * 16
+    uint4 a, b;
+
+    __device__ __forceinline__ uint32_t off(int i) const { return min(off0 + (uint32_t)i * (QL_WAVES * 1024u), last); }
+    __device__ __forceinline__ uint4 load(int i) const { return *reinterpret_cast<const uint4 *>(row + off(i)); }
+    __device__ __forceinline__ void store(int i, const uint4 &v) const
+    {
+        *reinterpret_cast<__attribute__((address_space(3))) r64_u32x4 *>((uintptr_t)(lds_base + off(i))) = r64_u32x4{v.x, v.y, v.z, v.w};
+    }
+    template <int AB>
+    __device__ __forceinline__ void at(int g)
+    {
+        if (AB & 8) return;
+        if (g == 0) { a = load(0); b = load(1); }                // step 0: in front of the barrier that frees the buffer (loads only)
+        else if (g < 5) { store(2 * g - 2, a); store(2 * g - 1, b); a = load(2 * g); b = load(2 * g + 1); }      // step 1: right behind it; 2..4: pairs 1..3
+        else { store(8, a); store(9, b); }
+    }
+};
+
+template <int FK, int AB>
+__device__ __forceinline__ void tiled_positions(const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
+                                                uint32_t rank_lo, uint32_t rank_hi, uint32_t c, uint32_t m, double ninv, uint32_t (&pos)[QL_P][S64T_MAX_FK + 1], TileStager &st)
+{
+    // Pixel by pixel, two chains (position, step) side by side -- not the rows of four of k_query_s64: four reductions in flight are
+    // 16 more live registers, which this kernel does not have (the hashes, the kept positions and the stager's slots: ~105 of 128).
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) {
+        if (it == 0) st.template at<AB>(0); else if ((it & 1) == 0) st.template at<AB>(it / 2 + 1);
+        uint32_t p, stp;
+        if (AB & 1) { p = hl1[it] & 0x7FFFFu; stp = hl2[it] & 0x3FFFFu; }
+        else {
+            const double t0 = __builtin_fma(hd1[it], ninv, 0x1.8p52), t1 = __builtin_fma(hd2[it], ninv, 0x1.8p52);
+            const uint32_t s0 = (uint32_t)__builtin_bit_cast(uint64_t, t0) * m + hl1[it], s1 = (uint32_t)__builtin_bit_cast(uint64_t, t1) * m + hl2[it];   // rows_reduce4
+            p = min(s0, s0 + m); stp = min(s1, s1 + m);
+        }
+        if (it == 0) {
+            if (!(AB & 32)) __syncthreads();                      // every wave has finished the previous frame's last tile: the buffer is free
+            st.template at<AB>(1);
+        }
+#pragma unroll
+        for (int j = 0; j < FK; ++j) {
+            pos[it][j] = p;
+            const uint32_t u = p + stp;
+            p = min(u, u - m);
+        }
+        const uint32_t rk = it < 4 ? rank_lo : rank_hi;
+        const uint64_t k = (it & 3) == 0 ? rank_le<0>(rk, c) : (it & 3) == 1 ? rank_le<1>(rk, c) : (it & 3) == 2 ? rank_le<2>(rk, c) : rank_le<3>(rk, c);
+        pos[it][FK] = select_or_ones(k, p);                       // activated, or "in no tile"
+    }
+}
+
+// One tile's probes of a lane's 8 pixels (pairs, rows of 2 x (FK + 1) probes): the FAIL bits of the tile, MSB-first (bit 7 - it).
+template <int FK, int AB>
+__device__ __forceinline__ uint32_t tiled_pass(const uint32_t (&pos)[QL_P][S64T_MAX_FK + 1], uint32_t lds_base_bytes, uint32_t tile_word0, uint32_t tile_words)
+{
+    constexpr int NP = FK + 1;
+    uint32_t five = 5u;
+    asm volatile("" : "+s"(five));
+    uint32_t pbf = 0;
+    // One pair's words at a time: the other three waves of the SIMD cover the LDS latency (profiles/r03_query_ablation.txt: the
+    // depth of the read pipeline of k_query_s64 does not show in its time), and the registers are needed for the kept positions.
+    uint32_t wrd[2][NP];
+#pragma unroll
+    for (int g = 0; g < QL_P / 2; ++g) {
+        // (no wave priorities here: with k_query_s64's progress-tied s_setprio this kernel measured 282 us instead of 214 at 2160p x 8 --
+        // the waves still issuing their share of the next tile's LDS-DMA wait behind the ones already probing; tools/bench_query4.hip)
+        if (AB & 2048) { if (g == 0) __builtin_amdgcn_s_setprio(3); else if (g == 1) __builtin_amdgcn_s_setprio(2); else if (g == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t wa = pos[2 * g][j] >> five, wb = pos[2 * g + 1][j] >> five;
+            RBF_ROW();
+            const uint32_t ra = wa - tile_word0, rb = wb - tile_word0;
+            RBF_ROW();
+            const uint32_t ia = min(ra, tile_words), ib = min(rb, tile_words);        // in this tile, or the SAFE dword behind it
+            RBF_ROW();
+            const uint32_t aa = (ia << 2) + lds_base_bytes, ab = (ib << 2) + lds_base_bytes;
+            RBF_ROW();
+            wrd[0][j] = (AB & 2) ? aa * 0x9E3779B1u : *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)aa);
+            wrd[1][j] = (AB & 2) ? ab * 0x9E3779B1u : *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)ab);
+            RBF_ROW();
+        }
+        uint32_t f0 = 0u, f1 = 0u;
+        if (!(AB & 2)) __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0), once per pair
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f0 = (wrd[0][j] << (pos[2 * g][j] & 31u)) | f0;
+            f1 = (wrd[1][j] << (pos[2 * g + 1][j] & 31u)) | f1;
+            RBF_ROW();
+        }
+        pbf = __builtin_amdgcn_alignbit(pbf, f0, 31);
+        RBF_ROW();
+        pbf = __builtin_amdgcn_alignbit(pbf, f1, 31);
+        RBF_ROW();
+    }
+    return pbf;
+}
+
+// One coded frame of k_query_s64t: the probe positions (no filter needed) with the frame's first tile riding into LDS underneath them
+// through registers (the barrier that frees the buffer is inside, after the first pixel pair), the previous frame's outputs
+// (`flush`), then the tiles.  Returns the FAIL bits of the lane's 8 pixels.
+template <int FK, int AB, typename FLUSH>
+__device__ __forceinline__ uint32_t tiled_frame(const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
+                                                uint32_t rank_lo, uint32_t rank_hi, uint32_t c_v, uint32_t m_v, double ninv, TileStager &st,
+                                                const uint32_t *row, uint32_t fwords, uint32_t tile_words, uint32_t lds_base, uint32_t fbase, uint32_t wave, uint32_t lane, FLUSH &&flush)
+{
+    uint32_t pos[QL_P][S64T_MAX_FK + 1];
+    const uint32_t ntiles = (fwords + tile_words - 1) / tile_words;
+    st.row = reinterpret_cast<const uint8_t *>(row);
+    st.last = (((fwords < tile_words ? fwords : tile_words) + 3u) & ~3u) * 4u - 16u;
+    tiled_positions<FK, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, pos, st);
+    st.template at<AB>(5);
+    flush();
+    uint32_t pbf = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const uint32_t w0 = t * tile_words;
+        if (t) {                                  // the other tiles have nothing to ride under: LDS-DMA between two barriers
+            const uint32_t words = fwords - w0 < tile_words ? fwords - w0 : tile_words;
+            if (!(AB & 32)) __syncthreads();      // the previous tile's probes are done
+            if (!(AB & 8)) dma_row(lds_base, row + w0, words, wave, lane, QL_WAVES);
+            if (!(AB & 32)) dma_wait_all();       // my share has landed ...
+        } else if (!(AB & 32)) __builtin_amdgcn_s_waitcnt(0xC07F);          // my pieces are written (lgkmcnt(0)) ...
+        if (!(AB & 32)) __syncthreads();          // ... and everyone's
+        pbf |= tiled_pass<FK, AB>(pos, fbase, w0, tile_words);
+    }
+    return pbf;
+}
+
+template <int AB = 0>
+__global__ __launch_bounds__(QL_THREADS) void k_query_s64t(
+    uint64_t n, uint32_t nactive, const FrameTable tab /* as for k_query_s64 */, Seeds seeds,
+    const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t tile_words /* multiple of 4 */,
+    uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words, uint64_t empty_lo, uint64_t empty_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: so are seg and live)
+    const uint64_t seg = (uint64_t)blockIdx.x * QL_WAVES + wave;
+    const bool live = seg < nseg;
+    uint4 *geo = reinterpret_cast<uint4 *>(lds + s64t_geo_word(tile_words));
+    uint64_t *tl = reinterpret_cast<uint64_t *>(lds);              // sorted thresholds: the tile buffer is free until the first tile lands
+    FrameDev fd_mine{};
+    if (threadIdx.x < 2u * MAX_BATCH) fd_mine = tab.f[threadIdx.x < nactive ? threadIdx.x : 0u];
+
+    double hd1[QL_P], hd2[QL_P];
+    uint32_t hl1[QL_P], hl2[QL_P];
+    uint32_t rank_lo = 0, rank_hi = 0;
+    uint32_t validmask = 0;
+    const uint64_t i0 = seg * QL_SEG_PIXELS + (uint64_t)lane * QL_P;
+    {
+        uint64_t h1[QL_P], h2[QL_P], ha[QL_P];
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
+            if (live && i0 + it < n) validmask |= 1u << it;
+        }
+        if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) {
+                const bool act = (validmask >> it) & 1u;
+                const Hash3 h = hash3_index((uint32_t)(i0 + it), act, seeds);
+                h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) {
+            hd1[it] = (double)h1[it]; hl1[it] = (uint32_t)h1[it];
+            hd2[it] = (double)h2[it]; hl2[it] = (uint32_t)h2[it];
+            asm volatile("" : "+v"(hd1[it]), "+v"(hd2[it]));      // converted HERE: the 64-bit forms die before the search (else they spill)
+        }
+        if (threadIdx.x < 2u * MAX_BATCH) {
+            tl[threadIdx.x] = threadIdx.x < nactive ? fd_mine.T : ~0ull;
+            if (threadIdx.x < nactive) geo[threadIdx.x] = make_uint4(fd_mine.m, fd_mine.floor_k, (uint32_t)fd_mine.M, (uint32_t)(fd_mine.M >> 32));
+        }
+        __syncthreads();
+        uint32_t top = 1;
+        while (2u * top <= nactive) top *= 2u;
+        top = __builtin_amdgcn_readfirstlane(top);
+        uint32_t r[QL_P];
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) r[it] = 0;
+        for (uint32_t step = top; step; step >>= 1) {
+#pragma unroll
+            for (int it = 0; it < QL_P; ++it) {
+                const uint64_t t = tl[r[it] + step - 1u];
+                r[it] |= t <= ha[it] ? step : 0u;
+            }
+        }
+        rank_lo = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        rank_hi = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        __syncthreads();                          // everyone has read the thresholds before the first tile lands on them
+    }
+    if (threadIdx.x < 4u) lds[tile_words + threadIdx.x] = 0u;    // SAFE (after the search: the thresholds lay over the buffer)
+    uint32_t invalid_byte = 0;                                    // bit 7-j: pixel j is not a position of the frame -> must fail
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) invalid_byte |= ((validmask >> it) & 1u) ? 0u : (0x80u >> it);
+    uint8_t *pass_bytes = reinterpret_cast<uint8_t *>(pass_words);
+
+    for (uint32_t half = 0; half < 2; ++half) {                   // frames that are not coded: nothing passes
+        uint64_t bits = half ? empty_hi : empty_lo;
+        while (bits) {
+            const uint32_t g = half * 64u + (uint32_t)__builtin_ctzll(bits);
+            bits &= bits - 1;
+            if (live && lane == 0) seg_cnt[(uint64_t)g * nseg + seg] = 0;
+            if (live) pass_bytes[((uint64_t)g * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = 0;
+        }
+    }
+    if (nactive == 0) return;
+
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    const uint32_t fbase = vgpr_copy(lds_base);
+    const uint64_t pb_stride = nseg * (QL_SEG_PIXELS / 8);
+    uint32_t out_pb = 0, out_f = 0;
+    bool out_pending = false;
+    auto flush = [&]() {                                          // the previous frame's verdict byte and pass count (as k_query_s64)
+        if (!out_pending) return;
+        const uint32_t cnt = __popc(out_pb);
+        const uint32_t npass = __popcll(__ballot((cnt & 1u) != 0)) + 2u * __popcll(__ballot((cnt & 2u) != 0)) + 4u * __popcll(__ballot((cnt & 4u) != 0)) + 8u * __popcll(__ballot((cnt & 8u) != 0));
+        if (live) {                                               // (addresses rebuilt here: two 64-bit pointers per lane would not fit beside the positions)
+            pass_bytes[(uint64_t)out_f * pb_stride + seg * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)out_pb;
+            if (lane == 0) seg_cnt[(uint64_t)out_f * nseg + seg] = npass;
+        }
+    };
+
+    TileStager st;
+    st.a = st.b = make_uint4(0, 0, 0, 0);
+    st.off0 = wave * 1024u + lane * 16u;
+    st.lds_base = lds_base;
+    for (uint32_t j = 0; j < nactive; ++j) {
+        const uint4 gv = geo[j];
+        const uint32_t m_s = __builtin_amdgcn_readfirstlane(gv.x), fkc = __builtin_amdgcn_readfirstlane(gv.y);
+        const uint32_t m_v = vgpr_copy(m_s);
+        const double ninv = __builtin_bit_cast(double, ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(gv.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(gv.z));
+        const uint32_t fk = fkc & 0xFFu, f = fkc >> 16;
+        const uint32_t c_v = vgpr_copy((fkc >> 8) & 0xFFu);
+        const uint32_t fwords = filter_words(m_s);
+        const uint32_t *row = image + (uint64_t)f * image_stride_words32;
+        // One instantiation of the whole frame per floor(k*): with the switch around the two halves instead, the kept positions
+        // meet in 24 phi nodes between them and the register allocator spills the hashes (198 dwords).
+        uint32_t pbf;
+        switch (fk) {
+        case 0: pbf = tiled_frame<0, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, st, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
+        case 1: pbf = tiled_frame<1, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, st, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
+        default: pbf = tiled_frame<2, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, st, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
+        }
+        out_pb = ~(pbf | invalid_byte) & 0xFFu; out_f = f; out_pending = true;
     }
     flush();
 }

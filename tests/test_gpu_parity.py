@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module", params=["lds_double_buffer", "lds_query_r64", "lds_dma_query", "lds_single_buffer", "lds_barrett_only", "lds_query_p4", "hash_in_insert", "lds_tiled_1KiB", "lds_tiled_8KiB",
-                                        "lds_tiled_8KiB_insert_tab", "lds_tiled_8KiB_dma_query", "generic"])
+                                        "lds_tiled_8KiB_insert_tab", "lds_tiled_8KiB_dma_query", "lds_tiled_8KiB_query_r64", "generic"])
 def eng(request):
     """Every kernel family must be bit-exact: the LDS-resident fast path (default whenever the filter
     fits in LDS; with and without filter double-buffering), the LDS-tiled path that 4K-class filters
@@ -25,15 +25,16 @@ def eng(request):
     integer Barrett reductions, so both forms are pinned to the same fixtures.  The default FP64 kernel is k_query_s64 (round 3: pass in
     rows, frame geometry in LDS); "lds_query_r64" selects k_query_r64 (round 2: probe image staged through registers, activation
     ranks), "lds_dma_query" its predecessor k_query_f64 (LDS-DMA staging, 64-bit
-    activation hashes); with tiles the pair is k_query_r64t / k_query_f64t ("lds_tiled_8KiB_dma_query").  "lds_query_p4" selects the 4-pixels-per-
+    activation hashes); with tiles the default is k_query_s64t where every coded frame of the batch has floor(k*) <= 2 (probe positions kept in
+    registers across the tiles) and k_query_r64t otherwise or on request ("lds_tiled_8KiB_query_r64"), then k_query_f64t ("lds_tiled_8KiB_dma_query").  "lds_query_p4" selects the 4-pixels-per-
     lane FP64 query kernel, "hash_in_insert" the insert kernel that hashes the set positions itself instead of gathering
     from the pixel-index hash table.  With tiles, rbf_encode_gop (which knows the masks' set-bit counts) inserts through
     k_insert_positions + k_insert_records; "lds_tiled_8KiB_insert_tab" keeps the tiled k_insert_tab there too."""
     ctx = nat.Context(0)
-    if request.param == "lds_query_r64":
+    if request.param in ("lds_query_r64", "lds_tiled_8KiB_query_r64"):
         ctx.option(nat.OPT_QUERY_R64, 1)
     ctx.force_generic({"lds_double_buffer": 0, "lds_query_r64": 0, "lds_dma_query": 1 << 13, "lds_single_buffer": 2, "lds_barrett_only": 8, "lds_query_p4": 64, "hash_in_insert": 32, "lds_tiled_1KiB": 4 << 16, "lds_tiled_8KiB": 32 << 16,
-                       "lds_tiled_8KiB_insert_tab": (32 << 16) | 128, "lds_tiled_8KiB_dma_query": (32 << 16) | (1 << 13),
+                       "lds_tiled_8KiB_insert_tab": (32 << 16) | 128, "lds_tiled_8KiB_dma_query": (32 << 16) | (1 << 13), "lds_tiled_8KiB_query_r64": 32 << 16,
                        "generic": 1}[request.param])
     e = BloomEngine(ctx)
     yield e
