@@ -433,8 +433,12 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
 // per pixel -- and a tile costs 5 instructions per probe: word index, distance to the tile's first word, unsigned min against the
 // tile length (a probe outside the tile reads the SAFE dword behind it, "bit set"), address, combine.  A pixel whose extra probe
 // is not activated gets position 2^32 - 1 for it, which is in no tile.  Verdicts accumulate as one FAIL bit per pixel across the
-// tiles.  A frame's first tile is staged through registers underneath its reductions (TileStager), the other tiles by LDS-DMA
-// between two barriers.  Only for batches whose coded frames all have floor(k*) <= S64T_MAX_FK (the kept positions are registers); the host sends
+// tiles.  Staging: LDS-DMA, the first tile issued in steps between the frame's reductions (TileDma), the others between two barriers.
+// It does not hide: 2160p x 8 frames measures 150 us without staging and 217 with (tools/bench_query4.hip, profiles/
+// r03_query_tiled_ablation.txt) -- 64 (workgroup, tile) stages per CU x 153 KB = 2.5 GB per launch from L2 at 37 TB/s, which is both
+// the L2s' aggregate peak (8 XCDs x 16 channels x 128 B/clk) and the CUs' L1 rate (64 B/clk each); staging the first tile through
+// registers (TileStager, AB & 4096) measures the same.  Two half-size buffers would hide it but double the tile passes (+40 us).
+// Only for batches whose coded frames all have floor(k*) <= S64T_MAX_FK (the kept positions are registers); the host sends
 // anything else to k_query_r64t.  Table, outputs and LDS geometry as k_query_s64; LDS: tile_words + 4 dwords, then S64_GEO_BYTES.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t S64T_MAX_FK = 2;
@@ -467,9 +471,37 @@ struct TileStager {
     }
 };
 
-template <int FK, int AB>
+// The same through LDS-DMA: no registers, no wait between a piece's load and its LDS write -- each step only ISSUES its pieces
+// (four right behind the barrier, two in front of pixels 2, 4 and 6), and the frame waits once, after its reductions.
+struct TileDma {
+    const uint32_t *row;            // the tile's first dword in the image row (uniform)
+    uint32_t lds_base;              // byte address of the buffer (uniform)
+    uint32_t npieces;               // 16-byte pieces of the tile (uniform; the image rows are padded to whole pieces)
+    uint32_t wave, lane;
+
+    __device__ __forceinline__ void piece(uint32_t i) const      // piece row wave + 16 i of the tile: 1 KiB, one 16-byte piece per lane
+    {
+        const uint32_t c = wave + i * QL_WAVES;
+        if ((c << 6) + 64u <= npieces || (c << 6) + lane < npieces) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (c << 10));
+            const uint32_t off = (lane << 4) + (c << 10);
+            uint32_t keep;                                        // M0 is saved and restored inside the block (dma_row, rbf_kernels_q64.h)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(off), "s"(row) : "memory");
+        }
+    }
+    template <int AB>
+    __device__ __forceinline__ void at(int step)
+    {
+        if (AB & 8) return;
+        if (step == 1) { piece(0); piece(1); piece(2); piece(3); }
+        else if (step >= 2 && step <= 4) { piece(2 * step); piece(2 * step + 1); }
+    }
+};
+
+template <int FK, int AB, typename STAGER>
 __device__ __forceinline__ void tiled_positions(const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
-                                                uint32_t rank_lo, uint32_t rank_hi, uint32_t c, uint32_t m, double ninv, uint32_t (&pos)[QL_P][S64T_MAX_FK + 1], TileStager &st)
+                                                uint32_t rank_lo, uint32_t rank_hi, uint32_t c, uint32_t m, double ninv, uint32_t (&pos)[QL_P][S64T_MAX_FK + 1], STAGER &st)
 {
     // Pixel by pixel, two chains (position, step) side by side -- not the rows of four of k_query_s64: four reductions in flight are
     // 16 more live registers, which this kernel does not have (the hashes, the kept positions and the stager's slots: ~105 of 128).
@@ -546,19 +578,29 @@ __device__ __forceinline__ uint32_t tiled_pass(const uint32_t (&pos)[QL_P][S64T_
 }
 
 // One coded frame of k_query_s64t: the probe positions (no filter needed) with the frame's first tile riding into LDS underneath them
-// through registers (the barrier that frees the buffer is inside, after the first pixel pair), the previous frame's outputs
+// (the barrier that frees the buffer is inside, after the first pixel), the previous frame's outputs
 // (`flush`), then the tiles.  Returns the FAIL bits of the lane's 8 pixels.
 template <int FK, int AB, typename FLUSH>
 __device__ __forceinline__ uint32_t tiled_frame(const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
-                                                uint32_t rank_lo, uint32_t rank_hi, uint32_t c_v, uint32_t m_v, double ninv, TileStager &st,
+                                                uint32_t rank_lo, uint32_t rank_hi, uint32_t c_v, uint32_t m_v, double ninv,
                                                 const uint32_t *row, uint32_t fwords, uint32_t tile_words, uint32_t lds_base, uint32_t fbase, uint32_t wave, uint32_t lane, FLUSH &&flush)
 {
     uint32_t pos[QL_P][S64T_MAX_FK + 1];
     const uint32_t ntiles = (fwords + tile_words - 1) / tile_words;
-    st.row = reinterpret_cast<const uint8_t *>(row);
-    st.last = (((fwords < tile_words ? fwords : tile_words) + 3u) & ~3u) * 4u - 16u;
-    tiled_positions<FK, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, pos, st);
-    st.template at<AB>(5);
+    const uint32_t words0 = ((fwords < tile_words ? fwords : tile_words) + 3u) & ~3u;
+    if (AB & 4096) {                              // tools/bench_query4.hip: the first tile through registers
+        TileStager st;
+        st.a = st.b = make_uint4(0, 0, 0, 0);
+        st.off0 = wave * 1024u + lane * 16u;
+        st.lds_base = lds_base;
+        st.row = reinterpret_cast<const uint8_t *>(row);
+        st.last = words0 * 4u - 16u;
+        tiled_positions<FK, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, pos, st);
+        st.template at<AB>(5);
+    } else {
+        TileDma st{row, lds_base, words0 >> 2, wave, lane};
+        tiled_positions<FK, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, pos, st);
+    }
     flush();
     uint32_t pbf = 0;
     for (uint32_t t = 0; t < ntiles; ++t) {
@@ -568,7 +610,7 @@ __device__ __forceinline__ uint32_t tiled_frame(const double (&hd1)[QL_P], const
             if (!(AB & 32)) __syncthreads();      // the previous tile's probes are done
             if (!(AB & 8)) dma_row(lds_base, row + w0, words, wave, lane, QL_WAVES);
             if (!(AB & 32)) dma_wait_all();       // my share has landed ...
-        } else if (!(AB & 32)) __builtin_amdgcn_s_waitcnt(0xC07F);          // my pieces are written (lgkmcnt(0)) ...
+        } else if (!(AB & 32)) { if (AB & 4096) __builtin_amdgcn_s_waitcnt(0xC07F); else dma_wait_all(); }      // my pieces of the first tile have landed ...
         if (!(AB & 32)) __syncthreads();          // ... and everyone's
         pbf |= tiled_pass<FK, AB>(pos, fbase, w0, tile_words);
     }
@@ -670,10 +712,6 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64t(
         }
     };
 
-    TileStager st;
-    st.a = st.b = make_uint4(0, 0, 0, 0);
-    st.off0 = wave * 1024u + lane * 16u;
-    st.lds_base = lds_base;
     for (uint32_t j = 0; j < nactive; ++j) {
         const uint4 gv = geo[j];
         const uint32_t m_s = __builtin_amdgcn_readfirstlane(gv.x), fkc = __builtin_amdgcn_readfirstlane(gv.y);
@@ -687,9 +725,9 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64t(
         // meet in 24 phi nodes between them and the register allocator spills the hashes (198 dwords).
         uint32_t pbf;
         switch (fk) {
-        case 0: pbf = tiled_frame<0, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, st, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
-        case 1: pbf = tiled_frame<1, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, st, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
-        default: pbf = tiled_frame<2, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, st, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
+        case 0: pbf = tiled_frame<0, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
+        case 1: pbf = tiled_frame<1, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
+        default: pbf = tiled_frame<2, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, row, fwords, tile_words, lds_base, fbase, wave, lane, flush); break;
         }
         out_pb = ~(pbf | invalid_byte) & 0xFFu; out_f = f; out_pending = true;
     }

@@ -90,6 +90,7 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 2; ++rep) {
         ROW(R64T, 0, "k_query_r64t");
         ROW(S64T, 0, "k_query_s64t");
+        ROW(S64T, 4096, "k_query_s64t, first tile through registers");
         ROW(S64T, 2048, "k_query_s64t with k_query_s64's wave priorities");
     }
     for (uint32_t ff : {1u, 2u, 4u, 8u})
