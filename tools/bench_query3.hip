@@ -143,6 +143,14 @@ int main(int argc, char **argv)
     printf("pure passes, k_query_s64: 4 waves/SIMD %6.1f | 2 waves/SIMD %6.1f | 1 wave/SIMD %6.1f us\n",
            run<8 | 32>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), run<8 | 32, S64, 512>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb),
            run<8 | 32, S64, 256>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb));
+    // the same ablations per occupancy (512- and 256-thread workgroups run 2 and 4 rounds on the 256 CUs): does the pass follow its VALU count anywhere?
+#define OCC(T, name) printf("pure passes at %s: all %6.1f | no reductions %6.1f | no LDS reads %6.1f | none of the three %6.1f | no hashing %6.1f | 1 frame %6.1f us\n", name, \
+        run<8 | 32, S64, T>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), run<8 | 32 | 1, S64, T>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), \
+        run<8 | 32 | 2, S64, T>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), run<8 | 32 | 1 | 2 | 4, S64, T>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), \
+        run<8 | 32 | 16, S64, T>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), run<8 | 32, S64, T>(n, 1, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb))
+    OCC(1024, "4 waves/SIMD");
+    OCC(512, "2 waves/SIMD");
+    OCC(256, "1 wave/SIMD ");
     printf("full kernel, k_query_s64: 1024-thread workgroups %6.1f | 512 %6.1f us\n",
            run<0>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), run<0, S64, 512>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb));
     return 0;

@@ -2,6 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03final; mkdir -p $O
 ./build/bench_query3 2 > $O/bench_query3.txt 2>&1
+./build/bench_query4 > $O/bench_query4.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --no-cpu-baseline --no-clips --interleaved 2>/dev/null | tail -1 > $O/bench_interleaved.json
 python bench.py --no-cpu-baseline --no-clips --bits 16 2>/dev/null | tail -1 > $O/bench_uint16.json

@@ -45,12 +45,21 @@ while time.time() < t_end:
         frames = np.ascontiguousarray(frames[..., 0])
     n = W * H
     desc = dict(seed=seed, case=cases, knob=knob, W=W, H=H, C=C, dtype=np.dtype(dtype).name, F=F, seeds=seeds, thr=thr)
+    # round 3: planar luma block (device de-interleave at upload), a resident-GOP slot other than 0, k_query_r64 / r64t instead of
+    # k_query_s64 / s64t, the separate finish launch instead of the mask kernel's fused tail
+    planar = bool(rng.random() < 0.5)
+    slots = int(rng.integers(1, 4)) if planar else 1
+    slot = int(rng.integers(0, slots))
+    opts = (int(rng.random() < 0.25), int(rng.random() < 0.25))
+    desc.update(planar=planar, slot=slot, slots=slots, query_r64=opts[0], separate_finish=opts[1])
     ctx = nat.Context(0)
     ctx.force_generic(knob)
+    ctx.option(nat.OPT_QUERY_R64, opts[0])
+    ctx.option(nat.OPT_SEPARATE_FINISH, opts[1])
     eng = BloomEngine(ctx)
-    coder = GopCoder(ctx, W, H, F, channels=C, sample_bytes=np.dtype(dtype).itemsize, seeds=seeds, threshold=thr)
-    coder.load_frames(frames)
-    coder.encode()
+    coder = GopCoder(ctx, W, H, F, channels=C, sample_bytes=np.dtype(dtype).itemsize, seeds=seeds, threshold=thr, planar_luma=planar, resident_gops=slots)
+    coder.load_frames(frames, gop=slot) if planar else coder.load_frames(frames)
+    coder.encode(slot) if planar else coder.encode()
     block = coder.pack()
     res = coder.results()
     recs = unpack_device_record(block.numpy(ctx), n)

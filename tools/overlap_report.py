@@ -2,7 +2,7 @@
 """overlap_report.py <kernel_trace.csv> -- how much do the kernels of the bench's pipelines overlap on the GPU?
 
 Reads a rocprofv3 --kernel-trace CSV (Kernel_Name, Start_Timestamp, End_Timestamp, Queue_Id/Stream_Id ...), keeps the
-steady-state part (drops the first and last 10 % of the time span) and prints: the sum of the kernel durations, the
+timed region (the densest half of the query launches) and prints: the sum of the kernel durations, the
 length of the union of their intervals (= GPU busy time), the idle time, and, per kernel, how much of its running time
 it shared with at least one other kernel and with which."""
 import csv
@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("k_query_s64", "k_query_r64t", "k_query_r64", "k_query_f64t", "k_query_f64", "k_insert_tab", "k_insert_positions", "k_insert_records", "k_residual_mask_gop", "k_compact_witness",
+    for key in ("k_query_s64t", "k_query_s64", "k_query_r64t", "k_query_r64", "k_query_f64t", "k_query_f64", "k_insert_tab", "k_insert_positions", "k_insert_records", "k_residual_mask_gop", "k_compact_witness",
                 "k_filter_reduce", "k_finish_ones", "k_hash_table", "k_pack"):
         if key in name:
             return key
@@ -24,9 +24,12 @@ def main(path):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    q = [r for r in rows if r[2].startswith("k_query_")] or rows       # the bench's own time span
-    t0, t1 = q[0][0], max(r[1] for r in q)
-    lo, hi = t0 + (t1 - t0) // 10, t1 - (t1 - t0) // 10
+    # the timed region = the densest run of query launches (the bench also launches kernels, sparsely, before and after it: warm-up,
+    # PCIe legs): the window of half of all query launches, consecutive, that spans the least time
+    q = [r for r in rows if r[2].startswith("k_query_")] or rows
+    k = max(1, len(q) // 2)
+    best = min(range(len(q) - k + 1), key=lambda i: q[i + k - 1][1] - q[i][0])
+    lo, hi = q[best][0], q[best + k - 1][1]
     rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
     total = sum(e - s for s, e, _ in rows)
     # sweep line
