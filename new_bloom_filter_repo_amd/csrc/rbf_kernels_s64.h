@@ -47,6 +47,14 @@ struct RowStager2 {
     __device__ __forceinline__ void at(int g)
     {
         if (AB & 8) return;
+        if (AB & 8192) {                         // staggered: a piece is written two pairs after its load was issued (the first one: one)
+            if (g == 0) { a = load(0); b = load(1); }
+            else if (g == 1) { store(0, a); a = load(2); }
+            else if (g == 2) { store(1, b); b = load(3); }
+            else if (g == 3) { store(2, a); a = load(4); }
+            else { store(3, b); store(4, a); }
+            return;
+        }
         if (g == 0) { a = load(0); b = load(1); }
         else if (g == 1) { store(0, a); store(1, b); a = load(2); b = load(3); }
         else if (g == 2) { store(2, a); store(3, b); a = load(4); }
@@ -82,6 +90,8 @@ __device__ __forceinline__ uint32_t select_or_ones(uint64_t mask, uint32_t if_se
 
 #define RBF_ROW() __builtin_amdgcn_sched_barrier(0)
 
+__device__ uint64_t *g_query_rowstamps = nullptr;      // tools/bench_query3.hip, AB & 4096: [first / last wave of workgroup 0][frame][16]
+
 // The two reductions of the two pixels of pair g, as rows of four: x = {pos0, step} of pixel 2g, {pos0, step} of pixel 2g + 1.
 // Needs no filter image, so the kernel runs pair 0's IN FRONT of the frame's barrier.
 template <int AB>
@@ -115,7 +125,7 @@ template <int FK, int AB, typename STAGER, typename HOOK>
 __device__ __forceinline__ void frame_pass_rows(
     const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
     uint32_t rank_lo, uint32_t rank_hi, uint32_t c /* VGPR */, uint32_t lds_base_bytes /* VGPR */, uint32_t safe_pos /* VGPR */, uint32_t m /* VGPR */, double ninv,
-    uint32_t (&x)[4], uint32_t &pbf, STAGER &st, HOOK &&after_first_reads)
+    uint32_t (&x)[4], uint32_t &pbf, STAGER &st, HOOK &&after_first_reads, uint64_t (&ts)[16] /* AB & 4096: s_memtime at 13 points of the pass */)
 {
     static_assert(FK >= 1, "at least one deterministic probe");
     constexpr int NP = FK + 1, NG = QL_P / 2;
@@ -177,22 +187,34 @@ __device__ __forceinline__ void frame_pass_rows(
     // the other (timeline: the oldest wave's pass takes 2 400 cycles, the youngest's 4 200) and the youngest finishes alone, at the
     // one instruction per ~5 cycles a single wave can issue, while fifteen waves stand at the barrier.  With the priority tied to
     // progress the waves behind are served first and all four finish together.
+    // (AB & 4096, tools/bench_query3.hip: the shader clock at 13 points of the pass, read without waiting -- s_memtime returns through
+    // lgkmcnt, i.e. with the pass's own waits -- and stored by the kernel after the pass)
+#define RBF_STAMP(i) do { if (AB & 4096) { asm volatile("s_memtime %0" : "=s"(ts[i])); RBF_ROW(); } } while (0)
+    RBF_STAMP(0);
     if (!(AB & 2048)) __builtin_amdgcn_s_setprio(3);
     steps_and_reads(0, x);
     st.template at<AB>(0);
     RBF_ROW();
+    RBF_STAMP(1);
     after_first_reads();
     RBF_ROW();
+    RBF_STAMP(2);
 #pragma unroll
     for (int g = 1; g < NG; ++g) {
         if (!(AB & 2048)) { if (g == 1) __builtin_amdgcn_s_setprio(2); else if (g == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         rows_reduce4<AB>(g, hd1, hl1, hd2, hl2, m, ninv, x);      // the reads of pair g - 1 fly under these rows
+        RBF_STAMP(3 * g);
         combine2(g - 1);
+        RBF_STAMP(3 * g + 1);
         steps_and_reads(g, x);
         st.template at<AB>(g);
         RBF_ROW();
+        RBF_STAMP(3 * g + 2);
     }
     combine2(NG - 1);
+    st.template at<AB>(4);
+    RBF_STAMP(12);
+#undef RBF_STAMP
 }
 
 // Any floor(k*) and partial waves (positions past the end of the frame must fail): pixel by pixel, probes in a loop.
@@ -218,6 +240,7 @@ __device__ __forceinline__ void frame_pass_plain(
         fail = (probe_image_word<0>(lds_base_bytes, pc) << (pc & 31u)) | fail;
         pbf = __builtin_amdgcn_alignbit(pbf, fail, 31);
     }
+    st.template at<AB>(4);
 }
 
 // FrameTable as this kernel reads it (host: query_table_s64, rbf_api.hip) -- COMPACTED over the coded frames of the batch:
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
     Geo cg = geometry_take(0, geometry_issue(0));
     // the first frame's image: staged in one go (once per launch)
     aim(cg, 0u);
-    st.template at<AB>(0); st.template at<AB>(1); st.template at<AB>(2); st.template at<AB>(3);
+    st.template at<AB>(0); st.template at<AB>(1); st.template at<AB>(2); st.template at<AB>(3); st.template at<AB>(4);
     uint32_t cur = 0;
     const uint32_t safe_v = vgpr_copy(safe_pos);
     // where my verdict byte / my wave's count of frame f go: base + f * stride
@@ -401,16 +424,21 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
         aim(ng, cur ^ 1u);
         const uint32_t fbase = vgpr_copy(lds0 + cur * bufwords * 4u);
         uint32_t pbf = 0;
+        uint64_t ts[16] = {};
         if (rows) {
             switch (fk) {
-            case 1: frame_pass_rows<1, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush); break;
-            case 2: frame_pass_rows<2, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush); break;
-            case 3: frame_pass_rows<3, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush); break;
-            default: frame_pass_rows<4, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush); break;
+            case 1: frame_pass_rows<1, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
+            case 2: frame_pass_rows<2, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
+            case 3: frame_pass_rows<3, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
+            default: frame_pass_rows<4, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
             }
         } else {
             flush();
             frame_pass_plain<AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, validmask, fbase, safe_v, m_v, ninv, fk, pbf, st);
+        }
+        if ((AB & 4096) && g_query_rowstamps && blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int i = 0; i < 13; ++i) g_query_rowstamps[((threadIdx.x ? 1u : 0u) * MAX_BATCH + j) * 16 + i] = ts[i];
         }
         stamp(j, 3);
         out_pb = ~pbf & 0xFFu; out_f = f; out_pending = true;

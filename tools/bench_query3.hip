@@ -102,6 +102,7 @@ int main(int argc, char **argv)
         V3(S64, 256, "k_query_s64, geometry by scalar loads per frame");
         V3(S64, 2048, "k_query_s64 without wave priorities");
         V3(S64, 0, "k_query_s64 (geometry from LDS)");
+        V3(S64, 8192, "k_query_s64, staggered staging (2 pairs ahead)");
     }
 #define A3(K, V, name) printf("%-40s pure %6.1f | no reductions %6.1f | no LDS reads %6.1f | no counts %6.1f | none of the three %6.1f | no hashing %6.1f us\n", name, \
         run<(V) | 8 | 32, K>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), run<(V) | 8 | 32 | 1, K>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), \
@@ -143,6 +144,35 @@ int main(int argc, char **argv)
     printf("pure passes, k_query_s64: 4 waves/SIMD %6.1f | 2 waves/SIMD %6.1f | 1 wave/SIMD %6.1f us\n",
            run<8 | 32>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), run<8 | 32, S64, 512>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb),
            run<8 | 32, S64, 256>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb));
+    {   // shader-clock stamps at 13 points of the frame pass (AB & 4096): first and last wave of workgroup 0, averaged over frames 2 .. F-2
+        uint64_t *drs; const size_t rsw = (size_t)2 * MAX_BATCH * 16;
+        CK(hipMalloc(&drs, rsw * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_query_rowstamps), &drs, sizeof drs));
+        const char *pts[12] = {"steps+reads 0", "outputs of the previous frame", "reduce 1", "combine 0", "steps+reads 1", "reduce 2", "combine 1", "steps+reads 2", "reduce 3", "combine 2", "steps+reads 3", "combine 3"};
+        auto report = [&](const char *name, float us) {
+            std::vector<uint64_t> rs(rsw); CK(hipMemcpy(rs.data(), drs, rsw * 8, hipMemcpyDeviceToHost));
+            printf("pass stamps, %s (%.1f us with stamps), ticks per interval, first wave | last wave of workgroup 0:\n", name, us);
+            for (int w = 0; w < 2; ++w) {
+                double sum[12] = {0}; double frame = 0;
+                for (uint32_t f = 2; f + 2 < F; ++f) {
+                    const uint64_t *t = rs.data() + ((size_t)w * MAX_BATCH + f) * 16;
+                    for (int i = 0; i < 12; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+                    frame += (double)(rs[((size_t)w * MAX_BATCH + f + 1) * 16] - t[0]);
+                }
+                printf("  %s wave: ", w ? "last " : "first");
+                double tot = 0;
+                for (int i = 0; i < 12; ++i) { printf("%s %.0f | ", pts[i], sum[i] / (F - 4)); tot += sum[i] / (F - 4); }
+                printf("pass %.0f, frame to frame %.0f ticks\n", tot, frame / (F - 4));
+            }
+        };
+#define RS(V, T, name) do { CK(hipMemset(drs, 0, rsw * 8)); const float t_ = run<(V) | 4096, S64, T>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb, 1); report(name, t_); } while (0)
+        RS(0, 1024, "full kernel, 4 waves/SIMD");
+        RS(8 | 32, 1024, "pure passes, 4 waves/SIMD");
+        RS(8 | 32, 256, "pure passes, 1 wave/SIMD");
+        RS(8 | 32 | 1, 256, "pure passes without reductions, 1 wave/SIMD");
+        RS(8 | 32 | 1 | 2 | 4, 256, "pure passes, none of the three, 1 wave/SIMD");
+        RS(8 | 32 | 1 | 2 | 4, 1024, "pure passes, none of the three, 4 waves/SIMD");
+    }
     // the same ablations per occupancy (512- and 256-thread workgroups run 2 and 4 rounds on the 256 CUs): does the pass follow its VALU count anywhere?
 #define OCC(T, name) printf("pure passes at %s: all %6.1f | no reductions %6.1f | no LDS reads %6.1f | none of the three %6.1f | no hashing %6.1f | 1 frame %6.1f us\n", name, \
         run<8 | 32, S64, T>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), run<8 | 32 | 1, S64, T>(n, F, tab, sd, fstride, fwmax, sc, nseg, (uint64_t *)sb), \
