@@ -121,7 +121,7 @@ __device__ __forceinline__ void rows_reduce4(int g, const double (&hd1)[QL_P], c
 // of pair g - 1 fly under the reductions of pair g.  `x` arrives holding pair 0's reductions (computed in front of the barrier);
 // `after_first_reads()` runs once pair 0's reads are in flight (the kernel puts the previous frame's outputs there).
 // AB (ablation mask, tools/bench_query3.hip only; 0 in the library): 1 = no reductions, 2 = no LDS probes, 4 = no pass counting.
-template <int FK, int AB, typename STAGER, typename HOOK>
+template <int FK, int AB, bool OVERLAP = true, typename STAGER, typename HOOK>
 __device__ __forceinline__ void frame_pass_rows(
     const double (&hd1)[QL_P], const uint32_t (&hl1)[QL_P], const double (&hd2)[QL_P], const uint32_t (&hl2)[QL_P],
     uint32_t rank_lo, uint32_t rank_hi, uint32_t c /* VGPR */, uint32_t lds_base_bytes /* VGPR */, uint32_t safe_pos /* VGPR */, uint32_t m /* VGPR */, double ninv,
@@ -129,14 +129,16 @@ __device__ __forceinline__ void frame_pass_rows(
 {
     static_assert(FK >= 1, "at least one deterministic probe");
     constexpr int NP = FK + 1, NG = QL_P / 2;
-    uint32_t pos[2][2][NP], wrd[2][2][NP];                         // [pair parity][pixel of the pair][probe]
+    // OVERLAP = false (floor(k*) = 5: nearly static frames; 6 would spill): one pair's positions and words at a time -- they are 2 x 2 x 7 registers
+    // each otherwise -- and the pair's reads are waited for right behind their issue; the other waves of the SIMD cover them.
+    uint32_t pos[OVERLAP ? 2 : 1][2][NP], wrd[OVERLAP ? 2 : 1][2][NP];       // [pair parity][pixel of the pair][probe]
     uint32_t five = 5u;                                            // opaque: written with a literal 5 the compiler folds shift, shift, add into shift, and, add
     asm volatile("" : "+s"(five));
     auto lds_word = [&](uint32_t addr) -> uint32_t {
         return (AB & 2) ? addr * 0x9E3779B1u : *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
     };
     auto steps_and_reads = [&](int g, const uint32_t (&x)[4]) {    // positions of the pair's probes; every read is issued as soon as its address exists
-        const int par = g & 1;
+        const int par = OVERLAP ? g & 1 : 0;
         uint32_t pa = x[0], pb_ = x[2];
         const uint32_t sa = x[1], sb = x[3];
 #pragma unroll
@@ -168,7 +170,7 @@ __device__ __forceinline__ void frame_pass_rows(
         RBF_ROW();
     };
     auto combine2 = [&](int g) {                                   // verdicts of pair g: the sign bit of `fail` says "some probed filter bit is 0"
-        const int par = g & 1;
+        const int par = OVERLAP ? g & 1 : 0;
         uint32_t f0 = 0u, f1 = 0u;
         if (!(AB & 2)) __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0), once: left alone the compiler waits in front of each of the six words
 #pragma unroll
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
         const double ninv = __builtin_bit_cast(double, ((uint64_t)cg.ninv_hi << 32) | cg.ninv_lo);
         const uint32_t fk = cg.fkc & 0xFFu, f = cg.fkc >> 16;
         const uint32_t c_v = vgpr_copy((cg.fkc >> 8) & 0xFFu);
-        const bool rows = whole_wave && fk >= 1u && fk <= 4u;     // else: other floor(k*), or the frame's last segments (positions past the end)
+        const bool rows = whole_wave && fk >= 1u && fk <= 5u;     // else: other floor(k*), or the frame's last segments (positions past the end)
         uint32_t x[4] = {0, 0, 0, 0};
         if (rows) rows_reduce4<AB>(0, hd1, hl1, hd2, hl2, m_v, ninv, x);
         const Geo ng = geometry_take(jn, ngv);
@@ -430,7 +432,8 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
             case 1: frame_pass_rows<1, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
             case 2: frame_pass_rows<2, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
             case 3: frame_pass_rows<3, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
-            default: frame_pass_rows<4, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
+            case 4: frame_pass_rows<4, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
+            default: frame_pass_rows<5, AB, false>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
             }
         } else {
             flush();
