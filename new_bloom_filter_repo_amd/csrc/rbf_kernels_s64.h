@@ -252,7 +252,9 @@ __device__ __forceinline__ void frame_pass_plain(
 // `empty_lo / empty_hi`: bit f set = frame f of the batch is not coded (m == 0) and this launch writes its (empty) outputs.
 // Dynamic LDS: two image buffers of ((fwords_max + 3) & ~3) + 4 dwords, then S64_GEO_BYTES.
 // AB bits: 2048 = no wave priorities, 8 = no staging, 16 = no hashing, 32 = no barrier (wrong results), 64 = no output, 256 = frame geometry by scalar loads from
-// the kernel-argument segment in every frame (what k_query_r64 does), 1 / 2 / 4 as in frame_pass_rows.
+// the kernel-argument segment in every frame (what k_query_r64 does), 1 / 2 / 4 as in frame_pass_rows, 128 = one output store per launch (wrong
+// results), 1024 = phase stamps of the frame loop, 4096 = stamps at 13 points of the pass, 8192 = staggered staging (RowStager2).  The library
+// instantiates AB = 0 only; every other value exists for tools/bench_query3.hip (profiles/r03_query_ablation.txt).
 template <int AB = 0>
 __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
     uint64_t n, uint32_t nactive, const FrameTable tab, Seeds seeds,
@@ -648,6 +650,8 @@ __device__ __forceinline__ uint32_t tiled_frame(const double (&hd1)[QL_P], const
     return pbf;
 }
 
+// AB bits (tools/bench_query4.hip only; the library instantiates 0): 1 = no reductions, 2 = no LDS reads, 8 = no staging, 32 = no barriers / waits
+// (wrong results), 2048 = k_query_s64's wave priorities in the tile passes, 4096 = the first tile through registers (TileStager) instead of LDS-DMA.
 template <int AB = 0>
 __global__ __launch_bounds__(QL_THREADS) void k_query_s64t(
     uint64_t n, uint32_t nactive, const FrameTable tab /* as for k_query_s64 */, Seeds seeds,
