@@ -157,15 +157,9 @@ int main()
         printf("    %-54s full %6.1f | no staging %6.1f | pure passes %6.1f | pure, no ballots %6.1f us\n", name, tf, ts, tp, tn); } while (0)
         for (int rep = 0; rep < 2; ++rep) {
         R3V(0, "r64 base (group schedule, 3-slot stager)");
-        R3V(R64_STAGER2, "2-slot stager");
-        R3V(R64_PIXEL_PIPE, "pixel pipeline depth 2");
-        R3V(R64_PIXEL_PIPE | R64_STAGER2, "pixel pipeline depth 2, 2-slot stager");
-        R3V(R64_PIXEL_PIPE | R64_PIPE_DEPTH3 | R64_STAGER2, "pixel pipeline depth 3, 2-slot stager");
-        R3V(R64_LOADS_FIRST | R64_STAGER2, "group schedule, loads first, 2-slot stager");
-        R3V(R64_PLANE_BALLOT, "base + bit-plane ballots");
-        R3V(R64_PIXEL_PIPE | R64_PLANE_BALLOT, "pixel pipeline depth 2 + bit-plane ballots");
-        R3V(R64_PIXEL_PIPE | R64_PIPE_DEPTH3 | R64_STAGER2 | R64_PLANE_BALLOT, "pixel pipeline depth 3, 2-slot + bit-plane ballots");
-        R3V(R64_LOADS_FIRST | R64_STAGER2 | R64_PLANE_BALLOT, "loads first, 2-slot + bit-plane ballots");
+        // (The schedule variants of section 1 of profiles/r03_query_ablation.txt -- two staging slots, pixel pipelines of depth 2
+        // and 3, reads before the previous combine, plane ballots -- were template bits of k_query_r64 in the working tree of that
+        // experiment only; what they taught went into k_query_s64 (rbf_kernels_s64.h, tools/bench_query3.hip).)
         }
         return 0;
     }
