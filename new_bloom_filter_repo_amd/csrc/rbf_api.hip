@@ -951,8 +951,13 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
             uint32_t nactive; uint64_t empty[2];
             const FrameTable stab = query_table_s64(tab, nframes, &nactive, empty);
             if (quiet_passthrough) empty[0] = empty[1] = 0;
-            if (int r = allow_big_lds((const void *)k_query_s64<0>)) return r;
-            hipLaunchKernelGGL(k_query_s64<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes + S64_GEO_BYTES, ctx->stream,
+            // the 120-register kernel (a neighbour pipeline's mask / compaction waves fit next to it) unless the batch has floor(k*) = 4 or 5,
+            // which only the 127-register one passes in rows
+            bool wide = false;
+            for (uint32_t f = 0; f < nframes; ++f) if (tab.f[f].m && (tab.f[f].floor_k == 4u || tab.f[f].floor_k == 5u)) wide = true;
+            auto kern64 = wide ? k_query_s64w<0> : k_query_s64<0>;
+            if (int r = allow_big_lds((const void *)kern64)) return r;
+            hipLaunchKernelGGL(kern64, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes + S64_GEO_BYTES, ctx->stream,
                                n, nactive, stab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                                ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out, empty[0], empty[1]);
         } else if (!ctx->query_dma) {

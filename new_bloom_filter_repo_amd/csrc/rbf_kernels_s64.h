@@ -255,9 +255,15 @@ __device__ __forceinline__ void frame_pass_plain(
 // the kernel-argument segment in every frame (what k_query_r64 does), 1 / 2 / 4 as in frame_pass_rows, 128 = one output store per launch (wrong
 // results), 1024 = phase stamps of the frame loop, 4096 = stamps at 13 points of the pass, 8192 = staggered staging (RowStager2).  The library
 // instantiates AB = 0 only; every other value exists for tools/bench_query3.hip (profiles/r03_query_ablation.txt).
-template <int AB = 0>
-__global__ __launch_bounds__(QL_THREADS) void k_query_s64(
-    uint64_t n, uint32_t nactive, const FrameTable tab, Seeds seeds,
+//
+// Two kernels share the body: k_query_s64 (floor(k*) <= 3 in the rows pass; capped at 120 VGPRs, so that with its 16 waves a CU
+// keeps 32 registers per SIMD lane free -- exactly one wave of the planar mask kernel (32 VGPRs) or of k_compact_witness (25) per
+// SIMD: a neighbour pipeline's mask and compaction kernels then run UNDERNEATH the query instead of queueing behind it, 130 ->
+// 126 us per step with four pipelines) and k_query_s64w (rows up to floor(k*) = 5, 127 VGPRs, nothing co-resides), which the host
+// picks for batches that contain floor(k*) = 4 or 5.  WIDE = false sends 4 and 5 to the plain pass (correct, slower).
+template <int AB, bool WIDE>
+__device__ __forceinline__ void query_s64_body(
+    uint64_t n, uint32_t nactive, const FrameTable &tab, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t fwords_max,
     uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words,
     uint4 *__restrict__ table_out /* nullable: write the pixel-index hash table for the NEXT batch's insert kernel */,
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
         const double ninv = __builtin_bit_cast(double, ((uint64_t)cg.ninv_hi << 32) | cg.ninv_lo);
         const uint32_t fk = cg.fkc & 0xFFu, f = cg.fkc >> 16;
         const uint32_t c_v = vgpr_copy((cg.fkc >> 8) & 0xFFu);
-        const bool rows = whole_wave && fk >= 1u && fk <= 5u;     // else: other floor(k*), or the frame's last segments (positions past the end)
+        const bool rows = whole_wave && fk >= 1u && fk <= (WIDE ? 5u : 3u);       // else: other floor(k*), or the frame's last segments (positions past the end)
         uint32_t x[4] = {0, 0, 0, 0};
         if (rows) rows_reduce4<AB>(0, hd1, hl1, hd2, hl2, m_v, ninv, x);
         const Geo ng = geometry_take(jn, ngv);
@@ -433,9 +439,9 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
             switch (fk) {
             case 1: frame_pass_rows<1, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
             case 2: frame_pass_rows<2, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
-            case 3: frame_pass_rows<3, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
-            case 4: frame_pass_rows<4, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
-            default: frame_pass_rows<5, AB, false>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
+            case 3: frame_pass_rows<3, AB, WIDE>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;   // (narrow: single-buffered)
+            case 4: if constexpr (WIDE) frame_pass_rows<4, AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
+            default: if constexpr (WIDE) frame_pass_rows<5, AB, false>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, st, flush, ts); break;
             }
         } else {
             flush();
@@ -455,6 +461,17 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_s64(
     flush();
 }
 
+
+#define RBF_S64_PARAMS uint64_t n, uint32_t nactive, const FrameTable tab, Seeds seeds, const uint32_t *__restrict__ image, uint64_t image_stride_words32, \
+    uint32_t fwords_max, uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words, uint4 *__restrict__ table_out, uint64_t empty_lo, uint64_t empty_hi
+#define RBF_S64_ARGS n, nactive, tab, seeds, image, image_stride_words32, fwords_max, seg_cnt, nseg, pass_words, table_out, empty_lo, empty_hi
+// (amdgpu_num_vgpr counts HALF of gfx950's unified register file: 60 = 120 VGPRs of the 512 / 4 a wave may have at 4 waves per SIMD)
+template <int AB = 0>
+__attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) void k_query_s64(RBF_S64_PARAMS) { query_s64_body<AB, false>(RBF_S64_ARGS); }
+template <int AB = 0>
+__global__ __launch_bounds__(QL_THREADS) void k_query_s64w(RBF_S64_PARAMS) { query_s64_body<AB, true>(RBF_S64_ARGS); }
+#undef RBF_S64_PARAMS
+#undef RBF_S64_ARGS
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_query_s64t -- the same kernel for filters that do not fit LDS twice (1440p ... 5K, m < 2^23: BASELINE config 4), walked in TILES
