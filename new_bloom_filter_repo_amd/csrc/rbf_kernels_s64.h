@@ -669,8 +669,9 @@ __device__ __forceinline__ uint32_t tiled_frame(const double (&hd1)[QL_P], const
 
 // AB bits (tools/bench_query4.hip only; the library instantiates 0): 1 = no reductions, 2 = no LDS reads, 8 = no staging, 32 = no barriers / waits
 // (wrong results), 2048 = k_query_s64's wave priorities in the tile passes, 4096 = the first tile through registers (TileStager) instead of LDS-DMA.
+// (120 registers as k_query_s64, for the same reason: one wave of the mask / compaction kernels per SIMD runs underneath it)
 template <int AB = 0>
-__global__ __launch_bounds__(QL_THREADS) void k_query_s64t(
+__attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) void k_query_s64t(
     uint64_t n, uint32_t nactive, const FrameTable tab /* as for k_query_s64 */, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t tile_words /* multiple of 4 */,
     uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words, uint64_t empty_lo, uint64_t empty_hi)
