@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--no-clips", action="store_true", help="skip the clip300 / clip300_uint16 legs (BASELINE configs 3 and 5) behind the weak-scaling headline")
     ap.add_argument("--clip-leg-frames", type=int, default=300, help="frames of the clip legs of the default run")
     ap.add_argument("--clip-steps", type=int, default=10, help="timed passes over the clip in the clip legs")
+    ap.add_argument("--begin-ahead", type=int, default=-1, help="GOPs whose mask stage (rbf_encode_gop_begin) is enqueued before the oldest one is finished (rbf_encode_gop_finish); 0 = the one-call form, -1 = auto (pipelines - 1)")
+    ap.add_argument("--host-threads", type=int, default=0, help="1 = one host thread per pipeline (each calls rbf_encode_gop for its own context; ctypes drops the GIL) instead of one thread issuing begin / finish in turn")
+    ap.add_argument("--no-legs", action="store_true", help="skip the interleaved / config4_2160p / decode_1080p legs behind the headline")
     return ap.parse_args()
 
 
@@ -214,20 +217,65 @@ def main():
     slots = {}
     state = {"s": 0}
 
+    # One host thread feeds all pipelines: the mask stage of step s (rbf_encode_gop_begin) is enqueued `ahead` steps before the thread
+    # waits for its counts and enqueues its Bloom kernels (rbf_encode_gop_finish), so the thread never stands still while a mask
+    # kernel runs (round 3: it span inside every rbf_encode_gop for about half of the step).  ahead = 0 is the one-call form.
+    ahead = (ncoders - 1) if args.begin_ahead < 0 else min(args.begin_ahead, ncoders - 1)
+    import collections
+    pending = collections.deque()
+    host_s = {"t": 0.0}                           # time the feeding thread(s) spent inside the library calls of the steps
+
+    def finish_one():
+        k = pending.popleft()
+        if not gather:
+            coders[k].encode_finish()
+            return
+        with torch.cuda.stream(streams[k]):
+            t = og.begin(k)                       # this step's slot (waits stream-side for the outbox's previous transfer)
+            coders[k].encode_finish()
+            coders[k].pack(slots.setdefault(t.data_ptr(), Slot(t)))
+            og.end(k)                             # full outbox -> one asynchronous gather from the comm stream
+
     def step():
         k = state["s"] % ncoders
         g = (state["s"] // ncoders) % G_res       # a pipeline rotates over its resident GOPs
         state["s"] += 1
-        with torch.cuda.stream(streams[k]):
-            if not gather:
-                coders[k].encode(g)
-                return
-            t = og.begin(k)                       # this step's slot (waits stream-side for the outbox's previous transfer)
-            coders[k].encode(g)
-            coders[k].pack(slots.setdefault(t.data_ptr(), Slot(t)))
-            og.end(k)                             # full outbox -> one asynchronous gather from the comm stream
+        t0 = time.perf_counter()
+        coders[k].encode_begin(g)
+        pending.append(k)
+        if len(pending) > ahead:
+            finish_one()
+        host_s["t"] += time.perf_counter() - t0
+
+    def run_steps(nsteps):
+        if not (args.host_threads and not gather and ncoders > 1):
+            for _ in range(nsteps):
+                step()
+            return
+        # one thread per pipeline, each with its own context and stream: step i is pipeline i % ncoders' (i // ncoders)-th GOP
+        import threading
+        first = state["s"]
+        state["s"] += nsteps
+        spent = [0.0] * ncoders
+
+        def feed(k):
+            t0 = time.perf_counter()
+            for i in range(first, first + nsteps):
+                if i % ncoders == k:
+                    coders[k].encode((i // ncoders) % G_res)
+            spent[k] = time.perf_counter() - t0
+        threads = [threading.Thread(target=feed, args=(k,)) for k in range(ncoders)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        host_s["t"] += max(spent)
 
     def drain():
+        t0 = time.perf_counter()
+        while pending:
+            finish_one()
+        host_s["t"] += time.perf_counter() - t0
         if og is not None:
             og.flush()
 
@@ -247,16 +295,12 @@ def main():
         # worst-case slots (a record can never overflow one); only the used bytes of a slot travel
         og = OutboxGather(record_max // 8, G, device, streams=streams)
         probe = None
-        for _ in range(2 * G):                    # untimed: the first RCCL transfer of both outboxes (connection setup)
-            step()
+        run_steps(2 * G)                          # untimed: the first RCCL transfer of both outboxes (connection setup)
         drain()
         state["s"] = 0
-    t0 = time.perf_counter()
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     drain()
     torch.cuda.synchronize(device)
-    warm_s = (time.perf_counter() - t0) / max(1, args.warmup)
 
     def timed(nsteps, with_events):
         if with_events:
@@ -266,13 +310,14 @@ def main():
                 c.timing_reset()
                 c.timing(1 << nat.K_QUERY)
         barrier()
+        host_s["t"] = 0.0
         t0 = time.perf_counter()
-        for _ in range(nsteps):
-            step()
+        run_steps(nsteps)
         drain()
         torch.cuda.synchronize(device)
         barrier()
         elapsed = time.perf_counter() - t0
+        host_s["region"] = host_s["t"] / nsteps
         kt = {}
         if with_events:
             for c in ctxs:
@@ -331,14 +376,20 @@ def main():
 
     out = {
         "metric": "Mpixels/s Bloom insert+query, 1080p residuals",
-        "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": steps_timed, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps_timed * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "steps_timed": steps_timed, "timed_region_ms": round(elapsed * 1e3, 2),
+        "requested_steps": args.steps, "steps_timed": steps_timed, "timed_region_ms": round(elapsed * 1e3, 2),
+        "host_ms_per_step": round(host_s.get("region", 0.0) * 1e3, 4),
+        "host_feed": ("one thread per pipeline, each calling rbf_encode_gop on its own context" if (args.host_threads and not gather and ncoders > 1) else
+                      "one thread: rbf_encode_gop_begin of step s+%d is enqueued before rbf_encode_gop_finish of step s" % ahead if ahead else
+                      "one thread, one blocking rbf_encode_gop per step"),
         "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), %s, threshold 0, %s"
                                % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3",
                                   "planar Y resident (the mask stage reads luma only)" if planar else "interleaved YUV444 resident"),
                    "layout": "planar Y" if planar else "interleaved", "resident_gops_per_pipeline": G_res,
+                   "inputs": "resident in HBM before the timed region: %s; the timed step starts at the mask kernel"
+                             % ("Y planes extracted from the YUV444 frames on the host and uploaded once (the `interleaved_yuv444` leg keeps whole frames resident instead)" if planar else "whole interleaved YUV444 frames, uploaded once"),
                    "pixels_per_step": pixels_per_step, "gather_to_rank0": bool(gather), "gop_pipelines_per_gpu": ncoders,
                    "distinct_gop_per_pipeline": not args.shared_gop, "resident_input_mb_per_gpu": round(resident_mb, 1),
                    "gather": "exact-size: all_gather of the used sizes, then one grouped point-to-point message per peer; rank 0's own records are not sent" if gather else None,
@@ -402,10 +453,24 @@ def main():
             out["verified_vs_oracle"]["gops_per_pipeline"] = G_res
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, n, args.cpu_frames)
+    # ---- further legs of the same line (rank 0 of a single-GPU run only): the interleaved layout next to the planar headline, BASELINE
+    #      configs[3] (3840x2160) and the decode direction (A6) of the headline's own records
+    if world == 1 and rank == 0 and not args.no_legs and (W, H, F, args.bits) == (1920, 1080, 30, 8) and not args.density:
+        out["decode_1080p"] = decode_leg(torch, nat, coders, host_gops, n, pairs, G_res)
+        if planar:
+            out["interleaved_yuv444"] = pipelines_leg(torch, nat, device, local_rank, W, H, F, 8, False, 1, ncoders, density, ahead, 160, host_gops=[[h[0]] for h in host_gops], verify=not args.no_verify)
+        for c in coders:
+            c.close()
+        coders = [None]
+        torch.cuda.empty_cache()
+        out["config4_2160p"] = pipelines_leg(torch, nat, device, local_rank, 3840, 2160, 9, 8, True, 1, ncoders, density, ahead, 60, verify=not args.no_verify, seed=4000)
     # ---- BASELINE configs[2] and [4] in the same process group: one 300-frame clip sharded by frame (strong scaling), 8- and 16-bit
     if og is not None:
         og.close()
     if not args.no_clips:
+        for c in coders:
+            if c is not None:
+                c.close()
         del coders, coder, arenas, ctxs, ctx, og, slots, probe
         torch.cuda.empty_cache()
         env = (world, rank, local_rank, device, use_dist)
@@ -418,6 +483,131 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)        # the last thing on stdout (RCCL prints its own lines while it is alive)
+
+
+def decode_leg(torch, nat, coders, host_gops, n, pairs, G_res, reps=40):
+    """A6 (improved_video_compressor.py:268-307) over the step's own records: every pipeline decodes the (filter, witness, k, l) rows its
+    last encode left in HBM back into masks -- query + segment scan + expansion, rbf_bloom_decode_batch -- `reps` times on its own
+    stream; the decoded masks are compared with the masks the encoder saw AND with the CPU oracle's masks of the host frames."""
+    import ctypes
+    from oracle import oracle as orc
+    L = nat.lib()
+    outs = []
+    for c in coders:
+        c.encode(0)
+        outs.append(c._alloc(c.mask_stride * pairs))
+    for c in coders:
+        c.ctx.sync()
+
+    def decode(c, o):
+        nat.check(L.rbf_bloom_decode_batch(c.ctx.handle, c.filters.ptr, c.filter_stride, c.witness.ptr, c.witness_stride,
+                                           n, pairs, c.params, ctypes.byref(c.seeds), o.ptr, c.mask_stride))
+    for c, o in zip(coders, outs):
+        decode(c, o)
+    for c in coders:
+        c.ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for c, o in zip(coders, outs):
+            decode(c, o)
+    for c in coders:
+        c.ctx.sync()
+    dt = (time.perf_counter() - t0) / (reps * len(coders))
+    c0 = coders[0]
+    c0.ctx.timing_reset()
+    c0.ctx.timing(True)
+    for _ in range(20):
+        decode(c0, outs[0])
+    c0.ctx.sync()
+    c0.ctx.timing(False)
+    alone = {k: round(v[0] / 20, 4) for k, v in c0.ctx.timing_read().items() if v[1]}
+    frames = 0
+    for k, (c, o) in enumerate(zip(coders, outs)):
+        got = o.numpy(c.ctx)[:c.mask_stride * pairs].reshape(pairs, c.mask_stride)
+        seen = c.masks.numpy(c.ctx)[:c.mask_stride * pairs].reshape(pairs, c.mask_stride)
+        if not np.array_equal(got, seen):
+            raise SystemExit("decode leg: pipeline %d's decoded masks differ from the encoder's" % k)
+        gop = host_gops[k][0]
+        for f in range(pairs):
+            want = orc.residual_mask(np.ascontiguousarray(gop[f][..., 0]), np.ascontiguousarray(gop[f + 1][..., 0]), 0.0).reshape(-1)
+            if not np.array_equal(np.unpackbits(got[f])[:n], want):
+                raise SystemExit("decode leg: pipeline %d frame %d differs from the CPU oracle's mask" % (k, f))
+            frames += 1
+    return {"value": round(pairs * n / dt / 1e6, 1), "unit": "Mpixel/s", "ms_per_gop": round(dt * 1e3, 4), "pipelines": len(coders), "gops_timed": reps * len(coders),
+            "kernels_ms_per_gop_alone": alone, "what": "rbf_bloom_decode_batch over the 29 records of a headline step (query + scan + expand), records resident in HBM",
+            "verified_vs_oracle": {"frames": frames, "fields": "decoded mask == encoder's mask == oracle's mask"}}
+
+
+def pipelines_leg(torch, nat, device, local_rank, W, H, F, bits, planar, G_res, ncoders, density, ahead, steps, host_gops=None, verify=True, seed=3000):
+    """The headline's step on another geometry or layout, shortened: `ncoders` pipelines, begin / finish in turn, `steps` timed steps,
+    every kernel alone afterwards, every GOP checked against the CPU oracle; its own HBM roofline for the query kernel."""
+    from new_bloom_filter_repo_amd.gop import GopCoder, TorchArena, torch_allocator
+    from new_bloom_filter_repo_amd.synthetic import make_gop
+    import collections
+    n, pairs = W * H, F - 1
+    dtype = np.uint8 if bits == 8 else np.uint16
+    streams = [torch.cuda.Stream(device) for _ in range(ncoders)]
+    ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
+    arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
+    coders = [GopCoder(ctxs[k], W, H, F, channels=3, sample_bytes=bits // 8, allocator=torch_allocator(device), out_allocator=arenas[k],
+                       planar_luma=planar, keep_interleaved=not planar, resident_gops=G_res) for k in range(ncoders)]
+    if host_gops is None:
+        host_gops = [[np.stack(make_gop(seed + 16 * k + g, W, H, F, p=density, dtype=dtype)) for g in range(G_res)] for k in range(ncoders)]
+    for k in range(ncoders):
+        for g in range(G_res):
+            coders[k].load_frames(host_gops[k][g], g)
+    torch.cuda.synchronize(device)
+    pending = collections.deque()
+
+    def run(nsteps, first=0):
+        for s in range(first, first + nsteps):
+            k = s % ncoders
+            coders[k].encode_begin((s // ncoders) % G_res)
+            pending.append(k)
+            if len(pending) > ahead:
+                coders[pending.popleft()].encode_finish()
+        while pending:
+            coders[pending.popleft()].encode_finish()
+    run(2 * ncoders)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    c0 = coders[0]
+    c0.ctx.timing_reset()
+    c0.ctx.timing(True)
+    for i in range(20):
+        c0.encode(i % G_res)
+    c0.ctx.sync()
+    c0.ctx.timing(False)
+    alone = {k: round(v[0] / 20, 4) for k, v in c0.ctx.timing_read().items() if v[1]}
+    out = {"value": round(pairs * n / dt / 1e6, 1), "unit": "Mpixel/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "pipelines": ncoders,
+           "workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP, k*=2.3, %s resident" % (W, H, bits, F, "planar Y" if planar else "interleaved YUV444"),
+           "resident_input_mb": round(sum(h.nbytes for hs in host_gops for h in hs) / (3 if planar else 1) / 1e6, 1),
+           "kernels_ms_per_step_alone": alone}
+    checked = []
+    for g in range(G_res):
+        for k in range(ncoders):
+            coders[k].encode(g)
+        for k in range(ncoders):
+            checked.append((host_gops[k][g], coders[k].results()))
+    res = checked[0][1]
+    alg_bytes = pairs * n / 8 + sum(r["l"] for r in res) / 8 + sum(r["witness_bits"] for r in res) / 8
+    if alone.get("query"):
+        ach = alg_bytes / (alone["query"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_query_s64t" if n > 1920 * 1080 else "k_query_s64", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBPS, 5), "avg_launch_ms": alone["query"], "launches_averaged": 20,
+                           "algorithmic_bytes_per_launch": int(alg_bytes)}
+    if verify:
+        out["verified_vs_oracle"] = verify_all([h for h, _ in checked], [r for _, r in checked], n, len(checked))
+    for c in coders:
+        c.close()
+    for c in ctxs:
+        c.close()
+    del coders, ctxs, arenas
+    torch.cuda.empty_cache()
+    return out
 
 
 def check_gathered(og, world, G, pairs, n, res_all):
@@ -583,22 +773,25 @@ def cpu_baseline(res, n, nframes):
         passes += 1
     # the same port with the frames spread over the host's cores (frames are independent; ctypes drops the GIL)
     from concurrent.futures import ThreadPoolExecutor
-    threads = max(1, min(len(frames), os.cpu_count() or 1))
+    threads = max(1, os.cpu_count() or 1)
+    jobs = max(len(frames), 2 * threads)          # two frames per host core (the step's masks, cyclically): every core it reports is busy
 
-    def one(i):
+    def one(j):
+        i = j % len(frames)
         r, mask = frames[i], masks[i]
         bit_array = np.zeros(r["l"], dtype=np.uint8)
         witness = np.zeros(n, dtype=np.uint8)
         L.orc_compress(mask.ctypes.data, n, r["l"], ctypes.c_double(r["k"]), seeds, bit_array.ctypes.data, witness.ctypes.data)
     with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(one, range(threads)))       # (threads started, pages touched)
         t0 = time.perf_counter()
-        list(pool.map(one, range(len(frames))))
+        list(pool.map(one, range(jobs)))
         t_all = time.perf_counter() - t0
     return {"value": round(px / t_total / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
             "sample": "%d passes over the step's %d masks (%d pixels each), insert+query/witness in the scalar C oracle, %.1f s"
                       % (passes, len(frames), n, t_total),
-            "all_cores": {"value": round(len(frames) * n / t_all / 1e6, 1), "unit": "Mpixel/s", "cores": threads, "host_cpus": os.cpu_count(),
-                          "sample": "one pass, one frame per thread, %.1f s" % t_all},
+            "all_cores": {"value": round(jobs * n / t_all / 1e6, 1), "unit": "Mpixel/s", "cores": threads, "host_cpus": os.cpu_count(),
+                          "sample": "%d frames (the step's %d masks, cyclically) over %d threads, one frame per call, %.2f s" % (jobs, len(frames), threads, t_all)},
             "reference_python_mpixels_per_s": {"value": 0.38, "source": "BASELINE.md (recorded constant: the reference's own Python loops, build container, 1 core)"}}
 
 

@@ -38,7 +38,7 @@ extern "C" {
 #define RBF_EIO      (-5)   /* a HIP runtime call failed; see rbf_last_error() */
 #define RBF_ERANGE  (-34)
 
-#define RBF_ABI_VERSION 2
+#define RBF_ABI_VERSION 3
 
 typedef struct rbf_ctx rbf_ctx;
 
@@ -234,6 +234,28 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
                    void *filters_dev, uint64_t filter_stride_bytes,
                    void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
                    rbf_filter_params *params_out, double *k_out);
+
+/* The same in two phases (`..._masks()` -> host parameter math -> `..._blooms()`; the reference does these steps one
+ * after the other per frame, improved_video_compressor.py:198-266 -- mask, :211-215 parameters, :235-237 insert, :245-253 query).
+ *   rbf_encode_gop_begin   checks EVERY argument first (a bad call touches neither the stream nor the caller's buffers), enqueues the
+ *                          mask stage (its last workgroup publishes the set-bit counts into pinned host memory and the witness /
+ *                          stats rows are cleared on the way) and returns without waiting.
+ *   rbf_encode_gop_poll    *ready = 1 once the counts have arrived (never blocks).
+ *   rbf_encode_gop_finish  waits for the counts, runs rbf_plan_batch, enqueues insert / reduce / query / compaction; params_out /
+ *                          k_out as for rbf_encode_gop.  Clears the pending state even when it fails.
+ * One GOP per context may be between begin and finish (a second begin returns RBF_EINVAL); the buffers named in begin must stay
+ * valid until the kernels enqueued by finish have run.  A thread that feeds several contexts issues begin(k+1) before finish(k) and
+ * never stands still while a mask kernel runs; rbf_encode_gop is begin + finish. */
+int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                         uint32_t nframes, uint32_t width, uint32_t height,
+                         uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                         uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                         const rbf_seeds *seeds,
+                         void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                         void *filters_dev, uint64_t filter_stride_bytes,
+                         void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev);
+int rbf_encode_gop_poll(rbf_ctx *ctx, int *ready);
+int rbf_encode_gop_finish(rbf_ctx *ctx, rbf_filter_params *params_out, double *k_out);
 
 /* ---- exact-size record of a batch (what the gather to rank 0 moves) ------------- */
 /* Compacts the padded output rows of an encode into ONE contiguous self-describing block on the

@@ -59,6 +59,10 @@ _PROTOS = {
     "rbf_plan_batch": (_int, [_u64, ctypes.POINTER(_u64), _u32, _int, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
     "rbf_encode_gop": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, ctypes.POINTER(Seeds),
                               _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
+    "rbf_encode_gop_begin": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, ctypes.POINTER(Seeds),
+                                    _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp]),
+    "rbf_encode_gop_poll": (_int, [_vp, ctypes.POINTER(_int)]),
+    "rbf_encode_gop_finish": (_int, [_vp, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
     "rbf_residual_mask_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, _vp, _u64, _vp]),
     "rbf_record_max_bytes": (_u64, [_u32, _u64]),
     "rbf_pack_records": (_int, [_vp, _u32, _u64, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double),

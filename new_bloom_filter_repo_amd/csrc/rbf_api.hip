@@ -83,6 +83,13 @@ struct rbf_ctx {
     uint64_t *ones_pinned = nullptr; size_t host_cap = 0;
     uint64_t *ones_mapped_dev = nullptr;     // device address of the same block
     uint64_t publish_token = 0;
+    struct PendingGop {                      // between rbf_encode_gop_begin and rbf_encode_gop_finish
+        bool active = false;
+        uint64_t token = 0, n = 0; uint32_t pairs = 0; rbf_seeds seeds{};
+        const void *masks_dev = nullptr; uint64_t mask_stride_bytes = 0;
+        void *filters_dev = nullptr; uint64_t filter_stride_bytes = 0;
+        void *witnesses_dev = nullptr; uint64_t witness_stride_bytes = 0; uint64_t *stats_dev = nullptr;
+    } gop;
     std::vector<rbf_filter_params> plan;
     std::vector<double> plan_k;
     // timing
@@ -735,6 +742,25 @@ static int launch_finish_ones(rbf_ctx *ctx, uint64_t *ones_dev, uint32_t pairs, 
     return RBF_OK;
 }
 
+// every argument check of the mask stage, with no side effect (rbf_encode_gop_begin runs it before it touches the stream)
+static int check_mask_args(const void *frames_dev, uint64_t frame_stride_bytes, uint32_t nframes, uint32_t width, uint32_t height,
+                           uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes, uint32_t sample_bytes, const int32_t *thr_floors,
+                           const void *masks_dev, uint64_t mask_stride_bytes, const uint64_t *ones_dev)
+{
+    if (!frames_dev || !masks_dev || !ones_dev) return fail(RBF_EINVAL, "null device pointer");
+    if (nframes < 2) return fail(RBF_EINVAL, "need at least 2 frames, got %u", nframes);
+    if (width == 0 || height == 0) return fail(RBF_EINVAL, "empty frame %ux%u", width, height);
+    if (sample_bytes != 1 && sample_bytes != 2) return fail(RBF_EINVAL, "sample_bytes must be 1 or 2, got %u", sample_bytes);
+    if (pixel_stride_bytes < sample_bytes || pixel_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "pixel stride %u incompatible with %u-byte samples", pixel_stride_bytes, sample_bytes);
+    if (row_pitch_bytes < (uint64_t)width * pixel_stride_bytes || row_pitch_bytes % sample_bytes) return fail(RBF_EINVAL, "row pitch %llu too small or misaligned", (unsigned long long)row_pitch_bytes);
+    if (frame_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "frame stride misaligned");
+    if (int r = check_frame_geometry((uint64_t)width * height, nframes - 1, mask_stride_bytes)) return r;
+    if (thr_floors)
+        for (uint32_t i = 0; i + 1 < nframes; ++i)
+            if (thr_floors[i] < 0) return fail(RBF_EINVAL, "negative threshold %d for pair %u", thr_floors[i], i);
+    return RBF_OK;
+}
+
 static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
                               uint32_t nframes, uint32_t width, uint32_t height,
                               uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
@@ -743,15 +769,9 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
                               const MaskFinish *gop_tail = nullptr /* rbf_encode_gop: publish + clears; fused into the mask kernel when it covers the frame */)
 {
     if (int r = set_device(ctx)) return r;
-    if (!frames_dev || !masks_dev || !ones_dev) return fail(RBF_EINVAL, "null device pointer");
-    if (nframes < 2) return fail(RBF_EINVAL, "need at least 2 frames, got %u", nframes);
-    if (width == 0 || height == 0) return fail(RBF_EINVAL, "empty frame %ux%u", width, height);
-    if (sample_bytes != 1 && sample_bytes != 2) return fail(RBF_EINVAL, "sample_bytes must be 1 or 2, got %u", sample_bytes);
-    if (pixel_stride_bytes < sample_bytes || pixel_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "pixel stride %u incompatible with %u-byte samples", pixel_stride_bytes, sample_bytes);
-    if (row_pitch_bytes < (uint64_t)width * pixel_stride_bytes || row_pitch_bytes % sample_bytes) return fail(RBF_EINVAL, "row pitch %llu too small or misaligned", (unsigned long long)row_pitch_bytes);
-    if (frame_stride_bytes % sample_bytes) return fail(RBF_EINVAL, "frame stride misaligned");
+    if (int r = check_mask_args(frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
+                                thr_floors, masks_dev, mask_stride_bytes, ones_dev)) return r;
     const uint64_t n = (uint64_t)width * height;
-    if (int r = check_frame_geometry(n, nframes - 1, mask_stride_bytes)) return r;
     const uint32_t pairs = nframes - 1;
     if (ctx->ones_acc_cap < (size_t)pairs * 8) {
         if (ctx->ones_acc) { HIP_TRY(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ones_acc); ctx->ones_acc = nullptr; ctx->ones_acc_cap = 0; }
@@ -760,7 +780,10 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
         ctx->ones_acc_cap = want;
         ctx->ones_acc_dirty = true;
     }
-    if (ctx->ones_acc_dirty) HIP_TRY(hipMemsetAsync(ctx->ones_acc, 0, ctx->ones_acc_cap, ctx->stream));
+    if (ctx->ones_acc_dirty) {                                    // a launch failed or was abandoned: counts AND tickets start from zero again
+        HIP_TRY(hipMemsetAsync(ctx->ones_acc, 0, ctx->ones_acc_cap, ctx->stream));
+        if (ctx->mask_ticket) HIP_TRY(hipMemsetAsync(ctx->mask_ticket, 0, (MASK_TICKETS + 1) * 4, ctx->stream));
+    }
     ctx->ones_acc_dirty = true;                                   // until k_finish_ones has been enqueued
     uint64_t *const acc = ctx->ones_acc;
     const int32_t *thr_tab = nullptr;
@@ -770,10 +793,7 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
         for (uint32_t base = 0; base < pairs; base += ThrChunk::N) {
             ThrChunk c{};
             const uint32_t cnt = pairs - base < ThrChunk::N ? pairs - base : ThrChunk::N;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                if (thr_floors[base + i] < 0) return fail(RBF_EINVAL, "negative threshold %d for pair %u", thr_floors[base + i], base + i);
-                c.v[i] = thr_floors[base + i];
-            }
+            for (uint32_t i = 0; i < cnt; ++i) c.v[i] = thr_floors[base + i];
             hipLaunchKernelGGL(k_store_thresholds, dim3(1), dim3(ThrChunk::N), 0, ctx->stream, c, ctx->thr_tab + base, cnt);
         }
         HIP_TRY(hipGetLastError());
@@ -803,7 +823,10 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
         if (gop_tail && !ctx->no_fused_finish && fast_segs * 16 == nwords && !(((uintptr_t)gop_tail->clear_a | (uintptr_t)gop_tail->clear_b) & 15)) {
             if (!ctx->mask_ticket) {
                 HIP_TRY(hipMalloc((void **)&ctx->mask_ticket, (MASK_TICKETS + 1) * 4));
-                HIP_TRY(hipMemsetAsync(ctx->mask_ticket, 0, (MASK_TICKETS + 1) * 4, ctx->stream));
+                if (hipError_t e = hipMemsetAsync(ctx->mask_ticket, 0, (MASK_TICKETS + 1) * 4, ctx->stream)) {      // never keep tickets that were not zeroed
+                    (void)hipFree(ctx->mask_ticket); ctx->mask_ticket = nullptr;
+                    return fail(RBF_EIO, "hipMemsetAsync(mask tickets): %s", hipGetErrorString(e));
+                }
             }
             fin = *gop_tail;
             fin.enabled = 1; fin.count = pairs; fin.ticket = ctx->mask_ticket; fin.ones_out = ones_dev;
@@ -1045,6 +1068,9 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         // 72 us against 96 with the gather) -- whichever insert kernel runs, with or without the masks' set-bit counts.
         const bool table_too_big = ((size_t)n + QL_SEG_PIXELS) * 32 > HASH_TABLE_CACHE_BYTES;
         bool hashed_positions = use_tab && (table_too_big || (pl.insert_two_phase && ctx->hash_positions));
+        if (use_tab && hashed_positions && ctx->hash_shared &&
+            (ctx->hash_shared->n != n || ctx->hash_shared->seeds.h1 != seeds->h1 || ctx->hash_shared->seeds.h2 != seeds->h2 || ctx->hash_shared->seeds.act != seeds->act))
+            hash_table_release(ctx);                              // this context moved to a geometry that hashes: it no longer pins the old geometry's table
         if (use_tab && !hashed_positions) {
             bool built = false;
             if (!hash_table_acquire(ctx, n, *seeds, &built)) hashed_positions = true;        // no device memory for the table: hash instead
@@ -1312,8 +1338,7 @@ int rbf_extract_luma_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_
     uint64_t bx = (n + 256 * 4 - 1) / (256 * 4);
     if (bx < 1) bx = 1;
     if (bx > 8192) bx = 8192;
-    LaunchTimer t(ctx, RBF_K_MASK);
-    if (sample_bytes == 1)
+    if (sample_bytes == 1)                                        // (untimed: an upload-time pass, not a kernel of the step)
         hipLaunchKernelGGL(k_extract_luma<uint8_t>, dim3((uint32_t)bx, nframes), dim3(256), 0, ctx->stream, (const uint8_t *)frames_dev, frame_stride_bytes,
                            width, n, row_pitch_bytes, pixel_stride_bytes, (uint8_t *)luma_dev);
     else
@@ -1323,22 +1348,30 @@ int rbf_extract_luma_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_
     return RBF_OK;
 }
 
-int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
-                   uint32_t nframes, uint32_t width, uint32_t height,
-                   uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
-                   uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
-                   const rbf_seeds *seeds,
-                   void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
-                   void *filters_dev, uint64_t filter_stride_bytes,
-                   void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
-                   rbf_filter_params *params_out, double *k_out)
+// The two halves of rbf_encode_gop (`..._masks()` -> host -> `..._blooms()`).  begin: every check, then the mask stage is
+// enqueued and the call returns; finish: wait for the counts the mask kernel's last workgroup publishes into pinned host memory, the
+// float64 parameter math, then insert / reduce / query / compaction are enqueued.  One GOP per context is between the two at a time;
+// a caller with several contexts issues begin(k + 1) before finish(k), so that its thread never stands still while a mask kernel runs.
+int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                         uint32_t nframes, uint32_t width, uint32_t height,
+                         uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                         uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                         const rbf_seeds *seeds,
+                         void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                         void *filters_dev, uint64_t filter_stride_bytes,
+                         void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev)
 {
+    if (!ctx) return fail(RBF_EINVAL, "null context");
+    if (ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_begin: the previous GOP of this context has not been finished");
     if (!filters_dev || !witnesses_dev || !stats_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
     if (int r = set_device(ctx)) return r;
-    if (nframes < 2) return fail(RBF_EINVAL, "need at least 2 frames, got %u", nframes);
+    // nothing below this block has run, and nothing of the caller's has been touched, when an argument is bad
+    if (int r = check_mask_args(frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
+                                thr_floors, masks_dev, mask_stride_bytes, ones_dev)) return r;
     const uint32_t pairs = nframes - 1;
     const uint64_t n = (uint64_t)width * height;
     if (witness_stride_bytes % 8 || witness_stride_bytes < ((n + 63) / 64) * 8) return fail(RBF_EINVAL, "witness stride too small or misaligned");
+    if (filter_stride_bytes % 8) return fail(RBF_EINVAL, "filter stride must be a multiple of 8");
     if (pairs > ctx->host_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->ones_pinned) HIP_TRY(hipHostFree(ctx->ones_pinned));
@@ -1369,21 +1402,61 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
     if (int r = residual_mask_impl(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
                                    pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, false, &tail))
         return r;
+    rbf_ctx::PendingGop &g = ctx->gop;
+    g.active = true; g.token = token; g.n = n; g.pairs = pairs; g.seeds = *seeds;
+    g.masks_dev = masks_dev; g.mask_stride_bytes = mask_stride_bytes;
+    g.filters_dev = filters_dev; g.filter_stride_bytes = filter_stride_bytes;
+    g.witnesses_dev = witnesses_dev; g.witness_stride_bytes = witness_stride_bytes; g.stats_dev = stats_dev;
+    return RBF_OK;
+}
+
+int rbf_encode_gop_poll(rbf_ctx *ctx, int *ready)
+{
+    if (!ctx || !ready) return fail(RBF_EINVAL, "null pointer");
+    if (!ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_poll: no GOP has been begun on this context");
+    *ready = __atomic_load_n((volatile uint64_t *)ctx->ones_pinned, __ATOMIC_ACQUIRE) == ctx->gop.token ? 1 : 0;
+    return RBF_OK;
+}
+
+int rbf_encode_gop_finish(rbf_ctx *ctx, rbf_filter_params *params_out, double *k_out)
+{
+    if (!ctx) return fail(RBF_EINVAL, "null context");
+    if (!ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_finish: no GOP has been begun on this context");
+    if (int r = set_device(ctx)) return r;
+    const rbf_ctx::PendingGop g = ctx->gop;
+    ctx->gop.active = false;                                      // whatever happens below, the context is free for the next begin
     volatile uint64_t *flag = ctx->ones_pinned;
-    for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != token; ++spins) {
+    for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != g.token; ++spins) {
         if ((spins & 0xFFFF) == 0xFFFF) {                    // every ~65k polls make sure the stream is still alive
             hipError_t q = hipStreamQuery(ctx->stream);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(RBF_EIO, "stream failed while waiting for the mask kernel: %s", hipGetErrorString(q));
-            if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != token)
+            if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != g.token)
                 return fail(RBF_EIO, "mask kernel finished without publishing its counts");
         }
         __builtin_ia32_pause();
     }
-    if (int r = rbf_plan_batch(n, ctx->ones_pinned + 1, pairs, 1, ctx->plan.data(), ctx->plan_k.data())) return r;
-    if (params_out) memcpy(params_out, ctx->plan.data(), (size_t)pairs * sizeof(rbf_filter_params));
-    if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)pairs * sizeof(double));
-    return encode_batch_impl(ctx, masks_dev, mask_stride_bytes, n, pairs, ctx->plan.data(), seeds,
-                             filters_dev, filter_stride_bytes, witnesses_dev, witness_stride_bytes, stats_dev, true, ctx->ones_pinned + 1);
+    if (int r = rbf_plan_batch(g.n, ctx->ones_pinned + 1, g.pairs, 1, ctx->plan.data(), ctx->plan_k.data())) return r;
+    if (params_out) memcpy(params_out, ctx->plan.data(), (size_t)g.pairs * sizeof(rbf_filter_params));
+    if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)g.pairs * sizeof(double));
+    return encode_batch_impl(ctx, g.masks_dev, g.mask_stride_bytes, g.n, g.pairs, ctx->plan.data(), &g.seeds,
+                             g.filters_dev, g.filter_stride_bytes, g.witnesses_dev, g.witness_stride_bytes, g.stats_dev, true, ctx->ones_pinned + 1);
+}
+
+int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                   uint32_t nframes, uint32_t width, uint32_t height,
+                   uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                   uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                   const rbf_seeds *seeds,
+                   void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                   void *filters_dev, uint64_t filter_stride_bytes,
+                   void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
+                   rbf_filter_params *params_out, double *k_out)
+{
+    if (int r = rbf_encode_gop_begin(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
+                                     thr_floor, thr_floors, seeds, masks_dev, mask_stride_bytes, ones_dev, filters_dev, filter_stride_bytes,
+                                     witnesses_dev, witness_stride_bytes, stats_dev))
+        return r;
+    return rbf_encode_gop_finish(ctx, params_out, k_out);
 }
 
 // ------------------------------------------------------------------------------------------

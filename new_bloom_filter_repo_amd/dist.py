@@ -155,6 +155,8 @@ class OutboxGather:
                 return
             ob, count, ready, posted = job
             try:
+                # After an error EVERY rank has raised in the same exchange (the flag travels in the size collective), so every rank
+                # skips the same later jobs: nobody is left alone in a collective.
                 if self.error is None:
                     self._post(ob, count, ready)
             except BaseException as e:                          # surfaced by the next begin() / flush() of the owning thread
@@ -215,24 +217,35 @@ class OutboxGather:
 
     def _exchange(self, ob, count):
         torch, dist = self._torch, self._dist
-        heads = self.out[ob][:count, :4].cpu().numpy().view(np.uint64)          # blocks this (helper) thread only
-        used, damaged = [], 0
-        for h in heads:
-            if int(h[0]) != RECORD_MAGIC or int(h[3]) != 0 or int(h[2]) > self.slot_words * 8:
-                damaged = 1
-                used.append(0)
-            else:
-                used.append((int(h[2]) + 7) // 8 * 8)
-        # sizes + an error flag travel together: a rank with a damaged record must not leave the others hanging in the collective
+        # Everything that can fail on THIS rank alone -- the header read, the checks, the payload's allocation -- happens in front of
+        # the size collective, and its failure travels IN the collective (flag 2; 1 = damaged record): the other ranks are already
+        # in, or on their way into, that all_gather and would wait for ever for a rank that raised before it.
+        used, flag, local, payload = [0] * count, 0, None, None
+        try:
+            heads = self.out[ob][:count, :4].cpu().numpy().view(np.uint64)          # blocks this (helper) thread only
+            self._hook("heads")
+            for j, h in enumerate(heads):
+                if int(h[0]) != RECORD_MAGIC or int(h[3]) != 0 or int(h[2]) > self.slot_words * 8:
+                    flag = 1
+                else:
+                    used[j] = (int(h[2]) + 7) // 8 * 8
+            if flag:
+                used = [0] * count
+            elif self.rank != self.dst and sum(used):
+                payload = torch.cat([self.out[ob][j, :u // 8].view(torch.uint8) for j, u in enumerate(used)])
+        except BaseException as e:
+            used, flag, local, payload = [0] * count, 2, e, None
         mine = torch.zeros(self.G + 1, dtype=torch.int64, device=self.device)
         mine[:count] = torch.tensor(used, dtype=torch.int64, device=self.device)
-        mine[self.G] = damaged
+        mine[self.G] = flag
         sizes = [torch.zeros(self.G + 1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
         dist.all_gather(sizes, mine, group=self.group)
         sizes = [[int(x) for x in t.cpu().tolist()] for t in sizes]
+        if local is not None:
+            raise local                                         # after the collective: the peers have seen the flag
         bad = [r for r in range(self.world) if sizes[r][self.G]]
         if bad:
-            raise ValueError("a packed record in the outbox of rank(s) %s is damaged" % bad)      # on EVERY rank, after the collective
+            raise ValueError("a packed record in the outbox of rank(s) %s is damaged, or the rank failed before the exchange" % bad)      # on EVERY rank
         sizes = [t[:self.G] for t in sizes]
         ops, keep = [], []
         if self.rank == self.dst:
@@ -240,13 +253,15 @@ class OutboxGather:
             for r in range(self.world):
                 if r != self.dst and sum(sizes[r]):
                     ops.append(dist.P2POp(dist.irecv, self.inbox[ob][r][:sum(sizes[r])], self._peer(r), self.group))
-        elif sum(used):
-            payload = torch.cat([self.out[ob][j, :u // 8].view(torch.uint8) for j, u in enumerate(used)])
+        elif payload is not None:
             keep.append(payload)
             ops.append(dist.P2POp(dist.isend, payload, self._peer(self.dst), self.group))
             self.bytes_sent += int(payload.numel())
         works = dist.batch_isend_irecv(ops) if ops else []
         return works, keep
+
+    def _hook(self, where):
+        """Test seam (tests/test_dist_cpu.py makes one rank's helper thread fail here, in front of the collective)."""
 
     def _post(self, ob, count, ready):
         """Exchange `count` slots of outbox ob: on the comm stream behind `ready` (the writers' events).  Helper thread (or inline)."""
@@ -310,27 +325,38 @@ class OutboxGather:
 
 def gather_records(records, dst=0, group=None, device=None):
     """Gather every rank's [(frame_index, type, bytes)] to `dst`; returns the merged list sorted by
-    frame index on dst, None elsewhere.  Works on any backend (tensors live on `device`)."""
+    frame index on dst, None elsewhere.  Works on any backend (tensors live on `device`).  Exact sizes, like
+    gather_device_records: the lengths are all-gathered, then every rank but `dst` sends its bytes as one point-to-point
+    message and `dst` posts one receive per peer; dst's own records stay where they are, nothing is padded."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    payload = torch.from_numpy(pack_records(records)).to(device)
+    packed = pack_records(records)
+    payload = torch.from_numpy(packed).to(device)
     length = torch.tensor([payload.numel()], dtype=torch.int64, device=device)
     lengths = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(lengths, length, group=group)
-    maxlen = int(max(int(x.item()) for x in lengths))
-    padded = torch.zeros(maxlen, dtype=torch.uint8, device=device)
-    padded[:payload.numel()] = payload
-    slots = [torch.empty(maxlen, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, slots, dst=dst, group=group)
+    lengths = [int(x.item()) for x in lengths]
+    ops, inbox = [], {}
+    if rank == dst:
+        for r in range(world):
+            if r != dst:
+                inbox[r] = torch.empty(lengths[r], dtype=torch.uint8, device=device)
+                ops.append(dist.P2POp(dist.irecv, inbox[r], peer(r), group))
+    else:
+        ops.append(dist.P2POp(dist.isend, payload, peer(dst), group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     if rank != dst:
         return None
     merged = []
     for r in range(world):
-        merged += unpack_records(slots[r][:int(lengths[r].item())].cpu().numpy().tobytes())
+        merged += unpack_records(packed.tobytes() if r == dst else inbox[r].cpu().numpy().tobytes())
     merged.sort(key=lambda x: x[0])
     return merged
 

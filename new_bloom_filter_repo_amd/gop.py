@@ -189,6 +189,12 @@ class GopCoder:
 
     def encode(self, gop=0):
         """Enqueue one full pass over resident GOP `gop`; returns after the Bloom kernels are enqueued."""
+        self.encode_begin(gop)
+        self.encode_finish()
+
+    def encode_begin(self, gop=0):
+        """First half (rbf_encode_gop_begin): the mask stage of resident GOP `gop` is enqueued; returns without waiting.
+        A caller that drives several coders (one context each) begins the next coder's GOP before it finishes this one."""
         if self.adaptive is not None:
             self.thresholds = self.adaptive_floors()
             self.thr_tab = (ctypes.c_int32 * self.pairs)(*self.thresholds)
@@ -197,12 +203,21 @@ class GopCoder:
             src, fstride, pitch, pstride = self.luma.ptr + gop * self.luma_bytes * self.F, self.luma_bytes, self.W * self.sb, self.sb
         else:
             src, fstride, pitch, pstride = self.frames.ptr + gop * self.frame_bytes * self.F, self.frame_bytes, self.W * self.C * self.sb, self.C * self.sb
-        nat.check(nat.lib().rbf_encode_gop(
+        nat.check(nat.lib().rbf_encode_gop_begin(
             self.ctx.handle, src, fstride, self.F, self.W, self.H,
             pitch, pstride, self.sb, self.thr, self.thr_tab, ctypes.byref(self.seeds),
             self.masks.ptr, self.mask_stride, self.ones.ptr,
-            self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr,
-            self.params, self.k))
+            self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr))
+
+    def encode_ready(self):
+        """True once the mask stage's counts have reached the host (encode_finish will not wait)."""
+        ready = ctypes.c_int(0)
+        nat.check(nat.lib().rbf_encode_gop_poll(self.ctx.handle, ctypes.byref(ready)))
+        return bool(ready.value)
+
+    def encode_finish(self):
+        """Second half (rbf_encode_gop_finish): waits for the counts, plans the filters (float64, host), enqueues the Bloom kernels."""
+        nat.check(nat.lib().rbf_encode_gop_finish(self.ctx.handle, self.params, self.k))
 
     def pack(self, block=None):
         """Compact this GOP's output rows into one exact-size record on the device (rbf_pack_records);

@@ -97,7 +97,7 @@ def test_unpack_device_record_parser():
         unpack_device_record(np.zeros(64, np.uint8), n)
 
 
-def _outbox_worker(rank, world, port, q, G, steps, sw):
+def _outbox_worker(rank, world, port, q, G, steps, sw, threaded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, REPO)
@@ -106,7 +106,8 @@ def _outbox_worker(rank, world, port, q, G, steps, sw):
     from new_bloom_filter_repo_amd import dist as DD
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        og = DD.OutboxGather(sw, G, torch.device("cpu"))
+        og = DD.OutboxGather(sw, G, torch.device("cpu"), threaded=threaded)
+        assert og.threaded == bool(threaded)
         for s in range(steps):
             slot = og.begin(0)
             rec = torch.from_numpy(_fake_record(1 + s % 3, 2 + (5 * s + 3 * rank) % 17, 1000 * s + 100000 * rank))   # this step's "record"
@@ -124,23 +125,26 @@ def _outbox_worker(rank, world, port, q, G, steps, sw):
             q.put((og.sent, og.s, got, og.bytes_sent))
         else:
             q.put((og.sent, og.s, None, og.bytes_sent))
+        og.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("G,steps", [(4, 11), (1, 3), (3, 6), (16, 5)])
-def test_outbox_gather_gloo_world2(G, steps):
+@pytest.mark.parametrize("G,steps,world,threaded", [(4, 11, 2, False), (1, 3, 2, False), (3, 6, 2, False), (16, 5, 2, False),
+                                                    (4, 11, 2, True), (1, 3, 2, True), (3, 7, 3, True), (16, 5, 3, True), (2, 9, 3, False)])
+def test_outbox_gather_gloo_world2(G, steps, world, threaded):
     """bench.py's N > 1 bookkeeping on CPU: slot sequence, alternating outboxes, one exact-size exchange per full outbox,
     a partly filled outbox flushed at the end (only its filled slots travel), every rank's records arriving on rank 0 in
-    step order with exactly their used size; rank 0 sends nothing."""
+    step order with exactly their used size; rank 0 sends nothing.  threaded=True is the path a GPU run takes (the exchange on the
+    helper thread, collectives and grouped point-to-point posts from there) -- here with 2 and 3 ranks."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() * 7 + G * 13 + steps) % 2000
-    procs = [ctx.Process(target=_outbox_worker, args=(r, 2, port, q, G, steps, 400)) for r in range(2)]
+    port = 31500 + (os.getpid() * 7 + G * 13 + steps + 100 * world + 50 * int(threaded)) % 2000
+    procs = [ctx.Process(target=_outbox_worker, args=(r, world, port, q, G, steps, 400, threaded)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = [q.get(timeout=120) for _ in range(2)]
+    outs = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -153,15 +157,78 @@ def test_outbox_gather_gloo_world2(G, steps):
     for sent, s, got, bytes_sent in outs:
         assert sent == gathers and s == gathers * G            # every rank issued the same exchanges
         if got is None:
-            assert bytes_sent == sum(want(st, 1)[0] for st in range(steps))      # rank 1 sent exactly its used bytes
+            assert bytes_sent in [sum(want(st, r)[0] for st in range(steps)) for r in range(1, world)]      # a sender sent exactly its used bytes
             continue
         assert bytes_sent == 0                                  # rank 0's records never travel
         # the last two rounds live in the two outboxes; round r used outbox r % 2 and holds steps r*G .. r*G+G-1
         for rnd in range(max(0, gathers - 2), gathers):
-            for r in range(2):
+            for r in range(world):
                 recs = got[(rnd % 2, r)]
                 steps_in = [st for st in range(rnd * G, rnd * G + G) if st < steps]
                 assert recs == [want(st, r) for st in steps_in], (rnd, r, recs)
+
+
+def _outbox_failure_worker(rank, world, port, q, mode, threaded):
+    """mode "damaged": rank 1 posts a record with a broken header in its second exchange; mode "helper": rank 1's exchange fails on its
+    own in front of the size collective (the header read raises).  Every rank must raise from begin() / flush(); nobody may hang."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    from new_bloom_filter_repo_amd import dist as DD
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G, steps = 2, 10
+    try:
+        og = DD.OutboxGather(400, G, torch.device("cpu"), threaded=threaded)
+        calls = {"n": 0}
+        if mode == "helper" and rank == 1:
+            def hook(where):
+                calls["n"] += 1
+                if calls["n"] == 2:
+                    raise RuntimeError("simulated device error in the helper thread")
+            og._hook = hook
+        raised, at = None, None
+        try:
+            for s in range(steps):
+                slot = og.begin(0)
+                rec = torch.from_numpy(_fake_record(1, 3 + s, 1000 * s + 100000 * rank))
+                slot.zero_()
+                slot[:rec.numel()] = rec
+                if mode == "damaged" and rank == 1 and s == 3:
+                    slot[0] = 12345                             # not the magic: second exchange (steps 2, 3)
+                og.end(0)
+            og.flush()
+        except (ValueError, RuntimeError) as e:
+            raised, at = type(e).__name__ + ": " + str(e), og.sent
+        og.close()
+        q.put((rank, raised, at))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,threaded,world", [("damaged", True, 2), ("damaged", True, 3), ("damaged", False, 2), ("helper", True, 2), ("helper", True, 3), ("helper", False, 2)])
+def test_outbox_gather_failure_raises_on_every_rank(mode, threaded, world):
+    """A damaged record on one rank, or one rank's exchange failing before the size collective, with the exchange on
+    the helper thread at world 2 and 3: EVERY rank raises, none hangs (the queue reads time out otherwise) and all exit cleanly."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() * 11 + 17 * world + (5 if threaded else 0) + (3 if mode == "helper" else 0)) % 2000
+    procs = [ctx.Process(target=_outbox_failure_worker, args=(r, world, port, q, mode, threaded)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r for r, _, _ in outs] == list(range(world))
+    for rank, raised, at in outs:
+        assert raised is not None, (rank, "did not raise")
+        if mode == "helper" and rank == 1:
+            assert "simulated device error" in raised, raised           # the rank that failed re-raises its own error
+        else:
+            assert "rank(s) [1]" in raised, raised                      # everybody else learns WHO failed, from the size collective
 
 
 def _fake_record(nframes, payload_words, tag):

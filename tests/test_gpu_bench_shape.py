@@ -105,6 +105,66 @@ def test_config2_1080p_gop_four_pipelines_vs_oracle(oracle):
         c.close()
 
 
+def test_two_phase_gop_interleaved_over_two_contexts_vs_oracle(oracle):
+    """rbf_encode_gop_begin / _poll / _finish (SURVEY 8b's masks -> host -> blooms split): ONE host thread drives two contexts with
+    DIFFERENT GOPs and issues begin(k + 1) before finish(k), three rounds; both contexts' records equal the CPU oracle's frame by frame.
+    Also the contract's errors: a second begin on a busy context, finish / poll without begin, and a bad argument that must leave the
+    context usable and the caller's buffers untouched (validation in front of the token and the witness clear)."""
+    import time
+    import torch
+    W, H, F = 1920, 1080, 12
+    n = W * H
+    gops = [np.stack(make_gop(2100 + k, W, H, F)) for k in range(2)]
+    want = [oracle_gop(oracle, g) for g in gops]
+    device = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device) for _ in range(2)]
+    ctxs = [nat.Context(0, s.cuda_stream) for s in streams]
+    coders = [GopCoder(c, W, H, F, channels=3, sample_bytes=1, planar_luma=True, keep_interleaved=False) for c in ctxs]
+    for c, g in zip(coders, gops):
+        c.load_frames(g)
+    L = nat.lib()
+    # errors first
+    for fn in (lambda: coders[0].encode_finish(), lambda: coders[0].encode_ready()):
+        with pytest.raises(nat.RbfError) as e:
+            fn()
+        assert e.value.code == nat.RBF_EINVAL
+    coders[0].witness.buf.upload(np.full(64, 0xAB, dtype=np.uint8))
+    c0 = coders[0]
+    with pytest.raises(nat.RbfError) as e:             # mask stride 7: refused before anything is enqueued or cleared
+        nat.check(L.rbf_encode_gop_begin(c0.ctx.handle, c0.luma.ptr, c0.luma_bytes, F, W, H, W, 1, 1, 0, None, ctypes.byref(c0.seeds),
+                                         c0.masks.ptr, 7, c0.ones.ptr, c0.filters.ptr, c0.filter_stride, c0.witness.ptr, c0.witness_stride, c0.stats.ptr))
+    assert e.value.code == nat.RBF_EINVAL
+    ctxs[0].sync()
+    assert (c0.witness.buf.download(64) == 0xAB).all(), "a refused begin cleared the caller's witness rows"
+    coders[0].encode_begin()
+    with pytest.raises(nat.RbfError) as e:
+        coders[0].encode_begin()
+    assert e.value.code == nat.RBF_EINVAL
+    coders[0].encode_finish()
+    ctxs[0].sync()
+    check_records(coders[0].results(), want[0], n, "after the refused calls")
+    # the interleaving the bench uses
+    for rep in range(3):
+        coders[0].encode_begin()
+        coders[1].encode_begin()
+        coders[0].encode_finish()
+        coders[1].encode_finish()
+    coders[0].encode_begin()
+    t0 = time.time()
+    while not coders[0].encode_ready():                # poll never blocks; the counts arrive within the mask kernel's time
+        assert time.time() - t0 < 30
+    coders[1].encode_begin()
+    coders[1].encode_finish()
+    coders[0].encode_finish()
+    torch.cuda.synchronize(device)
+    for k in range(2):
+        check_records(coders[k].results(), want[k], n, "context %d" % k)
+    for c in coders:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
 @pytest.mark.parametrize("W,H,F,force", [(3840, 2160, 9, 0), (3840, 2160, 5, 128), (2560, 1440, 6, 0), (2560, 1440, 4, 1 << 15)],
                          ids=["2160p_records_hashed_2_tiles", "2160p_tiled_insert_tab", "1440p_records_hashed_1_tile", "1440p_again_no_table_rewrite"])
 def test_config4_large_frames_gop_vs_oracle(oracle, W, H, F, force):
