@@ -4,6 +4,7 @@
 #include "rbf_kernels_i64.h"
 #include "rbf_kernels_r64.h"
 #include "rbf_kernels_s64.h"
+#include "rbf_kernels_u64.h"
 #include "rbf_kernels_noise.h"
 #include "rbf_kernels_pack.h"
 
@@ -969,19 +970,19 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
             hipLaunchKernelGGL(k_query_p4<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
                                n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                                ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
-        } else if (!ctx->query_dma && !ctx->query_r64 && pl.query_lds_bytes + S64_GEO_BYTES <= LDS_LIMIT && pl.double_buffer) {
-            // k_query_s64 (default): compacted table, geometry in LDS behind the two image buffers
-            uint32_t nactive; uint64_t empty[2];
-            const FrameTable stab = query_table_s64(tab, nframes, &nactive, empty);
+        } else if (!ctx->query_dma && !ctx->query_r64 && pl.query_lds_bytes + u64_geo_bytes(nframes) <= LDS_LIMIT && pl.double_buffer &&
+                   (uint64_t)nframes * filter_stride_bytes < (1ull << 32)) {
+            // k_query_u64 (default): coded frames ordered by floor(k*), 32-byte frame records in LDS behind the two image buffers
+            uint32_t nactive; uint64_t empty[2]; U64Classes cls;
+            const FrameTable utab = query_table_u64(tab, nframes, &nactive, &cls, empty);
             if (quiet_passthrough) empty[0] = empty[1] = 0;
-            // the 120-register kernel (a neighbour pipeline's mask / compaction waves fit next to it) unless the batch has floor(k*) = 4 or 5,
-            // which only the 127-register one passes in rows
-            bool wide = false;
-            for (uint32_t f = 0; f < nframes; ++f) if (tab.f[f].m && (tab.f[f].floor_k == 4u || tab.f[f].floor_k == 5u)) wide = true;
-            auto kern64 = wide ? k_query_s64w<0> : k_query_s64<0>;
+            // the 111-register kernel (two waves of a neighbour pipeline's mask / compaction kernels fit next to it on every SIMD) unless the
+            // batch has floor(k*) = 4 or 5, which only the 118-register one passes in rows
+            const bool wide = cls.n[3] + cls.n[4] > 0;
+            auto kern64 = wide ? k_query_u64w<0> : k_query_u64<0>;
             if (int r = allow_big_lds((const void *)kern64)) return r;
-            hipLaunchKernelGGL(kern64, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes + S64_GEO_BYTES, ctx->stream,
-                               n, nactive, stab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+            hipLaunchKernelGGL(kern64, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes + u64_geo_bytes(nactive), ctx->stream,
+                               n, nactive, utab, cls, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
                                ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out, empty[0], empty[1]);
         } else if (!ctx->query_dma) {
             uint32_t passthrough;

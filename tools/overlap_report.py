@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("k_query_s64t", "k_query_s64", "k_query_r64t", "k_query_r64", "k_query_f64t", "k_query_f64", "k_insert_tab", "k_insert_positions", "k_insert_records", "k_residual_mask_gop", "k_compact_witness",
+    for key in ("k_query_u64w", "k_query_u64", "k_query_s64t", "k_query_s64", "k_query_r64t", "k_query_r64", "k_query_f64t", "k_query_f64", "k_insert_tab", "k_insert_positions", "k_insert_records", "k_residual_mask_gop", "k_compact_witness",
                 "k_filter_reduce", "k_finish_ones", "k_hash_table", "k_pack"):
         if key in name:
             return key
