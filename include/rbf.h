@@ -105,35 +105,31 @@ int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes); 
 #define RBF_K_HASHTAB 12      /* k_hash_table: the per-batch table of the pixel indices' three hashes */
 #define RBF_K_COUNT   13
 int rbf_timing_enable(rbf_ctx *ctx, int on);
-/* Testing / tuning knob (bit mask).  0 (default) = pick the fastest variant that fits.
+/* Testing / tuning knob (bit mask).  0 (default) = pick the fastest variant that fits.  Only LIVE alternatives are selectable (ABI 3
+ * dropped the bits that picked superseded kernels: 6 and 13 are ignored).
  *   bit 0       always the generic (global-memory filter) kernels
- *   bit 1       LDS fast path without double-buffering the filter
+ *   bit 1       LDS fast path without double-buffering the filter (the integer Barrett kernels)
  *   bit 2       per-pixel threshold compare in the GOP mask kernel even for threshold 0
  *   bit 3       Barrett reductions only (never the FP64 h mod m, which is taken when every filter of a batch has 2^15 <= m < 2^23)
  *   bit 4       run k_hash_table (the pixel-index hash table the insert kernel gathers from, 32 bytes per pixel, shared by the
  *               contexts of a process) for every batch instead of once per (device, frame size, seeds).
  *               FOOTPRINT: the table is process-global device memory -- 32 * (width*height + 512) bytes per (device, frame size,
  *               seeds) in use, e.g. 66 MB at 1080p -- allocated by the first encode of a geometry and released when the last
- *               context holding it is destroyed or moves to another geometry.  Geometries whose table would exceed 96 MB
- *               (2560x1440 and up) never get one: their insert kernels hash the set positions instead.
- *   bit 5       never use that table: the insert kernel hashes the set positions itself, as in ABI build 1
- *   bit 6       the 4-pixels-per-lane FP64 query kernel (k_query_p4) instead of k_query_f64
+ *               context holding it is destroyed or moves to another geometry (including one that never uses a table).  Geometries
+ *               whose table would exceed 96 MB (2560x1440 and up) never get one: their insert kernels hash the set positions instead.
+ *   bit 5       never use that table: the insert kernel hashes the set positions itself
  *   bit 7       filters of several LDS tiles are inserted by the tiled k_insert_tab even inside rbf_encode_gop (default there:
  *               k_insert_positions + k_insert_records)
  *   bits 8..12  temporal chunks of the GOP mask kernel (0 = auto)
- *   bit 13      k_query_f64 (probe image staged by LDS-DMA, 64-bit activation hashes) instead of k_query_r64 (staged through
- *               registers, activation ranks), the default FP64 query kernel
  *   bit 14      k_insert_positions hashes the set positions itself whatever the frame size (default: only when the table would
  *               exceed 96 MB)
  *   bit 15      the query kernel never rewrites the hash table (default: a context that is the table's only holder has it
  *               rewritten in every batch, which keeps it in the Infinity Cache)
- *   bits 16..31 LDS tile cap in units of 64 dwords (0 = all of LDS) */
+ *   bits 16..31 LDS tile cap in units of 64 dwords (0 = all of LDS): forces the tiled kernels */
 int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
-/* Further testing / tuning knobs (the bit mask above is full).  RBF_OPT_QUERY_R64 (value 0 / 1): 1 = k_query_r64, the round-2 FP64
- * query kernel, where k_query_s64 (round 3: pass written in rows, frame geometry in LDS, wave priorities) would run. */
-#define RBF_OPT_QUERY_R64 1
-/* RBF_OPT_SEPARATE_FINISH (0 / 1): 1 = rbf_encode_gop always hands the ones counts out through the separate k_finish_ones launch
- * (default: inside the GOP mask kernel whenever that kernel covers the whole frame). */
+/* Further testing / tuning knobs.  RBF_OPT_SEPARATE_FINISH (0 / 1): 1 = rbf_encode_gop always hands the ones counts out through the
+ * separate k_finish_ones launch (default: inside the GOP mask kernel whenever that kernel covers the whole frame).  (Option 1 of ABI 2,
+ * the round-2 query kernel, is gone with that kernel: RBF_EINVAL.) */
 #define RBF_OPT_SEPARATE_FINISH 2
 int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value);
 int rbf_timing_reset(rbf_ctx *ctx);

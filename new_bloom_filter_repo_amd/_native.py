@@ -18,7 +18,7 @@ RBF_ERANGE = -34
 K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE, K_PACK, K_HASHTAB = range(13)
 KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack", "hashtab"]
 STATS_PER_FRAME = 4
-OPT_QUERY_R64, OPT_SEPARATE_FINISH = 1, 2    # rbf_ctx_option keys (include/rbf.h)
+OPT_SEPARATE_FINISH = 2    # rbf_ctx_option keys (include/rbf.h); key 1 (round 3: the round-2 query kernel) is gone with that kernel
 
 
 class FilterParams(ctypes.Structure):
@@ -211,7 +211,7 @@ class Context:
             pass
 
     def option(self, option, value):
-        """rbf_ctx_option: further tuning knobs (OPT_QUERY_R64 = 1: the round-2 query kernel instead of k_query_s64)."""
+        """rbf_ctx_option: further tuning knobs (OPT_SEPARATE_FINISH: the GOP mask kernel's tail as its own launch)."""
         check(lib().rbf_ctx_option(self.handle, int(option), int(value)))
 
     def force_generic(self, on):

@@ -2,7 +2,6 @@
 // scratch management, launches on the context's single HIP stream, optional per-kernel timing.
 #include "../../include/rbf.h"
 #include "rbf_kernels_i64.h"
-#include "rbf_kernels_r64.h"
 #include "rbf_kernels_s64.h"
 #include "rbf_kernels_u64.h"
 #include "rbf_kernels_noise.h"
@@ -60,8 +59,6 @@ struct rbf_ctx {
     int no_two_phase = 0;            // 1 = tiled k_insert_tab even when the filter needs several LDS tiles
     int hash_positions = 0;          // 1 = k_insert_positions hashes the set positions itself whatever the table size
     int no_table_rewrite = 0;        // 1 = the query kernel never rewrites the hash table, sole holder or not
-    int query_dma = 0;               // 1 = k_query_f64 (LDS-DMA staging, 64-bit activation hashes) instead of k_query_r64
-    int query_r64 = 0;               // 1 = k_query_r64 (round 2) where k_query_s64 would run (rbf_ctx_option RBF_OPT_QUERY_R64)
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
     uint32_t *mask_ticket = nullptr;                              // the fused tail of the GOP mask kernel: workgroups done so far (zero between launches)
     int no_fused_finish = 0;                                      // 1 = always the separate k_finish_ones launch (rbf_ctx_option RBF_OPT_SEPARATE_FINISH)
@@ -74,7 +71,6 @@ struct rbf_ctx {
     uint32_t mask_chunks = 0;        // tuning: temporal chunks of the GOP mask kernel (0 = auto)
     int force_generic_mask_bits = 0; // tests: 1 = per-pixel threshold compare even for threshold 0
     int barrett_only = 0;            // tests/tuning: 1 = never take the FP64 reductions (mod_m_f64)
-    int query_p4 = 0;                // 1 = k_query_p4 (4 pixels per lane, two workgroups per CU) instead of k_query_f64
     int hash_rebuild = 0;            // 1 = run k_hash_table for every batch instead of taking the table the last query kernel wrote
     int no_hash_table = 0;           // 1 = the insert kernel hashes the set positions itself
     struct SharedHashTable *hash_shared = nullptr;                // the pixel-index hash table this context holds a reference to
@@ -368,11 +364,9 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on)
     ctx->force_generic_mask_bits = (on & 4) ? 1 : 0;
     ctx->barrett_only = (on & 8) ? 1 : 0;
     ctx->hash_rebuild = (on & 16) ? 1 : 0;
-    ctx->query_p4 = (on & 64) ? 1 : 0;
     ctx->no_hash_table = (on & 32) ? 1 : 0;
     ctx->no_two_phase = (on & 128) ? 1 : 0;
     ctx->mask_chunks = (uint32_t)(on >> 8) & 0x1F;           // tuning knob, bits 8..12
-    ctx->query_dma = (on & (1 << 13)) ? 1 : 0;
     ctx->hash_positions = (on & (1 << 14)) ? 1 : 0;
     ctx->no_table_rewrite = (on & (1 << 15)) ? 1 : 0;
     ctx->tile_words = ((uint32_t)on >> 16) << 6;             // bits 16..31: LDS tile cap in units of 64 dwords
@@ -383,7 +377,6 @@ int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value)
 {
     if (!ctx) return fail(RBF_EINVAL, "null context");
     switch (option) {
-    case RBF_OPT_QUERY_R64: ctx->query_r64 = value ? 1 : 0; return RBF_OK;
     case RBF_OPT_SEPARATE_FINISH: ctx->no_fused_finish = value ? 1 : 0; return RBF_OK;
     default: return fail(RBF_EINVAL, "unknown option %d", option);
     }
@@ -507,9 +500,8 @@ static inline uint64_t nseg_of(uint64_t n) { return (n + SEG_PIXELS - 1) / SEG_P
 constexpr size_t LDS_LIMIT = 160 * 1024;
 struct Plan {
     bool fast_insert;            // LDS partial-filter insert (any filter size, tiled when needed)
-    int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles (Barrett), 3 LDS tiles, FP64 (k_query_f64t)
+    int query_kind;              // 0 generic (global probes), 1 LDS whole filter, 2 LDS tiles (Barrett), 3 LDS tiles, FP64 (k_query_s64t)
     bool double_buffer, small_m;
-    bool query_p4;               // k_query_p4 instead of k_query_f64
     bool insert_tab;             // insert through the hash table + FP64 reductions (same size condition, any LDS fit)
     bool insert_two_phase;       // ... as k_insert_positions + k_insert_records (filters of more than one LDS tile, counts known on the host)
     bool f64_mod;                // every coded frame has F64MOD_M_MIN <= m <= F64MOD_M_MAX: reductions through the FP64 pipe
@@ -558,8 +550,8 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     const bool auto_tiles = ctx->tile_words == 0;
     p.fast_insert = !ctx->force_generic && mmax > 0 && !(auto_tiles && p.insert_tiles > MAX_INSERT_TILES);
     // query
-    // k_query_f64 (FP64 reductions, probe image) is double-buffered only; its buffers end with the SAFE dwords
-    if (2 * (fbytes + 16) > LDS_LIMIT || ctx->single_buffer) p.f64_mod = false;
+    // k_query_u64 (FP64 reductions, probe image) is double-buffered only; its buffers end with the SAFE dwords
+    if (2 * (fbytes + 16) + u64_geo_bytes(nframes) > LDS_LIMIT || ctx->single_buffer) p.f64_mod = false;      // (filters that fit twice but leave no room for the frame records go to the tiled kernel: one buffer)
     const size_t qbytes = fbytes + (p.f64_mod ? 16 : 0);
     p.double_buffer = 2 * qbytes <= LDS_LIMIT && !ctx->single_buffer;
     p.query_kind = 0;
@@ -610,7 +602,7 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
         p.slices.n[f] = (uint8_t)sf;
         p.per_tile += sf;
     }
-    // FP64 geometries that do not fit LDS twice (or whose tile size a test caps): k_query_f64t, double-buffered tiles
+    // FP64 geometries that do not fit LDS twice (or whose tile size a test caps): k_query_s64t, one buffer of maximal tiles
     if (!ctx->force_generic && mmax > 0 && sizes_f64 && !ctx->barrett_only && !ctx->single_buffer && !(p.query_kind == 1 && p.f64_mod)) {
         const uint32_t cap = (uint32_t)((LDS_LIMIT - S64_GEO_BYTES) / 4 - 4) & ~3u;       // one buffer of tile_words + 4 dwords, k_query_s64t's geometry behind it
         uint32_t tw = (p.fwords_max + 3u) & ~3u;
@@ -625,33 +617,13 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     if (p.query_kind != 1 && p.query_kind != 3) p.f64_mod = false;
     p.insert_tab = p.fast_insert && sizes_f64 && !ctx->no_hash_table && !ctx->barrett_only;
     p.image_stride_words = (p.fwords_max + 3u) & ~3u;
-    p.query_p4 = p.query_kind == 1 && p.f64_mod && ctx->query_p4;       // two single-buffered workgroups per CU, 4 pixels per lane (measured 7 % slower)
-    if (p.query_p4) p.query_lds_bytes = (size_t)(((p.fwords_max + 3u) & ~3u) + 4u) * 4;
-    const uint32_t segpx = p.query_p4 ? (uint32_t)P4_SEG_PIXELS : (p.query_kind == 1 || p.query_kind == 3) ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
+    const uint32_t segpx = (p.query_kind == 1 || p.query_kind == 3) ? (uint32_t)QL_SEG_PIXELS : p.query_kind == 2 ? (uint32_t)TQ_SEG_PIXELS : (uint32_t)SEG_PIXELS;
     p.nseg = (n + segpx - 1) / segpx;
     p.words_per_seg = segpx / 64;
     return p;
 }
 
-// The FrameTable k_query_r64 / k_query_r64t read (rbf_kernels_r64.h): M as in `qtab` (bits of -1/m); T = the coded frames'
-// thresholds SORTED (entry j = j-th smallest, ~0 past the last one); floor_k |= c << 8 with c = coded thresholds below the frame's own.
-static FrameTable rank_table(const FrameTable &tab, const FrameTable &qtab, uint32_t nframes, uint32_t *any_passthrough)
-{
-    *any_passthrough = 0;
-    for (uint32_t f = 0; f < nframes; ++f) if (!tab.f[f].m) *any_passthrough = 1;
-    FrameTable rtab = qtab;
-    uint64_t sorted[MAX_BATCH];
-    uint32_t coded = 0;
-    for (uint32_t f = 0; f < nframes; ++f) if (tab.f[f].m) sorted[coded++] = tab.f[f].T;
-    std::sort(sorted, sorted + coded);
-    for (uint32_t f = 0; f < nframes; ++f) {
-        rtab.f[f].T = f < coded ? sorted[f] : ~0ull;
-        if (tab.f[f].m) rtab.f[f].floor_k = tab.f[f].floor_k | ((uint32_t)(std::lower_bound(sorted, sorted + coded, tab.f[f].T) - sorted) << 8);
-    }
-    return rtab;
-}
-
-// The FrameTable k_query_s64 reads (rbf_kernels_s64.h): COMPACTED over the coded frames -- entry j = j-th coded frame: m, M = bits of
+// The FrameTable k_query_s64t reads (rbf_kernels_s64.h): COMPACTED over the coded frames -- entry j = j-th coded frame: m, M = bits of
 // -1/m, floor_k = floor(k*) | c << 8 | frame index << 16 (c = coded thresholds below the frame's own), T = j-th smallest threshold.
 // `empty`: bit f = frame f is not coded.
 static FrameTable query_table_s64(const FrameTable &tab, uint32_t nframes, uint32_t *nactive, uint64_t (&empty)[2])
@@ -914,88 +886,40 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         filter_stride_bytes = (uint64_t)pl.image_stride_words * 4;
     }
     if (pl.query_kind == 3) {
-        FrameTable qtab = tab;
-        for (uint32_t f = 0; f < nframes; ++f)
-            if (qtab.f[f].m) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
-        bool few_probes = true;                                   // k_query_s64t keeps a frame's probe positions in registers
-        for (uint32_t f = 0; f < nframes; ++f) if (tab.f[f].m && tab.f[f].floor_k > S64T_MAX_FK) few_probes = false;
-        if (!ctx->query_dma && !ctx->query_r64 && few_probes) {
-            uint32_t nactive; uint64_t empty[2];
-            const FrameTable stab = query_table_s64(tab, nframes, &nactive, empty);
-            if (quiet_passthrough) empty[0] = empty[1] = 0;
-            if (int r = allow_big_lds((const void *)k_query_s64t<0>)) return r;
-            hipLaunchKernelGGL(k_query_s64t<0>, dim3((uint32_t)bx), dim3(QL_THREADS), s64t_lds_bytes(pl.query_tile_words), ctx->stream,
-                               n, nactive, stab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
-                               ctx->seg_cnt, pl.nseg, ctx->pass_words, empty[0], empty[1]);
-        } else if (!ctx->query_dma) {
-            uint32_t passthrough;
-            const FrameTable rtab = rank_table(tab, qtab, nframes, &passthrough);
-            if (quiet_passthrough) passthrough = 0;
-            if (int r = allow_big_lds((const void *)k_query_r64t<0>)) return r;
-            const size_t lds_bytes = pl.query_lds_bytes > 2 * MAX_BATCH * 8 + 16 ? pl.query_lds_bytes : (size_t)2 * MAX_BATCH * 8 + 16;   // room for the thresholds' copy
-            hipLaunchKernelGGL(k_query_r64t<0>, dim3((uint32_t)bx), dim3(QL_THREADS), lds_bytes, ctx->stream,
-                               n, nframes, rtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
-                               ctx->seg_cnt, pl.nseg, ctx->pass_words, passthrough);
-        } else {
-            auto kern = k_query_f64t<0>;
-            if (int r = allow_big_lds((const void *)kern)) return r;
-            hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                               n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
-                               ctx->seg_cnt, pl.nseg, ctx->pass_words);
-        }
+        uint32_t nactive; uint64_t empty[2];
+        const FrameTable stab = query_table_s64(tab, nframes, &nactive, empty);
+        if (quiet_passthrough) empty[0] = empty[1] = 0;
+        if (int r = allow_big_lds((const void *)k_query_s64t)) return r;
+        hipLaunchKernelGGL(k_query_s64t, dim3((uint32_t)bx), dim3(QL_THREADS), s64t_lds_bytes(pl.query_tile_words), ctx->stream,
+                           n, nactive, stab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
+                           ctx->seg_cnt, pl.nseg, ctx->pass_words, empty[0], empty[1]);
     } else if (pl.query_kind == 1 && pl.f64_mod) {
-        // k_query_f64 reads -1/m (IEEE double, computed here on the host) from the table's M field instead of the Barrett constant
-        FrameTable qtab = tab;
-        for (uint32_t f = 0; f < nframes; ++f)
-            if (qtab.f[f].m) { const double ninv = -1.0 / (double)qtab.f[f].m; memcpy(&qtab.f[f].M, &ninv, 8); }
-        auto kern = k_query_f64<0>;
-        if (int r = allow_big_lds((const void *)kern)) return r;
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
-        // the kernel hashes every index anyway: it leaves the hash table of this geometry for the next batch's insert
-        uint4 *table_out = nullptr;
-        // A context that is the table's only holder has the kernel -- which hashes every index anyway -- write it again: 66 MB of
-        // identical values whose only purpose is to be in the Infinity Cache when the next batch's insert gathers from them (one
+        // A context that is the pixel-index hash table's only holder has the kernel -- which hashes every index anyway -- write it again:
+        // 66 MB of identical values whose only purpose is to be in the Infinity Cache when the next batch's insert gathers from them (one
         // pipeline: insert 47 -> 38 us, step 214 -> 209).  With several holders the table stays cached by being used.
+        uint4 *table_out = nullptr;
         const SharedHashTable *sh = ctx->hash_shared;
         if (table_for_next && sh && sh->n == n && sh->seeds.h1 == sd.h1 && sh->seeds.h2 == sd.h2 && sh->seeds.act == sd.act && !ctx->no_hash_table) {
             bool sole;
             { std::lock_guard<std::mutex> lk(g_hash_mu); sole = sh->refs == 1; }
             if (sole && !ctx->no_table_rewrite) table_out = ctx->hash_tab;
         }
-        if (pl.query_p4) {
-            if (int r = allow_big_lds((const void *)k_query_p4<0>)) return r;
-            hipLaunchKernelGGL(k_query_p4<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                               n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
-                               ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
-        } else if (!ctx->query_dma && !ctx->query_r64 && pl.query_lds_bytes + u64_geo_bytes(nframes) <= LDS_LIMIT && pl.double_buffer &&
-                   (uint64_t)nframes * filter_stride_bytes < (1ull << 32)) {
-            // k_query_u64 (default): coded frames ordered by floor(k*), 32-byte frame records in LDS behind the two image buffers
-            uint32_t nactive; uint64_t empty[2]; U64Classes cls;
-            const FrameTable utab = query_table_u64(tab, nframes, &nactive, &cls, empty);
-            if (quiet_passthrough) empty[0] = empty[1] = 0;
-            // the 111-register kernel (two waves of a neighbour pipeline's mask / compaction kernels fit next to it on every SIMD) unless the
-            // batch has floor(k*) = 4 or 5, which only the 118-register one passes in rows
-            const bool wide = cls.n[3] + cls.n[4] > 0;
-            auto kern64 = wide ? k_query_u64w<0> : k_query_u64<0>;
-            if (int r = allow_big_lds((const void *)kern64)) return r;
-            hipLaunchKernelGGL(kern64, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes + u64_geo_bytes(nactive), ctx->stream,
-                               n, nactive, utab, cls, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
-                               ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out, empty[0], empty[1]);
-        } else if (!ctx->query_dma) {
-            uint32_t passthrough;
-            const FrameTable rtab = rank_table(tab, qtab, nframes, &passthrough);
-            if (quiet_passthrough) passthrough = 0;
-            if (int r = allow_big_lds((const void *)k_query_r64<0>)) return r;
-            hipLaunchKernelGGL(k_query_r64<0>, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                               n, nframes, rtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
-                               ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out, passthrough);
-        } else
-        hipLaunchKernelGGL(kern, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes, ctx->stream,
-                           n, nframes, qtab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
-                           ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out);
+        // k_query_u64: coded frames ordered by floor(k*), 32-byte frame records in LDS behind the two image buffers
+        uint32_t nactive; uint64_t empty[2]; U64Classes cls;
+        const FrameTable utab = query_table_u64(tab, nframes, &nactive, &cls, empty);
+        if (quiet_passthrough) empty[0] = empty[1] = 0;
+        // the 111-register kernel (two waves of a neighbour pipeline's mask / compaction kernels fit next to it on every SIMD) unless the
+        // batch has floor(k*) = 4 or 5, which only the 118-register one passes in rows
+        const bool wide = cls.n[3] + cls.n[4] > 0;
+        auto kern64 = wide ? k_query_u64w<0> : k_query_u64<0>;
+        if (int r = allow_big_lds((const void *)kern64)) return r;
+        hipLaunchKernelGGL(kern64, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes + u64_geo_bytes(nactive), ctx->stream,
+                           n, nactive, utab, cls, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,
+                           ctx->seg_cnt, pl.nseg, ctx->pass_words, table_out, empty[0], empty[1]);
     } else if (pl.query_kind == 1) {
         auto kern = pl.double_buffer ? (pl.small_m ? k_query_lds<true, true> : k_query_lds<true, false>)
                                      : (pl.small_m ? k_query_lds<false, true> : k_query_lds<false, false>);
@@ -1088,8 +1012,8 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                 if (itab.f[f].m) { const double ninv = -1.0 / (double)itab.f[f].m; memcpy(&itab.f[f].M, &ninv, 8); }
         auto ikern = pl.small_m ? k_insert_lds<true> : k_insert_lds<false>;
         if (int r = allow_big_lds((const void *)ikern)) return r;
-        if (int r = allow_big_lds((const void *)k_insert_tab<0, false>)) return r;
-        if (int r = allow_big_lds((const void *)k_insert_tab<0, true>)) return r;
+        if (int r = allow_big_lds((const void *)k_insert_tab<false>)) return r;
+        if (int r = allow_big_lds((const void *)k_insert_tab<true>)) return r;
         const bool two_phase = pl.insert_two_phase && use_tab;    // (its record memory was reserved above)
         if (two_phase) {
             // itab.floor_k / rtab.T carry the index of the frame's first record (the kernels' own use of those fields: none)
@@ -1107,10 +1031,10 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
             if (int r = allow_big_lds((const void *)k_insert_records)) return r;
             LaunchTimer t(ctx, RBF_K_INSERT);
             if (hashed_positions)
-                hipLaunchKernelGGL((k_insert_positions<0, true>), dim3((uint32_t)S1, nframes), dim3(IP_THREADS), 0, ctx->stream,
+                hipLaunchKernelGGL((k_insert_positions<true>), dim3((uint32_t)S1, nframes), dim3(IP_THREADS), 0, ctx->stream,
                                    (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)nullptr, sd, ctx->ins_records, ctx->ins_counters);
             else
-                hipLaunchKernelGGL((k_insert_positions<0, false>), dim3((uint32_t)S1, nframes), dim3(IP_THREADS), 0, ctx->stream,
+                hipLaunchKernelGGL((k_insert_positions<false>), dim3((uint32_t)S1, nframes), dim3(IP_THREADS), 0, ctx->stream,
                                    (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, sd, ctx->ins_records, ctx->ins_counters);
         }
         for (uint32_t f0 = 0; f0 < nframes;) {                    // groups of pl.insert_group coded frames
@@ -1132,11 +1056,11 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                                    (const uint2 *)ctx->ins_records, (const uint32_t *)ctx->ins_counters, rtab, ctx->partials, part_stride,
                                    pl.insert_tile_words, grp, per_tile, pl.S);
             } else if (use_tab && hashed_positions)
-                hipLaunchKernelGGL((k_insert_tab<0, true>), dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                hipLaunchKernelGGL((k_insert_tab<true>), dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
                                    (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)nullptr, sd, ctx->partials, part_stride,
                                    pl.insert_tile_words, grp, per_tile, pl.S);
             else if (use_tab)
-                hipLaunchKernelGGL((k_insert_tab<0, false>), dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                hipLaunchKernelGGL((k_insert_tab<false>), dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
                                    (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, sd, ctx->partials, part_stride,
                                    pl.insert_tile_words, grp, per_tile, pl.S);
             else
@@ -1193,7 +1117,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
     return RBF_OK;
 }
 
-// One chunk of at most MAX_BATCH frames.  The FP64 kernels (hash-table insert, k_query_r64 / r64t) need EVERY coded filter of
+// One chunk of at most MAX_BATCH frames.  The FP64 kernels (hash-table insert, k_query_u64 / k_query_s64t) need EVERY coded filter of
 // their launch inside F64MOD_M_MIN <= m <= F64MOD_M_MAX; a single nearly static frame (1080p: < ~0.2 % changed pixels) used to
 // send its whole batch to the round-1 Barrett kernels.  A mixed batch is now coded in two passes over disjoint frame sets --
 // first the out-of-range frames (Barrett kernels; they also write the empty outputs of every frame that is not theirs), then
@@ -1209,7 +1133,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
     uint32_t in_range = 0, out_of_range = 0;
     for (uint32_t f = 0; f < nframes; ++f)
         if (params[f].m) ++((params[f].m >= F64MOD_M_MIN && params[f].m <= F64MOD_M_MAX) ? in_range : out_of_range);
-    if (in_range && out_of_range && !ctx->force_generic && !ctx->barrett_only && !ctx->query_dma && !ctx->no_hash_table && !ctx->single_buffer) {
+    if (in_range && out_of_range && !ctx->force_generic && !ctx->barrett_only && !ctx->no_hash_table && !ctx->single_buffer) {
         rbf_filter_params small[MAX_BATCH], big[MAX_BATCH];
         for (uint32_t f = 0; f < nframes; ++f) {
             small[f] = big[f] = params[f];
@@ -1217,7 +1141,7 @@ static int encode_chunk(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_strid
             (fp64 ? small[f] : big[f]).m = 0;
         }
         const Plan ps = make_plan(ctx, small, nframes, n, false), pb = make_plan(ctx, big, nframes, n, ones_host != nullptr);
-        const bool fp64_query = (pb.query_kind == 1 || pb.query_kind == 3) && pb.f64_mod && !pb.query_p4;
+        const bool fp64_query = (pb.query_kind == 1 || pb.query_kind == 3) && pb.f64_mod;
         if (fp64_query && pb.insert_tab && ps.nseg == pb.nseg && ps.words_per_seg == pb.words_per_seg) {
             if (int r = encode_chunk_pass(ctx, masks_dev, mask_stride_bytes, n, nframes, small, seeds, filters_dev, filter_stride_bytes,
                                           witnesses_dev, witness_stride_bytes, stats_dev, outputs_zeroed, nullptr, false, false))
@@ -1526,7 +1450,7 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
         uint32_t in_range = 0, out_of_range = 0;
         for (uint32_t f = 0; f < nframes; ++f)
             if (params[f].m) ++((params[f].m >= F64MOD_M_MIN && params[f].m <= F64MOD_M_MAX) ? in_range : out_of_range);
-        if (in_range && out_of_range && !ctx->force_generic && !ctx->barrett_only && !ctx->query_dma && !ctx->single_buffer) {
+        if (in_range && out_of_range && !ctx->force_generic && !ctx->barrett_only && !ctx->single_buffer) {
             rbf_filter_params small[MAX_BATCH], big[MAX_BATCH];
             for (uint32_t f = 0; f < nframes; ++f) {
                 small[f] = big[f] = params[f];
@@ -1534,7 +1458,7 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
                 (fp64 ? small[f] : big[f]).m = 0;
             }
             const Plan ps = make_plan(ctx, small, nframes, n), pb = make_plan(ctx, big, nframes, n);
-            if ((pb.query_kind == 1 || pb.query_kind == 3) && pb.f64_mod && !pb.query_p4 && ps.nseg == pl.nseg && pb.nseg == pl.nseg &&
+            if ((pb.query_kind == 1 || pb.query_kind == 3) && pb.f64_mod && ps.nseg == pl.nseg && pb.nseg == pl.nseg &&
                 ps.words_per_seg == wps && pb.words_per_seg == wps) {
                 FrameTable ts, tb;
                 if (int r = fill_table(small, nframes, &ts)) return r;

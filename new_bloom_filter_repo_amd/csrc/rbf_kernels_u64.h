@@ -34,7 +34,6 @@ constexpr uint32_t U64_REC_BYTES = 32;
 __host__ __device__ constexpr uint32_t u64_geo_bytes(uint32_t nactive) { return (nactive + 1u) * U64_REC_BYTES; }   // LDS behind the two image buffers: one record per coded frame + 1
 constexpr int U64_CLASSES = 6;                                    // floor(k*) = 1, 2, 3, 4, 5 in rows, then everything else (plain pass)
 
-#define U64_OVERLAP(FK, WIDE) ((FK) < 5)
 struct U64Classes { uint32_t n[U64_CLASSES]; };                  // coded frames per class, in the order of the compacted table
 
 // Host: the FrameTable k_query_u64 reads (see the kernel) from the batch's plain table (m, floor_k, T per frame; m == 0: not coded).
@@ -76,6 +75,7 @@ __host__ inline FrameTable query_table_u64(const FrameTable &tab, uint32_t nfram
 // front of the next barrier.  M0 = LDS address of the wave's piece; saved and restored around the block (a reserved register, not a
 // clobber).  Every piece runs under a launch-constant lane mask (rows are staged at the batch's pitch: lanes past its end must not
 // write behind the buffer; a piece wholly past it runs with no lanes).
+template <bool ON>
 struct RowDmaC {
     const uint8_t *image;           // the batch's probe images (the kernel argument: saddr addressing)
     uint32_t src;                   // byte offset of the row to stage + wave * 1024 + lane * 16 (the image block is < 4 GB)
@@ -109,10 +109,9 @@ struct RowDmaC {
                      : "s"(dst_m0), "v"(src), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "s"(image), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]), "s"(mask[3]), "s"(mask[4])
                      : "memory", "scc");
     }
-    template <int AB>
     __device__ __forceinline__ void at(int g)
     {
-        if (!(AB & 8) && g == 0) issue();
+        if (ON && g == 0) issue();
     }
 };
 
@@ -136,8 +135,8 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
 // `cls.n[k]`: frames of class k.  `empty_lo / empty_hi`: bit f set = frame f of the batch is not coded and this launch writes its
 // (empty) outputs.  Dynamic LDS: two image buffers of ((fwords_max + 3) & ~3) + 4 dwords, then u64_geo_bytes(nactive).
 // `image_stride_words32` is also what is staged per frame: rows must be readable over their whole pitch (the library's are).
-// AB (tools/bench_query5.hip only; the library instantiates 0): 8 = no staging, 32 = no barrier (wrong results), 64 = no outputs,
-// 4 = no pass counts, 1 / 2 as in frame_pass_rows, 2048 = no wave priorities.
+// AB: measurement variants for tools/bench_query5.hip (the library instantiates 0, where every test below folds away): 4 = no pass
+// counts, 8 = no staging, 32 = no barrier (wrong results), 64 = no outputs, 2048 = no wave priorities.
 template <int AB, bool WIDE>
 __device__ __forceinline__ void query_u64_body(
     uint64_t n, uint32_t nactive, const FrameTable &tab, const U64Classes &cls, Seeds seeds,
@@ -171,10 +170,7 @@ __device__ __forceinline__ void query_u64_body(
             h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
             if (live && i0 + it < n) validmask |= 1u << it;
         }
-        if (AB & 16) {
-#pragma unroll
-            for (int it = 0; it < QL_P; ++it) { h1[it] = (i0 + it) * P1; h2[it] = (i0 + it) * P2 + seeds.h2; ha[it] = (i0 + it) * P3; }
-        } else if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+        if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
 #pragma unroll
             for (int it = 0; it < QL_P; ++it) {
                 const bool act = (validmask >> it) & 1u;
@@ -243,7 +239,7 @@ __device__ __forceinline__ void query_u64_body(
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     const uint32_t pitch_bytes = (uint32_t)image_stride_words32 * 4u;
     const uint32_t off0 = wave * 1024u + lane * 16u;
-    RowDmaC dm;
+    RowDmaC<!(AB & 8)> dm;
     dm.image = reinterpret_cast<const uint8_t *>(image);
 #pragma unroll
     for (int i = 0; i < 5; ++i) dm.mask[i] = __ballot(off0 + (uint32_t)i * (QL_WAVES * 1024u) + 16u <= pitch_bytes);
@@ -253,7 +249,7 @@ __device__ __forceinline__ void query_u64_body(
         const uint32_t *w = reinterpret_cast<const uint32_t *>(geo);
         dm.src = w[8u * nactive + 4u] + off0;
         dm.dst_m0 = lds0 + wave * 1024u;
-        if (!(AB & 8)) dm.issue();
+        dm.at(0);
     }
     const uint32_t safe_v = vgpr_copy(safe_pos);
     const uint32_t seg_lane = seg * (QL_SEG_PIXELS / 8) + lane;      // my verdict byte inside a frame's row of pass bytes
@@ -292,20 +288,19 @@ __device__ __forceinline__ void query_u64_body(
             const double ninv = __builtin_bit_cast(double, ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(ga.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(ga.z));
             uint32_t x[4] = {0, 0, 0, 0};
             const bool rows = FK > 0 && whole_wave;
-            if (rows) rows_reduce4<AB>(0, hd1, hl1, hd2, hl2, m_v, ninv, x);          // needs no image: in front of the barrier
+            if (rows) rows_reduce4(0, hd1, hl1, hd2, hl2, m_v, ninv, x);          // needs no image: in front of the barrier
             dm.src = gb.x + off0;                                                      // (a uniform value used from the VGPR the read returned)
             dm.dst_m0 = (uint32_t)__builtin_amdgcn_readfirstlane(buf_sum - fbase) + wave * 1024u;
             if (!(AB & 8)) dma_wait_all();        // my pieces of THIS frame's image (issued during the previous pass, or by the prologue) have landed
             out_row = (uint32_t)__builtin_amdgcn_readfirstlane(gb.w);                 // output row of the PREVIOUS frame (shifted by the prologue)
             if (!(AB & 32)) __syncthreads();      // everyone's writes of the buffer I probe have landed; nobody probes the other one any more
             uint32_t pbf = 0;
-            uint64_t ts[16] = {};
             if (rows) {
-                if constexpr (FK > 0) frame_pass_rows<FK, AB, U64_OVERLAP(FK, WIDE)>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, dm, flush, ts);
+                if constexpr (FK > 0) frame_pass_rows<FK, (FK < 5), !(AB & 2048)>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, dm, flush);
             } else {
                 flush();
                 const uint32_t fk = FK > 0 ? (uint32_t)FK : (uint32_t)__builtin_amdgcn_readfirstlane(gb.z);
-                frame_pass_plain<AB>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, validmask, fbase, safe_v, m_v, ninv, fk, pbf, dm);
+                frame_pass_plain(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, validmask, fbase, safe_v, m_v, ninv, fk, pbf, dm);
             }
             out_pb = ~pbf & 0xFFu; out_pending = true;
             fbase = buf_sum - fbase;
@@ -332,8 +327,17 @@ __device__ __forceinline__ void query_u64_body(
     uint32_t fwords_max, uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words, uint4 *__restrict__ table_out, uint64_t empty_lo, uint64_t empty_hi
 #define RBF_U64_ARGS n, nactive, tab, cls, seeds, image, image_stride_words32, fwords_max, seg_cnt, nseg, pass_words, table_out, empty_lo, empty_hi
 // (120 VGPRs as k_query_s64: one wave of the planar mask kernel or of k_compact_witness per SIMD runs underneath it)
+#ifndef RBF_U64_VGPR_HALF
+#define RBF_U64_VGPR_HALF 60
+#endif
 template <int AB = 0>
-__attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) void k_query_u64(RBF_U64_PARAMS) { query_u64_body<AB, false>(RBF_U64_ARGS); }
+__attribute__((amdgpu_num_vgpr(RBF_U64_VGPR_HALF))) __global__ __launch_bounds__(QL_THREADS) void k_query_u64(RBF_U64_PARAMS)
+{
+#ifdef RBF_U64_PAD_VGPR                 // experiment (profiles/r04_coresidency.txt): occupy a high register so that fewer waves of other kernels fit next to this one
+    asm volatile("; pad" ::: RBF_U64_PAD_VGPR);
+#endif
+    query_u64_body<AB, false>(RBF_U64_ARGS);
+}
 template <int AB = 0>
 __global__ __launch_bounds__(QL_THREADS) void k_query_u64w(RBF_U64_PARAMS) { query_u64_body<AB, true>(RBF_U64_ARGS); }
 #undef RBF_U64_PARAMS

@@ -289,16 +289,16 @@ def test_fused_mask_tail_equals_separate_finish_kernel(oracle):
 
 def test_every_floor_k_branch_of_the_query_kernel_in_one_1080p_batch(oracle):
     """One 1080p GOP whose inter-frames have densities 0.3 ... 0.003, i.e. floor(k*) = 0, 0, 1, 2, 3, 3, 4, 5, 6, 7 in ONE launch of
-    k_query_s64w (the rows pass for 1..4, its single-buffered form for 5, the plain pass for 0, 6 and 7, ten different activation
-    thresholds for the rank search), one with floor(k*) <= 3 in k_query_s64 (the 120-register kernel) -- and with RBF_OPT_QUERY_R64
-    the round-2 kernel on the same batches.  Every frame against the oracle."""
+    k_query_u64w (class loops 1 ... 5 in rows -- 5 single-buffered -- and the plain pass for 0, 6 and 7; ten different activation
+    thresholds for the rank search; the host orders the frames by class, the records name their output rows), one with
+    floor(k*) <= 3 in k_query_u64 (the 111-register kernel), and one with an ODD number of coded frames of one class (the packed
+    pass counts end on a single frame).  Every frame against the oracle."""
     from new_bloom_filter_repo_amd.synthetic import next_frame
     W, H = 1920, 1080
     n = W * H
-    # the first batch contains floor(k*) = 4 and 5 -> k_query_s64w (rows up to 5); the second has 0 ... 3 only -> k_query_s64
-    # (120 registers: 3 single-buffered, 0 in the plain pass)
     for dens, ks in (([0.3, 0.2, 0.12, 0.0889, 0.05, 0.03, 0.02, 0.012, 0.006, 0.003], [0, 1, 2, 3, 4, 5, 6, 7]),
-                     ([0.2, 0.12, 0.0889, 0.05, 0.03], [0, 1, 2, 3])):
+                     ([0.2, 0.12, 0.0889, 0.05, 0.03], [0, 1, 2, 3]),
+                     ([0.0889, 0.0889, 0.0889], [2])):
         rng = np.random.default_rng(20260927 + len(dens))
         frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8)]
         for p in dens:
@@ -306,24 +306,25 @@ def test_every_floor_k_branch_of_the_query_kernel_in_one_1080p_batch(oracle):
         frames = np.stack(frames)
         want = oracle_gop(oracle, frames)
         assert sorted({int(k) for (_, _, k, l, _, _) in want if l}) == ks
-        for r64 in (0, 1):
-            ctx = nat.Context(0)
-            ctx.option(nat.OPT_QUERY_R64, r64)
-            coder = GopCoder(ctx, W, H, len(frames), planar_luma=True)
-            coder.load_frames(frames)
-            coder.encode()
-            check_records(coder.results(), want, n, "floor_k %s, r64=%d" % (ks, r64))
-            coder.close()
-            ctx.close()
+        ctx = nat.Context(0)
+        coder = GopCoder(ctx, W, H, len(frames), planar_luma=True)
+        coder.load_frames(frames)
+        coder.encode()
+        res = coder.results()
+        check_records(res, want, n, "floor_k %s" % ks)
+        decode_back(ctx, res, n, "floor_k %s" % ks)
+        coder.close()
+        ctx.close()
 
 
 def test_tiled_query_kernels_by_floor_k_at_2160p(oracle):
-    """3840x2160 (two LDS tiles per frame): a batch with floor(k*) = 0, 0, 1, 2 runs k_query_s64t (every instantiation of its
-    frame body), one that contains floor(k*) = 3 falls back to k_query_r64t as a whole.  Every frame against the oracle."""
+    """3840x2160 (two LDS tiles per frame), k_query_s64t: batches with floor(k*) = 0, 0, 1, 2 / 2, 3 / 4, 5, 6 -- every instantiation
+    of its frame body that keeps the probe positions in registers (0 ... 4) and the one that walks them again per tile (5 and up;
+    round 3 sent every batch with floor(k*) > 2 to k_query_r64t).  Every frame against the oracle."""
     from new_bloom_filter_repo_amd.synthetic import next_frame
     W, H = 3840, 2160
     n = W * H
-    for seed, dens, ks in ((1, [0.3, 0.2, 0.12, 0.0889], [0, 1, 2]), (2, [0.0889, 0.05], [2, 3])):
+    for seed, dens, ks in ((1, [0.3, 0.2, 0.12, 0.0889], [0, 1, 2]), (2, [0.0889, 0.05], [2, 3]), (3, [0.02, 0.012, 0.006], [4, 5, 6])):
         rng = np.random.default_rng(seed)
         frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8)]
         for p in dens:

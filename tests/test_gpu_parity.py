@@ -14,28 +14,21 @@ from new_bloom_filter_repo_amd.synthetic import make_gop, make_mask, P_KSTAR_2_3
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["lds_double_buffer", "lds_query_r64", "lds_dma_query", "lds_single_buffer", "lds_barrett_only", "lds_query_p4", "hash_in_insert", "lds_tiled_1KiB", "lds_tiled_8KiB",
-                                        "lds_tiled_8KiB_insert_tab", "lds_tiled_8KiB_dma_query", "lds_tiled_8KiB_query_r64", "generic"])
+@pytest.fixture(scope="module", params=["lds_double_buffer", "lds_single_buffer", "lds_barrett_only", "hash_in_insert", "lds_tiled_1KiB", "lds_tiled_8KiB",
+                                        "lds_tiled_8KiB_insert_tab", "generic"])
 def eng(request):
-    """Every kernel family must be bit-exact: the LDS-resident fast path (default whenever the filter
-    fits in LDS; with and without filter double-buffering), the LDS-tiled path that 4K-class filters
-    take (forced here onto small filters with 1 KiB / 8 KiB tiles so that every test crosses tile
-    boundaries) and the generic global-memory path.  The default LDS query kernel reduces h mod m through the FP64
-    pipe whenever every filter of the batch has 2^15 <= m < 2^23 (1080p / 2160p frames); "lds_barrett_only" keeps the
-    integer Barrett reductions, so both forms are pinned to the same fixtures.  The default FP64 kernel is k_query_s64 (round 3: pass in
-    rows, frame geometry in LDS); "lds_query_r64" selects k_query_r64 (round 2: probe image staged through registers, activation
-    ranks), "lds_dma_query" its predecessor k_query_f64 (LDS-DMA staging, 64-bit
-    activation hashes); with tiles the default is k_query_s64t where every coded frame of the batch has floor(k*) <= 2 (probe positions kept in
-    registers across the tiles) and k_query_r64t otherwise or on request ("lds_tiled_8KiB_query_r64"), then k_query_f64t ("lds_tiled_8KiB_dma_query").  "lds_query_p4" selects the 4-pixels-per-
-    lane FP64 query kernel, "hash_in_insert" the insert kernel that hashes the set positions itself instead of gathering
-    from the pixel-index hash table.  With tiles, rbf_encode_gop (which knows the masks' set-bit counts) inserts through
-    k_insert_positions + k_insert_records; "lds_tiled_8KiB_insert_tab" keeps the tiled k_insert_tab there too."""
+    """Every LIVE kernel family must be bit-exact (round 4 pruned the superseded FP64 query kernels: k_query_f64 / f64t / p4 / r64 / r64t /
+    s64 / s64w are in tools/legacy/, outside the library): the LDS-resident fast path -- k_query_u64 (FP64 reductions, frame records
+    and LDS-DMA staging; default whenever every filter of the batch has 2^15 <= m < 2^23 and fits LDS twice) with k_insert_tab
+    gathering from the pixel-index hash table; "lds_single_buffer" / "lds_barrett_only": the integer Barrett kernels (k_query_lds,
+    k_insert_lds), so both forms of h mod m are pinned to the same fixtures; "hash_in_insert": the insert kernel hashes its set
+    positions itself; the LDS-tiled path that 4K-class filters take (forced here onto small filters with 1 KiB / 8 KiB tiles so that
+    every test crosses tile boundaries): k_query_s64t for every floor(k*) (probe positions kept in registers across the tiles for
+    floor(k*) <= 4, walked again per tile otherwise), inserts through k_insert_positions + k_insert_records inside rbf_encode_gop
+    ("lds_tiled_8KiB_insert_tab" keeps the tiled k_insert_tab there too); and the generic global-memory path."""
     ctx = nat.Context(0)
-    if request.param in ("lds_query_r64", "lds_tiled_8KiB_query_r64"):
-        ctx.option(nat.OPT_QUERY_R64, 1)
-    ctx.force_generic({"lds_double_buffer": 0, "lds_query_r64": 0, "lds_dma_query": 1 << 13, "lds_single_buffer": 2, "lds_barrett_only": 8, "lds_query_p4": 64, "hash_in_insert": 32, "lds_tiled_1KiB": 4 << 16, "lds_tiled_8KiB": 32 << 16,
-                       "lds_tiled_8KiB_insert_tab": (32 << 16) | 128, "lds_tiled_8KiB_dma_query": (32 << 16) | (1 << 13), "lds_tiled_8KiB_query_r64": 32 << 16,
-                       "generic": 1}[request.param])
+    ctx.force_generic({"lds_double_buffer": 0, "lds_single_buffer": 2, "lds_barrett_only": 8, "hash_in_insert": 32, "lds_tiled_1KiB": 4 << 16, "lds_tiled_8KiB": 32 << 16,
+                       "lds_tiled_8KiB_insert_tab": (32 << 16) | 128, "generic": 1}[request.param])
     e = BloomEngine(ctx)
     yield e
     e.close()
@@ -500,7 +493,7 @@ def test_shared_hash_table_from_concurrent_threads(oracle):
         assert not errors, errors
 
 
-@pytest.mark.parametrize("force", [0, 1 << 13, 16 << 16], ids=["default", "dma_query", "tiles_4KiB"])
+@pytest.mark.parametrize("force", [0, 8, 16 << 16], ids=["default", "barrett_only", "tiles_4KiB"])
 def test_long_gop_129_inter_frames_vs_oracle(oracle, force):
     """A GOP of 130 frames = 129 inter-frames: the library splits it into batches of MAX_BATCH = 128 + 1.  The first batch fills
     every per-batch table to the brim -- 128 thresholds for the activation ranks (binary search from step 64, ranks up to 128),
@@ -547,7 +540,7 @@ def test_long_gop_129_inter_frames_vs_oracle(oracle, force):
     ctx.close()
 
 
-@pytest.mark.parametrize("force", [0, 32 << 16, 1 << 13, 8, 1 << 14 | 32 << 16], ids=["default", "tiles_8KiB", "dma_query_no_split", "barrett_only_no_split", "tiles_hashed_records"])
+@pytest.mark.parametrize("force", [0, 32 << 16, 8, 1 << 14 | 32 << 16], ids=["default", "tiles_8KiB", "barrett_only_no_split", "tiles_hashed_records"])
 def test_mixed_batch_is_split_over_the_kernel_families(oracle, force):
     """A GOP whose filters straddle the FP64 kernels' range (2^15 <= m < 2^23): busy frames next to nearly static ones (a few
     hundred changed pixels: m of a few thousand bits) and unchanged ones.  rbf_encode_gop codes such a batch in two passes --

@@ -4,8 +4,9 @@
 #include <cstdlib>
 #include <vector>
 #include <cstring>
-#include "../new_bloom_filter_repo_amd/csrc/rbf_kernels_i64.h"
+#include "legacy/rbf_kernels_i64.h"      // round-3 snapshot (namespace rbf::legacy)
 using namespace rbf;
+using namespace rbf::legacy;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int IAB>

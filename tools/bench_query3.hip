@@ -9,8 +9,9 @@
 #include <vector>
 #include <algorithm>
 #include <cstring>
-#include "../new_bloom_filter_repo_amd/csrc/rbf_kernels_s64.h"
+#include "legacy/rbf_kernels_s64.h"      // round-3 snapshot (namespace rbf::legacy): these kernels left the library in round 4
 using namespace rbf;
+using namespace rbf::legacy;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static const uint32_t *g_image = nullptr;

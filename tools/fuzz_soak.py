@@ -21,9 +21,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int.from_bytes(os.urandom(4), "little")
 rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
-KNOBS = [0, 0, 0, 2, 1, 4 << 16, 32 << 16, 4, 8, 16, 32, 64, (64 << 16) | 32, 16 | 64, (32 << 16) | (1 << 14), (32 << 16) | 128, (8 << 16) | (1 << 14), 8 << 16, 1 << 15, 1 << 13, (16 << 16) | (1 << 13), 0, 0]   # default (x3), single buffer, generic, tiled 1 KiB / 8 KiB, generic mask bits,
-#         Barrett only, hash table rebuilt per batch, hash in insert, k_query_p4, 16 KiB tiles + hash in insert, rebuilt table + p4,
-#         8 KiB tiles with hashed position records, 8 KiB tiles with the tiled k_insert_tab, 2 KiB tiles hashed / gathered records, no table rewrite, k_query_f64 (DMA) instead of k_query_r64, default x2  (rbf.h: rbf_ctx_force_generic)
+KNOBS = [0, 0, 0, 2, 1, 4 << 16, 32 << 16, 4, 8, 16, 32, (64 << 16) | 32, (32 << 16) | (1 << 14), (32 << 16) | 128, (8 << 16) | (1 << 14), 8 << 16, 1 << 15, 0, 0]   # default (x3), single buffer, generic, tiled 1 KiB / 8 KiB, generic mask bits,
+#         Barrett only, hash table rebuilt per batch, hash in insert, 16 KiB tiles + hash in insert, 8 KiB tiles with hashed position records,
+#         8 KiB tiles with the tiled k_insert_tab, 2 KiB tiles hashed / gathered records, no table rewrite, default x2  (rbf.h: rbf_ctx_force_generic)
 unpack = lambda a, nb: np.unpackbits(np.asarray(a, dtype=np.uint8))[:nb]
 t_end, cases, frames_done = time.time() + budget, 0, 0
 while time.time() < t_end:
@@ -45,21 +45,24 @@ while time.time() < t_end:
         frames = np.ascontiguousarray(frames[..., 0])
     n = W * H
     desc = dict(seed=seed, case=cases, knob=knob, W=W, H=H, C=C, dtype=np.dtype(dtype).name, F=F, seeds=seeds, thr=thr)
-    # round 3: planar luma block (device de-interleave at upload), a resident-GOP slot other than 0, k_query_r64 / r64t instead of
-    # k_query_s64 / s64t, the separate finish launch instead of the mask kernel's fused tail
+    # planar luma block (device de-interleave at upload), a resident-GOP slot other than 0, the separate finish launch instead of the mask
+    # kernel's fused tail, the two-phase form of rbf_encode_gop
     planar = bool(rng.random() < 0.5)
     slots = int(rng.integers(1, 4)) if planar else 1
     slot = int(rng.integers(0, slots))
     opts = (int(rng.random() < 0.25), int(rng.random() < 0.25))
-    desc.update(planar=planar, slot=slot, slots=slots, query_r64=opts[0], separate_finish=opts[1])
+    desc.update(planar=planar, slot=slot, slots=slots, two_phase=opts[0], separate_finish=opts[1])
     ctx = nat.Context(0)
     ctx.force_generic(knob)
-    ctx.option(nat.OPT_QUERY_R64, opts[0])
     ctx.option(nat.OPT_SEPARATE_FINISH, opts[1])
     eng = BloomEngine(ctx)
     coder = GopCoder(ctx, W, H, F, channels=C, sample_bytes=np.dtype(dtype).itemsize, seeds=seeds, threshold=thr, planar_luma=planar, resident_gops=slots)
     coder.load_frames(frames, gop=slot) if planar else coder.load_frames(frames)
-    coder.encode(slot) if planar else coder.encode()
+    if opts[0]:
+        coder.encode_begin(slot if planar else 0)
+        coder.encode_finish()
+    else:
+        coder.encode(slot) if planar else coder.encode()
     block = coder.pack()
     res = coder.results()
     recs = unpack_device_record(block.numpy(ctx), n)

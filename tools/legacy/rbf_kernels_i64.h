@@ -1,3 +1,5 @@
+// LEGACY (round 1 - round 3): a frozen copy of csrc/rbf_kernels_i64.h as it stood before the round-4 prune (ablation bits and all), kept for the old
+// harnesses of tools/.  NOT part of the library: nothing under new_bloom_filter_repo_amd/ includes it.  Namespace rbf::legacy.
 // rbf_kernels_i64.h -- the insert path for filters of 2^15 <= m < 2^23 bits (1080p / 2160p frames):
 //
 //   k_hash_table   the three XXH64 of EVERY pixel index of the frame geometry (they depend on the index and the seeds
@@ -21,7 +23,7 @@
 #pragma once
 #include "rbf_kernels_q64.h"
 
-namespace rbf {
+namespace rbf { namespace legacy {
 
 constexpr int HT_THREADS = 256;
 
@@ -69,6 +71,8 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 constexpr int IT_STEP_BYTES = 128;                 // mask bytes per wave step: a lane owns 16 pixels (two bytes)
 constexpr int IT_QUEUE = 64 + IT_STEP_BYTES * 8;   // carry (< 64) + one wave step
 
+// IAB (ablation mask, tools/bench_insert.hip only; 0 in the library): 1 = no table gather (fake entries), 2 = no
+// atomics, 4 = no LDS zeroing / partial store, 8 = no queueing (mask bytes read, nothing queued).
 // `fd`: M carries the bits of -1.0 / m (IEEE double, computed on the host) instead of the Barrett constant.
 //
 // The body shared by the two table-driven kernels that walk a mask: this wave takes wave steps g0 + wave, + NWAVES, ... < g1,
@@ -79,7 +83,7 @@ constexpr int IT_QUEUE = 64 + IT_STEP_BYTES * 8;   // carry (< 64) + one wave st
 // HASHED: no table -- the batch's three hashes are computed on the spot (hash3_index, as k_insert_lds does).  Cheaper than the
 // gather once the table (32 B per pixel) no longer fits the 256 MB Infinity Cache: at 2160p the gather of a GOP's 5.9 M
 // entries costs 58 us of random HBM reads, hashing them ~35.
-template <bool RECORDS, int NWAVES, bool HASHED = false>
+template <int IAB, bool RECORDS, int NWAVES, bool HASHED = false>
 __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mask, uint64_t n, const FrameDev &fd, const uint4 *__restrict__ table, const Seeds &seeds,
                                                  uint32_t *filt, uint32_t tile_bit0, uint32_t tile_bits, uint2 *__restrict__ records, uint32_t rpos,
                                                  uint32_t *q, uint64_t g0, uint64_t g1, uint32_t lane, uint32_t wave)
@@ -92,7 +96,7 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     const uint64_t T = fd.T;
     auto set_bit = [&](uint32_t pos) {
         const uint32_t rel = pos - tile_bit0;                      // unsigned: out-of-tile positions wrap high
-        if (rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
+        if (rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
     };
 
     // one batch of <= 64 keys in flight: its table entries are requested (`fetch`) when the batch leaves the queue and
@@ -101,7 +105,8 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     uint32_t pending = 0;                                          // keys of the batch in flight (wave-uniform)
     auto fetch = [&](uint32_t first, uint32_t count) {
         const uint32_t idx = lane < count ? q[first + lane] : 0u;  // idle lanes read entry 0 (always there)
-        if (HASHED) {
+        if (IAB & 1) { e0 = make_uint4(idx * 0x9E3779B1u, 0x41D00000u + (idx & 0xFFFFFu), idx * 0x85EBCA77u, 0x41E00000u + (idx & 0xFFFFu)); e1 = make_uint4(idx * 3u, idx * 7u, idx * 11u, idx * 13u); }
+        else if (HASHED) {
             const Hash3 h = hash3_index(idx, lane < count, seeds);      // wave-uniform call (it votes on the key length)
             const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h.h1), d2 = __builtin_bit_cast(uint64_t, (double)h.h2);
             e0 = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));    // the table's entry format
@@ -145,7 +150,7 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     };
     uint32_t nxt = load_bits(g0 + wave);
     for (uint64_t g = g0 + wave; g < g1; g += NWAVES) {
-        uint32_t bits = nxt;
+        uint32_t bits = (IAB & 8) ? (nxt & 0u) : nxt;
         nxt = load_bits(g + NWAVES);                               // prefetch
         // exclusive prefix of the per-lane counts (0..16): six DPP adds (the five ballots + ten mbcnt of k_insert_lds were a
         // third of this loop's skeleton)
@@ -172,7 +177,7 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     if (qn) { fetch(0, qn); finish(); }
 }
 
-template <bool HASHED = false>
+template <int IAB = 0, bool HASHED = false>
 __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
     const FrameTable tab, const uint4 *__restrict__ table /* unused when HASHED: the set positions are hashed on the spot */, Seeds seeds,
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     const uint32_t fwords = filter_words(fd.m);
     const uint32_t tile0 = tile * tile_words;
     if (tile0 >= fwords) return;
-    for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
+    if (!(IAB & 4)) for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
     __syncthreads();
 
     const uint64_t nbytes = (n + 7) >> 3;
@@ -201,12 +206,12 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     const uint64_t gper = (groups + S - 1) / S;
     const uint64_t g0 = (uint64_t)s * gper;
     const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
-    insert_tab_steps<false, IL_WAVES, HASHED>(masks + (uint64_t)f * mask_stride_bytes, n, fd, table, seeds, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
+    insert_tab_steps<IAB, false, IL_WAVES, HASHED>(masks + (uint64_t)f * mask_stride_bytes, n, fd, table, seeds, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
                                            queues + wave * IT_QUEUE, g0, g1, lane, wave);
     __syncthreads();
     uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;
     const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
-    const uint32_t pairs = (mine + 1) >> 1;                       // tile0 is even: 8-byte aligned
+    const uint32_t pairs = (IAB & 4) ? 1u : (mine + 1) >> 1;      // tile0 is even: 8-byte aligned
     for (uint32_t i = threadIdx.x; i < pairs; i += IL_THREADS)
         reinterpret_cast<uint2 *>(part)[i] = reinterpret_cast<const uint2 *>(filt)[i];
 }
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
 // ------------------------------------------------------------------------------------------
 constexpr int IP_THREADS = 256, IP_WAVES = IP_THREADS / WAVE;
 
-template <bool HASHED = false>
+template <int IAB = 0, bool HASHED = false>
 __global__ __launch_bounds__(IP_THREADS) void k_insert_positions(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
     const FrameTable tab /* M = bits of -1.0 / m, floor_k = index of the frame's first record */, const uint4 *__restrict__ table /* unused when HASHED */, Seeds seeds,
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_insert_positions(
     __syncthreads();
     uint32_t rpos = wg_base;
     for (uint32_t k = 0; k < wave; ++k) rpos += wcount[k];
-    insert_tab_steps<true, IP_WAVES, HASHED>(mask, n, fd, table, seeds, nullptr, 0u, 0u, records + fd.floor_k, (uint32_t)__builtin_amdgcn_readfirstlane((int)rpos),
+    insert_tab_steps<IAB, true, IP_WAVES, HASHED>(mask, n, fd, table, seeds, nullptr, 0u, 0u, records + fd.floor_k, (uint32_t)__builtin_amdgcn_readfirstlane((int)rpos),
                                           queues + wave * IT_QUEUE, g0, g1, lane, wave);
 }
 
@@ -331,4 +336,4 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_records(
         reinterpret_cast<uint2 *>(part)[k] = reinterpret_cast<const uint2 *>(lds)[k];
 }
 
-}  // namespace rbf
+} }  // namespace rbf::legacy

@@ -1,3 +1,5 @@
+// LEGACY (round 1 - round 3): a frozen copy of csrc/rbf_kernels_lds.h as it stood before the round-4 prune (ablation bits and all), kept for the old
+// harnesses of tools/.  NOT part of the library: nothing under new_bloom_filter_repo_amd/ includes it.  Namespace rbf::legacy.
 // rbf_kernels_lds.h -- the LDS-resident fast path (filters up to ~1.3 Mbit, i.e. 1080p-class frames).
 //
 // Measured on MI355X (tools/microbench.hip): random dword probes run at ~430 G/s from a 76 KB
@@ -15,9 +17,9 @@
 //                  workgroup stages that frame's filter into LDS and each lane does the per-frame
 //                  part only: two Barrett reductions mod m_f, the LDS probes, ballot + compaction.
 #pragma once
-#include "rbf_kernels.h"
+#include "../../new_bloom_filter_repo_amd/csrc/rbf_kernels.h"
 
-namespace rbf {
+namespace rbf { namespace legacy {
 
 constexpr int QL_THREADS = 1024;                   // 16 waves, one workgroup per CU, filter double-buffered in LDS
 constexpr int QL_WAVES = QL_THREADS / WAVE;
@@ -52,7 +54,9 @@ __device__ __forceinline__ uint32_t mod_m_small(uint64_t h, uint32_t m, uint32_t
 // ------------------------------------------------------------------------------------------
 // insert
 // ------------------------------------------------------------------------------------------
-template <bool SMALL_M>
+// IAB (ablation mask, tools/bench_insert.hip only; 0 in the library): 1 = no hashing, 2 = no LDS
+// atomics, 4 = no LDS zeroing / partial store, 8 = no queueing (mask bytes read, nothing queued).
+template <bool SMALL_M, int IAB = 0>
 __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
     const FrameTable tab, Seeds seeds,
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     const uint32_t tile0 = tile * tile_words;                     // first word of my tile
     if (tile0 >= fwords) return;
     const uint32_t tile_bit0 = tile0 << 5, tile_bits = tile_words << 5;
-    for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
+    if (!(IAB & 4)) for (uint32_t i = threadIdx.x; i < tile_words; i += IL_THREADS) filt[i] = 0;
     __syncthreads();
 
     const uint8_t *mask = masks + (uint64_t)f * mask_stride_bytes;
@@ -97,19 +101,21 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     auto drain_at = [&](uint32_t first, uint32_t count) {          // hash `count` (<= 64) queued positions
         const bool act = lane < count;                             // (wave-uniform call: hash3_index votes)
         const uint32_t idx = act ? q[first + lane] : 0u;
-        const Hash3 h = hash3_index(idx, act, seeds);
+        Hash3 h;
+        if (IAB & 1) { h.h1 = idx * P1; h.h2 = idx * P2 + 7; h.ha = idx * P3; }
+        else h = hash3_index(idx, act, seeds);
         if (act) {
             uint32_t pos, step;
             if (SMALL_M) { pos = mod_m_small(h.h1, m, m2, Mh, Ml); step = mod_m_small(h.h2, m, m2, Mh, Ml); }
             else         { pos = mod_m(h.h1, m, fd.M);             step = mod_m(h.h2, m, fd.M); }
             for (uint32_t j = 0; j < fd.floor_k; ++j) {
                 const uint32_t rel = pos - tile_bit0;              // unsigned: out-of-tile positions wrap high
-                if (rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
+                if (rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
                 const uint64_t s2 = (uint64_t)pos + step;
                 pos = (uint32_t)(s2 >= m ? s2 - m : s2);
             }
             const uint32_t rel = pos - tile_bit0;
-            if (h.ha < fd.T && rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
+            if (h.ha < fd.T && rel < tile_bits) { if (IAB & 2) filt[(rel >> 5) & 1023u] = pos; else atomicOr(&filt[rel >> 5], msb_bit(pos)); }
         }
     };
 
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     };
     uint32_t nxt = load_bits(g0 + wave);
     for (uint64_t g = g0 + wave; g < g1; g += IL_WAVES) {
-        uint32_t bits = nxt;
+        uint32_t bits = (IAB & 8) ? (nxt & 0u) : nxt;
         nxt = load_bits(g + IL_WAVES);                             // prefetch: the load flies while we hash
         // exclusive prefix of the per-lane counts (0..8) without a cross-lane scan: one ballot per bit
         // of the count, rank of the ballot below my lane (mbcnt), weighted sum -- no LDS round trips
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
     __syncthreads();
     uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;
     const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
-    const uint32_t pairs = (mine + 1) >> 1;                       // tile0 is even: 8-byte aligned
+    const uint32_t pairs = (IAB & 4) ? 1u : (mine + 1) >> 1;      // tile0 is even: 8-byte aligned
     for (uint32_t i = threadIdx.x; i < pairs; i += IL_THREADS)
         reinterpret_cast<uint2 *>(part)[i] = reinterpret_cast<const uint2 *>(filt)[i];
 }
@@ -314,7 +320,9 @@ __device__ __forceinline__ uint32_t probe_word(const uint32_t *filt, uint32_t po
 // the loop pb holds the lane's QL_P verdicts MSB-first -- exactly one byte of the packed pass vector.
 // Returns the wave's number of passing positions.  Branch-free for FK >= 0 so the QL_P dependency
 // chains interleave.
-template <bool SMALL_M, int FK>
+// AB (ablation mask, tools/bench_query.hip only; 0 in the library): 1 = no reductions, 2 = no LDS
+// probes, 4 = no ballot, 8 = no filter staging, 16 = no hashing, 32 = no barrier, 64 = no output.
+template <bool SMALL_M, int FK, int AB = 0>
 __device__ __forceinline__ uint32_t frame_pass(
     const uint64_t (&h1)[QL_P], const uint64_t (&h2)[QL_P], const uint64_t (&ha)[QL_P], uint32_t validmask,
     const uint32_t *filt, uint32_t m, uint64_t M, uint64_t T, uint32_t fk_rt, uint32_t &pb)
@@ -327,21 +335,22 @@ __device__ __forceinline__ uint32_t frame_pass(
 #pragma unroll
     for (int it = 0; it < QL_P; ++it) {
         uint32_t pos, step;
-        if (SMALL_M) { pos = mod_m_small(h1[it], m, m2, Mh, Ml); step = mod_m_small(h2[it], m, m2, Mh, Ml); }
+        if (AB & 1) { pos = (uint32_t)h1[it] & 0x7FFFFu; step = (uint32_t)h2[it] & 0x3FFFFu; }
+        else if (SMALL_M) { pos = mod_m_small(h1[it], m, m2, Mh, Ml); step = mod_m_small(h2[it], m, m2, Mh, Ml); }
         else         { pos = mod_m(h1[it], m, M);            step = mod_m(h2[it], m, M); }
         // Each probe shifts its word LEFT so that the probed bit lands in bit 31: the verdict is the
         // sign bit of the AND of all probes.  MSB-first bit (pos & 31) ^ 7 -> shift (pos ^ 24) & 31.
         uint32_t acc = validmask << (31 - it);                // only the sign bit is ever looked at: bit `it` -> bit 31
 #pragma unroll
         for (uint32_t j = 0; j < fk; ++j) {
-            acc &= probe_word(filt, pos) << ((pos ^ 24u) & 31u);
+            acc &= ((AB & 2) ? (pos * 0x9E3779B1u) : probe_word(filt, pos)) << ((pos ^ 24u) & 31u);
             if (SMALL_M) { const uint32_t s2 = pos + step; pos = min(s2, s2 - m); }
             else { const uint64_t s2 = (uint64_t)pos + step; pos = (uint32_t)(s2 >= m ? s2 - m : s2); }
         }
-        const uint32_t x = probe_word(filt, pos) << ((pos ^ 24u) & 31u);
+        const uint32_t x = ((AB & 2) ? (pos * 0x85EBCA77u) : probe_word(filt, pos)) << ((pos ^ 24u) & 31u);
         acc &= (ha[it] < T) ? x : 0x80000000u;
         pb = __builtin_amdgcn_alignbit(pb, acc, 31);          // (pb << 1) | (acc >> 31)
-        npass += __popcll(__ballot((int32_t)acc < 0));
+        if (!(AB & 4)) npass += __popcll(__ballot((int32_t)acc < 0));
     }
     return npass;
 }
@@ -353,7 +362,7 @@ __device__ __forceinline__ uint32_t frame_pass(
 // but the last character, see hash3_run8); a wave owns 512 consecutive pixels.
 //   seg_cnt[f*nseg + seg]                  passing positions of the segment (= witness bits it owns)
 // SMALL_M: every filter of the batch has 2 <= m <= 2^30 (host-checked) -> cheap reductions.
-template <bool DOUBLE_BUFFER, bool SMALL_M>
+template <bool DOUBLE_BUFFER, bool SMALL_M, int AB = 0>
 __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
     uint64_t n, uint32_t nframes, const FrameTable tab, Seeds seeds,
     const uint32_t *__restrict__ filters, uint64_t filter_stride_words32, uint32_t fwords_max,
@@ -377,7 +386,10 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
         h1[it] = 0; h2[it] = 0; ha[it] = ~0ull;
         if (live && i0 + it < n) validmask |= 1u << it;
     }
-    if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
+    if (AB & 16) {
+#pragma unroll
+        for (int it = 0; it < QL_P; ++it) { h1[it] = (i0 + it) * P1; h2[it] = (i0 + it) * P2 + seeds.h2; ha[it] = (i0 + it) * P3; }
+    } else if (!hash3_run8((uint32_t)i0, validmask, seeds, h1, h2, ha)) {
 #pragma unroll
         for (int it = 0; it < QL_P; ++it) {                      // mixed key lengths in this wave: index by index
             const bool act = (validmask >> it) & 1u;
@@ -395,13 +407,14 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
         }
     }
     // Every workgroup walks the frames in the same order: all CUs then pull the same 76 KB filter at
-    // about the same time, which the L2 serves best (measured in round 1: rotating the start frame per workgroup, so that
-    // ~29 different filters are in flight, costs +11 us per launch).
-    auto frame_at = [&](uint32_t k) -> uint32_t { return k; };
+    // about the same time, which the L2 serves best (measured: rotating the start frame per workgroup,
+    // AB & 512, so that ~29 different filters are in flight costs +11 us per launch).
+    const uint32_t rot = (AB & 512) ? blockIdx.x % nframes : 0u;
+    auto frame_at = [&](uint32_t k) -> uint32_t { const uint32_t g = k + rot; return g >= nframes ? g - nframes : g; };
     auto next_active = [&](uint32_t k) -> uint32_t { while (k < nframes && tab.f[frame_at(k)].m == 0) ++k; return k; };
     uint32_t k = next_active(0);
     uint32_t cur = 0;
-    if (DOUBLE_BUFFER && k < nframes) {
+    if (DOUBLE_BUFFER && k < nframes && !(AB & 8)) {
         const uint32_t f0 = frame_at(k);
         dma_filter(lds, filters + (uint64_t)f0 * filter_stride_words32, filter_words(tab.f[f0].m), wave, lane, nwaves);
     }
@@ -413,15 +426,19 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
         const FrameDev fd = tab.f[f];
         const uint32_t *filt;
         if (DOUBLE_BUFFER) {
-            dma_wait_all();           // my share of DMA(f) has landed ...
-            __syncthreads();          // ... and everyone's; buffer cur^1 is free again
+            if (!(AB & 32)) {
+                dma_wait_all();       // my share of DMA(f) has landed ...
+                __syncthreads();      // ... and everyone's; buffer cur^1 is free again
+            }
             filt = lds + cur * bufwords;
-            if (kn < nframes)
-                dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32, filter_words(tab.f[fn].m), wave, lane, nwaves);
+            if (kn < nframes && !(AB & 8))
+                dma_filter(lds + (cur ^ 1u) * bufwords, filters + (uint64_t)fn * filter_stride_words32,
+                           filter_words(tab.f[fn].m) >> ((AB & 128) ? 1 : 0), wave, (AB & 256) ? (wave < 4 ? lane : 64u) : lane,
+                           (AB & 256) ? 4u : nwaves);
             cur ^= 1u;
         } else {
             __syncthreads();          // previous frame's probes are done
-            dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, filter_words(fd.m), wave, lane, nwaves);
+            if (!(AB & 8)) dma_filter(lds, filters + (uint64_t)f * filter_stride_words32, filter_words(fd.m), wave, lane, nwaves);
             dma_wait_all();
             __syncthreads();
             filt = lds;
@@ -441,13 +458,13 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_lds(
         // floor(k*) is a small integer: straight-line code for the common values lets the compiler
         // issue every LDS probe of all QL_P pixels back to back instead of one round trip at a time.
         switch (fk) {
-        case 1: npass = frame_pass<SMALL_M, 1>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
-        case 2: npass = frame_pass<SMALL_M, 2>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
-        case 3: npass = frame_pass<SMALL_M, 3>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
-        case 4: npass = frame_pass<SMALL_M, 4>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
-        default: npass = frame_pass<SMALL_M, -1>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        case 1: npass = frame_pass<SMALL_M, 1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        case 2: npass = frame_pass<SMALL_M, 2, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        case 3: npass = frame_pass<SMALL_M, 3, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        case 4: npass = frame_pass<SMALL_M, 4, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
+        default: npass = frame_pass<SMALL_M, -1, AB>(h1, h2, ha, validmask, filt, m, M, T, fk, pb); break;
         }
-        if (live) {
+        if (!(AB & 64) && live) {
             pass_bytes[((uint64_t)f * nseg + seg) * (QL_SEG_PIXELS / 8) + lane] = (uint8_t)pb;
             if (lane == 0) seg_cnt[(uint64_t)f * nseg + seg] = npass;
         }
@@ -706,9 +723,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_expand_mask_p(
     masks[(uint64_t)f * mask_stride_words64 + w] = flip_bytes64(out);
 }
 
-}  // namespace rbf
+} }  // namespace rbf::legacy
 
-namespace rbf {
+namespace rbf { namespace legacy {
 
 // ------------------------------------------------------------------------------------------
 // A1 fast path: residual masks of a whole GOP, every frame read from HBM exactly once.
@@ -908,4 +925,4 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     if (lane == 0) __hip_atomic_store(fin.ticket + MASK_TICKETS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-}  // namespace rbf
+} }  // namespace rbf::legacy

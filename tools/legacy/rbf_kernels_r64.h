@@ -1,3 +1,6 @@
+// LEGACY (round 2 / round 3): a frozen copy of csrc/rbf_kernels_r64.h as it stood before the round-4 prune, kept for the old harnesses of tools/
+// (bench_query*.hip, bench_insert.hip) and for A/B comparisons against the kernels that replaced these.  NOT part of the library: nothing
+// under new_bloom_filter_repo_amd/ includes it.  Everything lives in namespace rbf::legacy.
 // rbf_kernels_r64.h -- k_query_r64: k_query_f64 (rbf_kernels_q64.h) with the two changes its own measurements asked for.
 //
 // 1. The probe image of the NEXT frame is staged through REGISTERS -- plain 16-byte global loads issued between the pixel
@@ -21,7 +24,7 @@
 #include "rbf_kernels_q64.h"
 #include <type_traits>
 
-namespace rbf {
+namespace rbf { namespace legacy {
 
 typedef uint32_t r64_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -514,4 +517,4 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_r64t(
     }
 }
 
-}  // namespace rbf
+} }  // namespace rbf::legacy
