@@ -72,6 +72,8 @@ def parse_args():
     ap.add_argument("--clip-steps", type=int, default=10, help="timed passes over the clip in the clip legs")
     ap.add_argument("--begin-ahead", type=int, default=-1, help="GOPs whose mask stage (rbf_encode_gop_begin) is enqueued before the oldest one is finished (rbf_encode_gop_finish); 0 = the one-call form, -1 = auto (pipelines - 1)")
     ap.add_argument("--host-threads", type=int, default=0, help="1 = one host thread per pipeline (each calls rbf_encode_gop for its own context; ctypes drops the GIL) instead of one thread issuing begin / finish in turn")
+    ap.add_argument("--side-compact", action="store_true", help="RBF_OPT_SIDE_COMPACT: the witness compaction on a library-owned side stream beside the next GOP's mask / insert / reduce, two output sets per pipeline (measured: no gain, profiles/r04_side_compact.txt)")
+    ap.add_argument("--skip-kernels", type=str, default="", help="diagnostic (results WRONG, implies --no-verify): comma list of insert,reduce,query,stitch not to launch -- what does each cost the overlapped step?")
     ap.add_argument("--no-legs", action="store_true", help="skip the interleaved / config4_2160p / decode_1080p legs behind the headline")
     return ap.parse_args()
 
@@ -173,8 +175,18 @@ def main():
     if args.lds_tile_kib or args.generic_kernels or args.rebuild_hash_table or args.force_bits:
         for c in ctxs:
             c.force_generic(((args.lds_tile_kib * 1024 // 256) << 16) | (1 if args.generic_kernels else 0) | (16 if args.rebuild_hash_table else 0) | args.force_bits)      # tile unit: 64 dwords
+    if args.skip_kernels:
+        args.no_verify = True
+        skip = sum(1 << {"insert": nat.K_INSERT, "reduce": nat.K_REDUCE, "query": nat.K_QUERY, "stitch": nat.K_STITCH}[k] for k in args.skip_kernels.split(","))
+        for c in ctxs:
+            c.option(nat.OPT_DEBUG_SKIP, skip)
+    side = args.side_compact
+    out_sets = 2 if side else 1
+    if side:
+        for c in ctxs:
+            c.option(nat.OPT_SIDE_COMPACT, 1)
     ctx = ctxs[0]
-    arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
+    arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs, out_sets)) for _ in range(ncoders)]
     planar = not args.interleaved
     if args.shared_gop and planar:
         raise SystemExit("--shared-gop is a diagnostic of the interleaved layout: add --interleaved")
@@ -183,7 +195,7 @@ def main():
     for k in range(ncoders):
         coders.append(GopCoder(ctxs[k], W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
                                out_allocator=arenas[k], frames_block=coders[0].frames if (k and args.shared_gop) else None,
-                               planar_luma=planar, keep_interleaved=not planar, resident_gops=G_res))
+                               planar_luma=planar, keep_interleaved=not planar, resident_gops=G_res, out_sets=out_sets))
     coder = coders[0]
     density = args.density or P_KSTAR_2_3
     host_gops = []                                # [pipeline][resident gop] -> (F, H, W, 3) host frames
@@ -399,6 +411,7 @@ def main():
                                  "one pixel-index hash table per (device, frame size, seeds), shared by the pipelines' contexts; built once, before the timed region" if args.streams > 1 else
                                  "built once; rewritten in every step by the query kernel (sole holder: keeps the table in the Infinity Cache for the next insert)",
                    "stages": "residual mask -> host params -> insert -> query+witness",
+                   "witness_compaction": "on a library-owned side stream behind the query (RBF_OPT_SIDE_COMPACT), beside the next GOP's mask / insert / reduce; two output sets per pipeline" if side else "on the pipeline's stream",
                    "launcher": os.environ.get("RBF_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process"),
                    "rccl_ranks": world if use_dist else 0,
                    "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by gloo world-2 tests (incl. the self-spawn launcher) and nccl world-1 tests"},
@@ -458,12 +471,12 @@ def main():
     if world == 1 and rank == 0 and not args.no_legs and (W, H, F, args.bits) == (1920, 1080, 30, 8) and not args.density:
         out["decode_1080p"] = decode_leg(torch, nat, coders, host_gops, n, pairs, G_res)
         if planar:
-            out["interleaved_yuv444"] = pipelines_leg(torch, nat, device, local_rank, W, H, F, 8, False, 1, ncoders, density, ahead, 160, host_gops=[[h[0]] for h in host_gops], verify=not args.no_verify)
+            out["interleaved_yuv444"] = pipelines_leg(torch, nat, device, local_rank, W, H, F, 8, False, 1, ncoders, density, ahead, 160, host_gops=[[h[0]] for h in host_gops], verify=not args.no_verify, side=side)
         for c in coders:
             c.close()
         coders = [None]
         torch.cuda.empty_cache()
-        out["config4_2160p"] = pipelines_leg(torch, nat, device, local_rank, 3840, 2160, 9, 8, True, 1, ncoders, density, ahead, 60, verify=not args.no_verify, seed=4000)
+        out["config4_2160p"] = pipelines_leg(torch, nat, device, local_rank, 3840, 2160, 9, 8, True, 1, ncoders, density, ahead, 60, verify=not args.no_verify, seed=4000, side=side)
     # ---- BASELINE configs[2] and [4] in the same process group: one 300-frame clip sharded by frame (strong scaling), 8- and 16-bit
     if og is not None:
         og.close()
@@ -538,7 +551,7 @@ def decode_leg(torch, nat, coders, host_gops, n, pairs, G_res, reps=40):
             "verified_vs_oracle": {"frames": frames, "fields": "decoded mask == encoder's mask == oracle's mask"}}
 
 
-def pipelines_leg(torch, nat, device, local_rank, W, H, F, bits, planar, G_res, ncoders, density, ahead, steps, host_gops=None, verify=True, seed=3000):
+def pipelines_leg(torch, nat, device, local_rank, W, H, F, bits, planar, G_res, ncoders, density, ahead, steps, host_gops=None, verify=True, seed=3000, side=True):
     """The headline's step on another geometry or layout, shortened: `ncoders` pipelines, begin / finish in turn, `steps` timed steps,
     every kernel alone afterwards, every GOP checked against the CPU oracle; its own HBM roofline for the query kernel."""
     from new_bloom_filter_repo_amd.gop import GopCoder, TorchArena, torch_allocator
@@ -548,9 +561,12 @@ def pipelines_leg(torch, nat, device, local_rank, W, H, F, bits, planar, G_res, 
     dtype = np.uint8 if bits == 8 else np.uint16
     streams = [torch.cuda.Stream(device) for _ in range(ncoders)]
     ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
-    arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs)) for _ in range(ncoders)]
+    if side:
+        for c in ctxs:
+            c.option(nat.OPT_SIDE_COMPACT, 1)
+    arenas = [TorchArena(device, GopCoder.record_bytes(n, pairs, 2 if side else 1)) for _ in range(ncoders)]
     coders = [GopCoder(ctxs[k], W, H, F, channels=3, sample_bytes=bits // 8, allocator=torch_allocator(device), out_allocator=arenas[k],
-                       planar_luma=planar, keep_interleaved=not planar, resident_gops=G_res) for k in range(ncoders)]
+                       planar_luma=planar, keep_interleaved=not planar, resident_gops=G_res, out_sets=2 if side else 1) for k in range(ncoders)]
     if host_gops is None:
         host_gops = [[np.stack(make_gop(seed + 16 * k + g, W, H, F, p=density, dtype=dtype)) for g in range(G_res)] for k in range(ncoders)]
     for k in range(ncoders):

@@ -18,7 +18,7 @@ RBF_ERANGE = -34
 K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE, K_PACK, K_HASHTAB = range(13)
 KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack", "hashtab"]
 STATS_PER_FRAME = 4
-OPT_SEPARATE_FINISH = 2    # rbf_ctx_option keys (include/rbf.h); key 1 (round 3: the round-2 query kernel) is gone with that kernel
+OPT_SEPARATE_FINISH, OPT_SIDE_COMPACT, OPT_DEBUG_SKIP = 2, 3, 99    # rbf_ctx_option keys (include/rbf.h); key 1 (round 3: the round-2 query kernel) is gone with that kernel
 
 
 class FilterParams(ctypes.Structure):
@@ -44,6 +44,7 @@ _PROTOS = {
     "rbf_ctx_create": (_int, [_int, _vp, ctypes.POINTER(_vp)]),
     "rbf_ctx_destroy": (_int, [_vp]),
     "rbf_ctx_sync": (_int, [_vp]),
+    "rbf_ctx_flush": (_int, [_vp]),
     "rbf_malloc": (_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "rbf_free": (_int, [_vp, _vp]),
     "rbf_memset": (_int, [_vp, _vp, _int, ctypes.c_size_t]),
@@ -190,6 +191,10 @@ class Context:
 
     def sync(self):
         check(lib().rbf_ctx_sync(self.handle))
+
+    def flush(self):
+        """The stream waits (device side) for what the library enqueued beside it (OPT_SIDE_COMPACT)."""
+        check(lib().rbf_ctx_flush(self.handle))
 
     def close(self):
         if self.handle:

@@ -61,6 +61,18 @@ struct rbf_ctx {
     int no_table_rewrite = 0;        // 1 = the query kernel never rewrites the hash table, sole holder or not
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
     uint32_t *mask_ticket = nullptr;                              // the fused tail of the GOP mask kernel: workgroups done so far (zero between launches)
+    // RBF_OPT_SIDE_COMPACT: the witness compaction of a GOP runs on a second stream, behind an event, so that the context's main stream
+    // goes on with the NEXT GOP's mask stage, parameter math, insert and reduce meanwhile; the main stream waits for it only in front of
+    // the next query launch (which overwrites the pass bytes the compaction reads) or when another call needs its results.
+    int side_compact = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_query = nullptr, ev_compact = nullptr;
+    bool side_ok = false;            // inside rbf_encode_gop_finish: this launch sequence may leave its compaction outstanding
+    bool side_pending = false;       // a compaction has been enqueued on side_stream and the main stream has not waited for it yet
+    const void *side_masks = nullptr; size_t side_masks_bytes = 0;            // what that compaction reads ...
+    const void *side_wit = nullptr; size_t side_wit_bytes = 0;                // ... and writes (caller-owned buffers)
+    const void *side_stats = nullptr; size_t side_stats_bytes = 0;
+    uint32_t debug_skip = 0;                                      // RBF_OPT_DEBUG_SKIP: bit RBF_K_* = do not launch that kernel of the encode path (WRONG results: sensitivity measurements only)
     int no_fused_finish = 0;                                      // 1 = always the separate k_finish_ones launch (rbf_ctx_option RBF_OPT_SEPARATE_FINISH)
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
@@ -108,16 +120,32 @@ static int grow(void **ptr, size_t *cap, size_t bytes)
     return RBF_OK;
 }
 
-static int set_device(rbf_ctx *ctx)
+// The main stream waits (on the device) for the compaction that runs on the side stream, if one is outstanding.
+static int join_side(rbf_ctx *ctx)
+{
+    if (!ctx->side_pending) return RBF_OK;
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_compact, 0));
+    ctx->side_pending = false;
+    return RBF_OK;
+}
+static inline bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb)
+{
+    return a && b && (const char *)a < (const char *)b + nb && (const char *)b < (const char *)a + na;
+}
+
+// Every entry point starts here.  `join`: the call may touch what an outstanding side-stream compaction reads or writes (everything
+// but the first half of rbf_encode_gop, which checks its own buffers against the compaction's).
+static int set_device(rbf_ctx *ctx, bool join = true)
 {
     if (!ctx) return fail(RBF_EINVAL, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (join) return join_side(ctx);
     return RBF_OK;
 }
 
 struct LaunchTimer {
-    rbf_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; bool on;
-    LaunchTimer(rbf_ctx *ctx, int kid) : c(ctx), id(kid), on((ctx->timing >> kid) & 1u)
+    rbf_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;
+    LaunchTimer(rbf_ctx *ctx, int kid, hipStream_t stream = nullptr) : c(ctx), id(kid), on((ctx->timing >> kid) & 1u), st(stream ? stream : ctx->stream)
     {
         if (!on) return;
         auto get = [&]() {
@@ -128,12 +156,12 @@ struct LaunchTimer {
         };
         a = get(); b = get();
         if (!a || !b) { on = false; return; }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, st);
     }
     ~LaunchTimer()
     {
         if (!on) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         try { c->pending.push_back({id, a, b}); }                 // timing is best effort; nothing may throw across the C ABI
         catch (...) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
     }
@@ -214,6 +242,7 @@ static int drain_timing(rbf_ctx *ctx)
 {
     if (ctx->pending.empty()) return RBF_OK;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
     for (auto &t : ctx->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
@@ -272,6 +301,9 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (!ctx) return RBF_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_query) (void)hipEventDestroy(ctx->ev_query);
+    if (ctx->ev_compact) (void)hipEventDestroy(ctx->ev_compact);
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->ones_pinned) (void)hipHostFree(ctx->ones_pinned);
@@ -297,6 +329,11 @@ int rbf_ctx_sync(rbf_ctx *ctx)
     if (int r = set_device(ctx)) return r;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RBF_OK;
+}
+
+int rbf_ctx_flush(rbf_ctx *ctx)
+{
+    return set_device(ctx);                       // joins whatever the library has outstanding beside the context's stream
 }
 
 int rbf_malloc(rbf_ctx *ctx, size_t bytes, void **out_dev)
@@ -378,6 +415,17 @@ int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value)
     if (!ctx) return fail(RBF_EINVAL, "null context");
     switch (option) {
     case RBF_OPT_SEPARATE_FINISH: ctx->no_fused_finish = value ? 1 : 0; return RBF_OK;
+    case RBF_OPT_DEBUG_SKIP: ctx->debug_skip = (uint32_t)value; return RBF_OK;
+    case RBF_OPT_SIDE_COMPACT: {
+        if (int r = set_device(ctx)) return r;                    // (joins an outstanding compaction before the mode changes)
+        if (value && !ctx->side_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_query, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_compact, hipEventDisableTiming));
+        }
+        ctx->side_compact = value ? 1 : 0;
+        return RBF_OK;
+    }
     default: return fail(RBF_EINVAL, "unknown option %d", option);
     }
 }
@@ -900,7 +948,9 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         LaunchTimer t(ctx, RBF_K_QUERY);
         // A context that is the pixel-index hash table's only holder has the kernel -- which hashes every index anyway -- write it again:
         // 66 MB of identical values whose only purpose is to be in the Infinity Cache when the next batch's insert gathers from them (one
-        // pipeline: insert 47 -> 38 us, step 214 -> 209).  With several holders the table stays cached by being used.
+        // pipeline: insert 47 -> 38 us, step 214 -> 209).  With several holders the table stays cached by being used.  (READING the hashes
+        // from the table instead of computing them was measured in round 4: 73.2 instead of 74.7 us alone, nothing in the step, and 66 MB of
+        // extra traffic per launch -- not kept.)
         uint4 *table_out = nullptr;
         const SharedHashTable *sh = ctx->hash_shared;
         if (table_for_next && sh && sh->n == n && sh->seeds.h1 == sd.h1 && sh->seeds.h2 == sd.h2 && sh->seeds.act == sd.act && !ctx->no_hash_table) {
@@ -1048,6 +1098,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
             f0 = f;
             if (!per_tile) continue;
             LaunchTimer t(ctx, RBF_K_INSERT);
+            if (ctx->debug_skip & (1u << RBF_K_INSERT)) continue;
             if (two_phase) {
                 FrameTable rtab = tab;
                 uint64_t first = 0;
@@ -1071,12 +1122,14 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);
             const uint64_t words = filter_stride_bytes / 4;
+            if (!(ctx->debug_skip & (1u << RBF_K_REDUCE))) {
             const uint32_t vec_ok = (words % 4 == 0 && ((uintptr_t)filters_dev % 16) == 0) ? 1u : 0u;
             uint32_t bx = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx < 1) bx = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                                (const uint32_t *)ctx->partials, part_stride, pl.S, pl.slices, tab, (uint32_t *)filters_dev, words, stats_dev, vec_ok,
                                image, (uint64_t)pl.image_stride_words);
+            }
         }
     } else {
         HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
@@ -1102,16 +1155,33 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         }
     }
     // ---- query: pass word of every 64 positions + per-segment pass counts
+    if (int r = join_side(ctx)) return r;         // (an outstanding compaction still reads the pass bytes and segment counts the query is about to overwrite)
+    if (!(ctx->debug_skip & (1u << RBF_K_QUERY)))
     if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, want_image, pl.insert_tab, quiet_passthrough)) return r;
     // ---- witness: pext(mask, pass) of every word lands at its bit offset (scan fused in)
-    if (compact) {
+    if (compact && !(ctx->debug_skip & (1u << RBF_K_STITCH))) {
         const uint64_t words = pl.nseg * pl.words_per_seg;
         uint64_t bx = (words + WG_THREADS * CW_CHUNKS - 1) / (WG_THREADS * CW_CHUNKS);
         if (bx < 1) bx = 1;
-        LaunchTimer t(ctx, RBF_K_STITCH);
-        hipLaunchKernelGGL(k_compact_witness, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
-                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4, stats_dev);
+        hipStream_t cs = ctx->stream;
+        if (ctx->side_ok && ctx->side_compact) {                       // behind the query, on the side stream
+            HIP_TRY(hipEventRecord(ctx->ev_query, ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->side_stream, ctx->ev_query, 0));
+            cs = ctx->side_stream;
+        }
+        {
+            LaunchTimer t(ctx, RBF_K_STITCH, cs);
+            hipLaunchKernelGGL(k_compact_witness, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, cs,
+                               ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
+                               (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4, stats_dev);
+        }
+        if (cs != ctx->stream) {
+            HIP_TRY(hipEventRecord(ctx->ev_compact, cs));
+            ctx->side_pending = true;
+            ctx->side_masks = masks_dev; ctx->side_masks_bytes = (size_t)nframes * mask_stride_bytes;
+            ctx->side_wit = witnesses_dev; ctx->side_wit_bytes = (size_t)nframes * witness_stride_bytes;
+            ctx->side_stats = stats_dev; ctx->side_stats_bytes = (size_t)nframes * RBF_STATS_PER_FRAME * 8;
+        }
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;
@@ -1161,7 +1231,7 @@ static int encode_batch_impl(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                              void *witnesses_dev, uint64_t witness_stride_bytes,
                              uint64_t *stats_dev, bool outputs_zeroed, const uint64_t *ones_host = nullptr)
 {
-    if (int r = set_device(ctx)) return r;
+    if (int r = set_device(ctx, !ctx->side_ok)) return r;
     if (!masks_dev || !params || !seeds || !filters_dev || !witnesses_dev || !stats_dev) return fail(RBF_EINVAL, "null pointer");
     if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
     if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
@@ -1289,7 +1359,7 @@ int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_st
     if (!ctx) return fail(RBF_EINVAL, "null context");
     if (ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_begin: the previous GOP of this context has not been finished");
     if (!filters_dev || !witnesses_dev || !stats_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
-    if (int r = set_device(ctx)) return r;
+    if (int r = set_device(ctx, false)) return r;
     // nothing below this block has run, and nothing of the caller's has been touched, when an argument is bad
     if (int r = check_mask_args(frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
                                 thr_floors, masks_dev, mask_stride_bytes, ones_dev)) return r;
@@ -1315,6 +1385,15 @@ int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_st
     // The GPU publishes the counts straight into host memory and clears the output buffers in the same pass -- inside the mask
     // kernel when it covers the whole frame, else through k_finish_ones -- so the only thing between the mask kernel and the
     // Bloom kernels is the host's float64 parameter math.
+    // An outstanding side-stream compaction (RBF_OPT_SIDE_COMPACT) reads the PREVIOUS GOP's masks and writes its witness rows and stats:
+    // this GOP's mask stage may start beside it only when it touches none of those (a caller that alternates two output sets), else
+    // it waits -- correct either way.
+    if (ctx->side_pending &&
+        (ranges_overlap(masks_dev, (size_t)pairs * mask_stride_bytes, ctx->side_masks, ctx->side_masks_bytes) ||
+         ranges_overlap(witnesses_dev, (size_t)pairs * witness_stride_bytes, ctx->side_wit, ctx->side_wit_bytes) ||
+         ranges_overlap(stats_dev, (size_t)pairs * RBF_STATS_PER_FRAME * 8, ctx->side_stats, ctx->side_stats_bytes) ||
+         ranges_overlap(witnesses_dev, (size_t)pairs * witness_stride_bytes, ctx->side_masks, ctx->side_masks_bytes)))
+        if (int r = join_side(ctx)) return r;
     const uint64_t token = ++ctx->publish_token;
     MaskFinish tail{};
     tail.host_block = ctx->ones_mapped_dev; tail.token = token;
@@ -1347,7 +1426,7 @@ int rbf_encode_gop_finish(rbf_ctx *ctx, rbf_filter_params *params_out, double *k
 {
     if (!ctx) return fail(RBF_EINVAL, "null context");
     if (!ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_finish: no GOP has been begun on this context");
-    if (int r = set_device(ctx)) return r;
+    if (int r = set_device(ctx, false)) return r;
     const rbf_ctx::PendingGop g = ctx->gop;
     ctx->gop.active = false;                                      // whatever happens below, the context is free for the next begin
     volatile uint64_t *flag = ctx->ones_pinned;
@@ -1363,8 +1442,11 @@ int rbf_encode_gop_finish(rbf_ctx *ctx, rbf_filter_params *params_out, double *k
     if (int r = rbf_plan_batch(g.n, ctx->ones_pinned + 1, g.pairs, 1, ctx->plan.data(), ctx->plan_k.data())) return r;
     if (params_out) memcpy(params_out, ctx->plan.data(), (size_t)g.pairs * sizeof(rbf_filter_params));
     if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)g.pairs * sizeof(double));
-    return encode_batch_impl(ctx, g.masks_dev, g.mask_stride_bytes, g.n, g.pairs, ctx->plan.data(), &g.seeds,
-                             g.filters_dev, g.filter_stride_bytes, g.witnesses_dev, g.witness_stride_bytes, g.stats_dev, true, ctx->ones_pinned + 1);
+    ctx->side_ok = true;
+    const int rc = encode_batch_impl(ctx, g.masks_dev, g.mask_stride_bytes, g.n, g.pairs, ctx->plan.data(), &g.seeds,
+                                     g.filters_dev, g.filter_stride_bytes, g.witnesses_dev, g.witness_stride_bytes, g.stats_dev, true, ctx->ones_pinned + 1);
+    ctx->side_ok = false;
+    return rc;
 }
 
 int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,

@@ -805,6 +805,18 @@ struct MaskFinish {
     uint4 *clear_b; uint64_t quads_b;
 };
 
+// sum over the wave's 64 lanes, valid in lane 63: quad swaps, row rotates, then the rows' totals broadcast forward
+__device__ __forceinline__ uint32_t mask_wave_sum_to_lane63(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true);     // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);     // row_ror:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);     // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);     // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 template <typename SAMPLE, int PIXEL_BYTES, bool NT = false, bool THR0 = false>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t nframes, uint64_t nsegs /* of 1024 px */,
@@ -826,12 +838,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         const uint64_t lane_off = (seg * 1024 + (uint64_t)lane * 16) * PIXEL_BYTES;
         const uint8_t *p = frames + lane_off;
         uint16_t *out = masks + seg * 64 + lane;
-        LP fa, fb, fc;                                            // three frames in registers, roles rotate
+        LP fa, fb, fc, fd;                                        // four frames in registers, roles rotate: TWO loads are in flight while a pair is compared
         fa.template load<NT>(p + (uint64_t)f0 * frame_stride);
         fb.template load<NT>(p + (uint64_t)(f0 + 1) * frame_stride);
-        // pair (prev, cur) = mask f-1; `nxt` receives frame f+1 meanwhile
-        auto step = [&](const LP &prev, const LP &cur, LP &nxt, uint32_t f) {
-            if (f + 1 <= f1) nxt.template load<NT>(p + (uint64_t)(f + 1) * frame_stride);
+        if (f0 + 2 <= f1) fc.template load<NT>(p + (uint64_t)(f0 + 2) * frame_stride);
+        // pair (prev, cur) = mask f-1; `nxt2` receives frame f+2 meanwhile (frame f+1 is already on its way)
+        auto step = [&](const LP &prev, const LP &cur, LP &nxt2, uint32_t f) {
+            if (f + 2 <= f1) nxt2.template load<NT>(p + (uint64_t)(f + 2) * frame_stride);
             const int32_t thr = thr_tab ? thr_tab[f - 1] : thr_all;
             uint32_t bits = 0;
             if (THR0) bits = lane_bits_thr0<SAMPLE, PIXEL_BYTES>(prev, cur);      // host: no per-pair table and thr == 0
@@ -843,17 +856,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
                 }
             }
             out[(uint64_t)(f - 1) * mask_stride_u16] = (uint16_t)bits;
-            uint32_t c = __popc(bits);
-#pragma unroll
-            for (int dlt = 32; dlt >= 1; dlt >>= 1) c += __shfl_down(c, dlt);
-            if (lane == 0 && c) atomicAdd(&cnt[f - 1], c);
+            // the wave's count of the pair: six DPP adds, total in lane 63 (six __shfl_down were six ds_bpermute round trips per step)
+            const uint32_t c = mask_wave_sum_to_lane63(__popc(bits));
+            if (lane == 63u && c) atomicAdd(&cnt[f - 1], c);
         };
-        // unrolled by three so that the rotation prev <- cur <- nxt costs no register moves (they were a
-        // quarter of the loop's VALU instructions)
-        for (uint32_t f = f0 + 1; f <= f1; f += 3) {
-            step(fa, fb, fc, f);
+        // unrolled by four so that the rotation prev <- cur <- nxt <- nxt2 costs no register moves
+        for (uint32_t f = f0 + 1; f <= f1; f += 4) {
+            step(fa, fb, fd, f);
             if (f + 1 <= f1) step(fb, fc, fa, f + 1);
-            if (f + 2 <= f1) step(fc, fa, fb, f + 2);
+            if (f + 2 <= f1) step(fc, fd, fb, f + 2);
+            if (f + 3 <= f1) step(fd, fa, fc, f + 3);
         }
     }
     __syncthreads();
