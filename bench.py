@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--no-clips", action="store_true", help="skip the clip300 / clip300_uint16 legs (BASELINE configs 3 and 5) behind the weak-scaling headline")
     ap.add_argument("--clip-leg-frames", type=int, default=300, help="frames of the clip legs of the default run")
     ap.add_argument("--clip-steps", type=int, default=10, help="timed passes over the clip in the clip legs")
-    ap.add_argument("--begin-ahead", type=int, default=-1, help="GOPs whose mask stage (rbf_encode_gop_begin) is enqueued before the oldest one is finished (rbf_encode_gop_finish); 0 = the one-call form, -1 = auto (pipelines - 1)")
+    ap.add_argument("--begin-ahead", type=int, default=0, help="GOPs whose mask stage (rbf_encode_gop_begin) is enqueued before the oldest one is finished (rbf_encode_gop_finish); 0 = the one-call form (default: the fastest feed measured, profiles/r04_feed_sweep.txt), -1 = pipelines - 1")
     ap.add_argument("--host-threads", type=int, default=0, help="1 = one host thread per pipeline (each calls rbf_encode_gop for its own context; ctypes drops the GIL) instead of one thread issuing begin / finish in turn")
     ap.add_argument("--side-compact", action="store_true", help="RBF_OPT_SIDE_COMPACT: the witness compaction on a library-owned side stream beside the next GOP's mask / insert / reduce, two output sets per pipeline (measured: no gain, profiles/r04_side_compact.txt)")
     ap.add_argument("--skip-kernels", type=str, default="", help="diagnostic (results WRONG, implies --no-verify): comma list of insert,reduce,query,stitch not to launch -- what does each cost the overlapped step?")
@@ -429,7 +429,7 @@ def main():
         if q_alone:
             achieved = alg_bytes / (q_alone * 1e-3) / 1e9
             default_shape = (W, H, F, args.bits) == (1920, 1080, 30, 8)
-            qname = "k_query_s64" if default_shape else "query kernel of this geometry (DESIGN.md 4)"
+            qname = "k_query_u64" if default_shape else "query kernel of this geometry (DESIGN.md 4)"
             rf = {"bound": "hbm", "kernel": qname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                   "avg_launch_ms": q_alone, "launches_averaged": ALONE_LAUNCHES,
@@ -612,7 +612,7 @@ def pipelines_leg(torch, nat, device, local_rank, W, H, F, bits, planar, G_res, 
     alg_bytes = pairs * n / 8 + sum(r["l"] for r in res) / 8 + sum(r["witness_bits"] for r in res) / 8
     if alone.get("query"):
         ach = alg_bytes / (alone["query"] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_query_s64t" if n > 1920 * 1080 else "k_query_s64", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        out["roofline"] = {"bound": "hbm", "kernel": "k_query_s64t" if n > 1920 * 1080 else "k_query_u64", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBPS, 5), "avg_launch_ms": alone["query"], "launches_averaged": 20,
                            "algorithmic_bytes_per_launch": int(alg_bytes)}
     if verify:
@@ -647,29 +647,30 @@ def check_gathered(og, world, G, pairs, n, res_all):
 
 
 def issue_roofline(W, H, F, bits, breakdown):
-    """Companion to the HBM roofline ('expect the kernel to sit on the integer-ALU ceiling first; report both'): the VALU-issue
-    bound of the two big kernels -- their VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, committed) at the four cycles per
-    wave-instruction and SIMD of gfx950's 16-lane SIMDs.  Replayed constants, tagged with their source; only valid for the workload
-    they were collected on."""
-    path = os.path.join(REPO, "profiles", "r03_issue_model.json")
-    if (W, H, F, bits) != (1920, 1080, 30, 8) or not os.path.exists(path) or not breakdown:
+    """Companion to the HBM roofline ('expect the kernel to sit on the integer-ALU ceiling first; report both'): the
+    instruction-issue bound of the query kernel's frame loop -- the ISA of the in-tree library's loop priced with the per-opcode issue
+    costs measured on this chip (profiles/r04_opbench2.txt; tools/make_r04_models.py writes profiles/r04_issue_model.json).  Two bounds
+    are given because the model has one open term: whether a scalar instruction costs the SIMD issue time next to a VALU stream (it
+    does in the micro-benchmark).  Replayed constants, tagged with their source; only valid for the workload they were made for."""
+    path = os.path.join(REPO, "profiles", "r04_issue_model.json")
+    if (W, H, F, bits) != (1920, 1080, 30, 8) or not os.path.exists(path) or not breakdown or not breakdown.get("query"):
         return None
     with open(path) as f:
         model = json.load(f)
-    out = {"bound": "valu-issue", "cycles_per_valu_wave_instruction": model["cycles_per_valu"],
-           "source": "profiles/r03_issue_model.json (replayed constants: SQ_INSTS_VALU per launch from profiles/r03_rocprofv3_summary.txt)"}
-    for kname, key in (("k_query_s64", "query"), ("k_insert_tab", "insert")):
-        m = model.get(kname)
-        if m and breakdown.get(key):
-            out[kname] = {"valu_bound_ms": m["valu_bound_ms"], "launch_ms_alone": breakdown[key], "frac": round(m["valu_bound_ms"] / breakdown[key], 3)}
-    return out
+    q = breakdown["query"]
+    lo, hi = model["frame_loop_issue_bound_valu_only_ms"], model["frame_loop_issue_bound_ms"]
+    return {"bound": "instruction issue (VALU, and VALU + SALU) of the 29 frame passes", "kernel": model["kernel"],
+            "frame_loop_valu_only_ms": lo, "frame_loop_valu_plus_salu_ms": hi, "launch_ms_alone": q,
+            "frac_of_launch": [round(lo / q, 3), round(hi / q, 3)],
+            "prologue_ms": model.get("prologue_ms"),
+            "source": "profiles/r04_issue_model.json (replayed constants: ISA histogram of the frame loop x profiles/r04_opbench2.txt)"}
 
 
 def measured_traffic(W, H, F, bits, custom_density):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
     collected in separate --pmc runs and corrected as MI355X_MICROARCH.md prescribes).  A replayed constant,
     tagged with its source; null for any other workload."""
-    for name in ("r03_query_traffic.json",):
+    for name in ("r04_query_traffic.json",):
         path = os.path.join(REPO, "profiles", name)
         if (W, H, F, bits) == (1920, 1080, 30, 8) and not custom_density and os.path.exists(path):
             with open(path) as f:

@@ -36,12 +36,17 @@ def test_every_cited_path_exists():
 
 def test_bench_replays_the_constants_it_names():
     src = open(os.path.join(REPO, "bench.py"), encoding="utf-8").read()
-    for name in ("r03_query_traffic.json", "r03_issue_model.json"):
+    for name in ("r04_query_traffic.json", "r04_issue_model.json"):
         assert name in src, name
         d = json.load(open(os.path.join(REPO, "profiles", name)))
         assert isinstance(d, dict) and d
-    t = json.load(open(os.path.join(REPO, "profiles/r03_query_traffic.json")))
+    t = json.load(open(os.path.join(REPO, "profiles/r04_query_traffic.json")))
     assert abs(t["hbm_bytes_per_launch"] - (2 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024) < 2048
-    m = json.load(open(os.path.join(REPO, "profiles/r03_issue_model.json")))
-    q = m["k_query_s64"]
-    assert abs(q["valu_bound_ms"] - q["valu_wave_insts_per_launch"] * m["cycles_per_valu"] / (m["simds"] * m["clock_ghz"] * 1e6)) < 1e-4
+    m = json.load(open(os.path.join(REPO, "profiles/r04_issue_model.json")))
+    # the bound is the table it is printed next to: sum(count x cycles) x waves per SIMD x frames / clock
+    cyc = sum(r["per_wave_and_frame"] * r["cycles_each"] for r in m["table"])
+    bound = 29 * cyc * m["waves_per_simd"] / (m["shader_clock_ghz"] * 1e9) * 1e3
+    assert abs(bound - m["frame_loop_issue_bound_ms"]) < 1e-3, (bound, m["frame_loop_issue_bound_ms"])
+    assert m["frame_loop_issue_bound_valu_only_ms"] < m["frame_loop_issue_bound_ms"]
+    assert m["kernel"].startswith("k_query_u64") and "k_query_u64" in src
+

@@ -8,11 +8,11 @@ echo "3840x2160, 8 inter-frames per step; throughput with the default four pipel
 echo "(FETCH_SIZE doubled for the query kernel: 16-byte LDS-DMA reads are under-reported by half on gfx950, MI355X_MICROARCH.md)"
 printf "%-9s %-10s %-9s %-10s %-10s %-12s %-12s %-12s \n" tile_KiB Gpixel/s ms/step insert_us query_us q_read_MB q_write_MB q_HBM_GB/s
 for t in 16 32 64 96 128 0; do
-  python $ROOT/bench.py --width 3840 --height 2160 --frames 9 --steps 40 --no-cpu-baseline --no-verify --no-clips --lds-tile-kib $t 2>/dev/null | grep '^{' | tail -1 > $OUT/bench_$t.json
+  python $ROOT/bench.py --width 3840 --height 2160 --frames 9 --steps 40 --no-cpu-baseline --no-verify --no-clips --no-legs --lds-tile-kib $t 2>/dev/null | grep '^{' | tail -1 > $OUT/bench_$t.json
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc_${t}_$c
     rocprofv3 --output-format csv --pmc $c --kernel-trace -d $OUT/pmc_${t}_$c -o pmc -- python $ROOT/bench.py --width 3840 --height 2160 --frames 9 --streams 1 --steps 10 --warmup 2 \
-      --no-cpu-baseline --no-kernel-timing --no-verify --no-clips --lds-tile-kib $t > $OUT/pmc_${t}_$c.log 2>&1
+      --no-cpu-baseline --no-kernel-timing --no-verify --no-clips --no-legs --lds-tile-kib $t > $OUT/pmc_${t}_$c.log 2>&1
   done
   python - "$OUT" "$t" <<'PY'
 import csv, glob, json, os, sys
