@@ -582,7 +582,7 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     const size_t fbytes = (size_t)((p.fwords_max + 3u) & ~3u) * 4;
     // insert: whole partial filter in LDS next to the per-wave queues, else tiles of the largest size that fits
     // the table-driven insert kernel has the larger per-wave queue; size the tiles for whichever may run
-    const size_t queue_bytes = (size_t)IL_WAVES * (IT_QUEUE > IL_QUEUE ? IT_QUEUE : IL_QUEUE) * 4;
+    const size_t queue_bytes = (size_t)IL_WAVES * (IT_WAVE_LDS_BYTES > IL_QUEUE * 4 ? IT_WAVE_LDS_BYTES : IL_QUEUE * 4);
     const uint32_t max_tile_words = (uint32_t)((LDS_LIMIT - queue_bytes) / 4) & ~3u;
     p.insert_tile_words = ((p.fwords_max + 3u) & ~3u) <= max_tile_words ? ((p.fwords_max + 3u) & ~3u) : max_tile_words;
     if (ctx->tile_words && ctx->tile_words < p.insert_tile_words) p.insert_tile_words = ctx->tile_words & ~3u;
@@ -1020,7 +1020,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
     FrameTable tab;
     if (int r = fill_table(params, nframes, &tab)) return r;
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * pl.words_per_seg * 8)) return r;
-    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
+    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4 + 16)) return r;     // + 16: k_compact_witness reads the counts four to a load
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
     const bool want_image = (pl.query_kind == 1 || pl.query_kind == 3) && pl.f64_mod;       // the reduce kernel also writes the FP64 query kernel's probe image
@@ -1062,8 +1062,10 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                 if (itab.f[f].m) { const double ninv = -1.0 / (double)itab.f[f].m; memcpy(&itab.f[f].M, &ninv, 8); }
         auto ikern = pl.small_m ? k_insert_lds<true> : k_insert_lds<false>;
         if (int r = allow_big_lds((const void *)ikern)) return r;
-        if (int r = allow_big_lds((const void *)k_insert_tab<false>)) return r;
-        if (int r = allow_big_lds((const void *)k_insert_tab<true>)) return r;
+        // one tile = the whole filter: the kernel without the in-tile test per probe
+        const bool whole = pl.insert_tiles == 1;
+        auto tkern = hashed_positions ? (whole ? k_insert_tab<true, true> : k_insert_tab<true, false>) : (whole ? k_insert_tab<false, true> : k_insert_tab<false, false>);
+        if (int r = allow_big_lds((const void *)tkern)) return r;
         const bool two_phase = pl.insert_two_phase && use_tab;    // (its record memory was reserved above)
         if (two_phase) {
             // itab.floor_k / rtab.T carry the index of the frame's first record (the kernels' own use of those fields: none)
@@ -1106,14 +1108,10 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                 hipLaunchKernelGGL(k_insert_records, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
                                    (const uint2 *)ctx->ins_records, (const uint32_t *)ctx->ins_counters, rtab, ctx->partials, part_stride,
                                    pl.insert_tile_words, grp, per_tile, pl.S);
-            } else if (use_tab && hashed_positions)
-                hipLaunchKernelGGL((k_insert_tab<true>), dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
-                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)nullptr, sd, ctx->partials, part_stride,
-                                   pl.insert_tile_words, grp, per_tile, pl.S);
-            else if (use_tab)
-                hipLaunchKernelGGL((k_insert_tab<false>), dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
-                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, (const uint4 *)ctx->hash_tab, sd, ctx->partials, part_stride,
-                                   pl.insert_tile_words, grp, per_tile, pl.S);
+            } else if (use_tab)
+                hipLaunchKernelGGL(tkern, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
+                                   (const uint8_t *)masks_dev, mask_stride_bytes, n, itab, hashed_positions ? (const uint4 *)nullptr : (const uint4 *)ctx->hash_tab, sd,
+                                   ctx->partials, part_stride, pl.insert_tile_words, grp, per_tile, pl.S);
             else
                 hipLaunchKernelGGL(ikern, dim3(per_tile * pl.insert_tiles), dim3(IL_THREADS), pl.insert_lds_bytes, ctx->stream,
                                    (const uint8_t *)masks_dev, mask_stride_bytes, n, tab, sd, ctx->partials, part_stride, pl.insert_tile_words,
@@ -1161,7 +1159,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
     // ---- witness: pext(mask, pass) of every word lands at its bit offset (scan fused in)
     if (compact && !(ctx->debug_skip & (1u << RBF_K_STITCH))) {
         const uint64_t words = pl.nseg * pl.words_per_seg;
-        uint64_t bx = (words + WG_THREADS * CW_CHUNKS - 1) / (WG_THREADS * CW_CHUNKS);
+        uint64_t bx = (words + WG_THREADS - 1) / WG_THREADS;
         if (bx < 1) bx = 1;
         hipStream_t cs = ctx->stream;
         if (ctx->side_ok && ctx->side_compact) {                       // behind the query, on the side stream

@@ -16,6 +16,33 @@ constexpr int SEG_ITERS = SEG_PIXELS / WAVE;     // 16
 constexpr int WG_THREADS = 256;
 constexpr int WG_WAVES = WG_THREADS / WAVE;      // 4
 
+// ---- wave-wide sums without LDS: DPP adds (a __shfl_* is a ds_bpermute round trip through LDS on gfx950) ------------------------
+// Sum over the wave's 64 lanes, valid in lane 63 (rows 1-3 hold partial totals): quad swaps, row rotates -- every lane of a row holds
+// the row's sum -- then the rows' totals broadcast forward.  Also used on a packed pair of 16-bit counts.
+__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true);     // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);     // row_ror:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);     // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);     // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+// Inclusive prefix sum over the wave's 64 lanes in six DPP adds: a Hillis-Steele scan inside every row of 16 lanes
+// (row_shr 1, 2, 4, 8; lanes without a source add 0), then row 0's / row 2's total onto rows 1 / 3 (row_bcast:15) and the
+// total of rows 0-1 onto rows 2-3 (row_bcast:31).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
 // ------------------------------------------------------------------------------------------
 // A1  residual mask: bit = abs_int16(prev - curr) > thr   (improved_video_compressor.py:801,808)
 // ------------------------------------------------------------------------------------------

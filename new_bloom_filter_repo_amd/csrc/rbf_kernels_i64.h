@@ -52,45 +52,50 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash_table(uint64_t n, Seeds see
     for (int it = 0; it < QL_P; ++it) hash_table_store(table, seg, lane, it, h1[it], h2[it], ha[it]);
 }
 
-// Inclusive prefix sum over the wave's 64 lanes in six DPP adds: a Hillis-Steele scan inside every row of 16 lanes
-// (row_shr 1, 2, 4, 8; lanes without a source add 0), then row 0's / row 2's total onto rows 1 / 3 (row_bcast:15) and the
-// total of rows 0-1 onto rows 2-3 (row_bcast:31).  No LDS, no ballots.
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
-{
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);      // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);      // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
-    return x;
-}
-
 constexpr int IT_STEP_BYTES = 128;                 // mask bytes per wave step: a lane owns 16 pixels (two bytes)
-constexpr int IT_QUEUE = 64 + IT_STEP_BYTES * 8;   // carry (< 64) + one wave step
+constexpr int IT_CHUNK_STEPS = 16;                 // wave steps whose mask bytes are staged in LDS at a time
+constexpr int IT_QUEUE = 64 + IT_STEP_BYTES * 8;   // queue entries (16 bits each): carry (< 64) + one wave step
+constexpr int IT_STAGE_BYTES = IT_CHUNK_STEPS * IT_STEP_BYTES;
+constexpr int IT_WAVE_LDS_BYTES = IT_QUEUE * 2 + IT_STAGE_BYTES;      // per wave: the queue, then the staged mask bytes (4224)
+static_assert(IT_WAVE_LDS_BYTES % 16 == 0 && (IT_QUEUE * 2) % 16 == 0, "the stage is written by LDS-DMA");
 
 // `fd`: M carries the bits of -1.0 / m (IEEE double, computed on the host) instead of the Barrett constant.
 //
 // The body shared by the two table-driven kernels that walk a mask: this wave takes wave steps g0 + wave, + NWAVES, ... < g1,
-// compacts the set positions through its LDS queue `q` and, for every batch of <= 64 keys, gathers the table entries and
+// compacts the set positions through its LDS queue and, for every batch of <= 64 keys, gathers the table entries and
 // reduces them.  RECORDS = false (k_insert_tab): the probe positions are OR-ed into the LDS tile `filt` covering bits
-// [tile_bit0, tile_bit0 + tile_bits).  RECORDS = true (k_insert_positions): the batch is appended to the frame's list of
+// [tile_bit0, tile_bit0 + tile_bits); WHOLE: the tile is the whole filter (every frame whose filter fits LDS next to the queues),
+// no in-tile test per probe.  RECORDS = true (k_insert_positions): the batch is appended to the frame's list of
 // InsertRecords, 64 contiguous records per batch, starting at records[rpos] (this wave's own range of the list).
 // HASHED: no table -- the batch's three hashes are computed on the spot (hash3_index, as k_insert_lds does).  Cheaper than the
 // gather once the table (32 B per pixel) no longer fits the 256 MB Infinity Cache: at 2160p the gather of a GOP's 5.9 M
 // entries costs 58 us of random HBM reads, hashing them ~35.
-template <bool RECORDS, int NWAVES, bool HASHED = false>
-__device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mask, uint64_t n, const FrameDev &fd, const uint4 *__restrict__ table, const Seeds &seeds,
+//
+// THE MASK BYTES COME THROUGH LDS (round 4).  A wave's steps are staged IT_CHUNK_STEPS at a time by LDS-DMA (eight
+// global_load_lds_dword per chunk, no registers) and then read with ds_read_u16.  Rounds 2 and 3 loaded every step's two bytes per
+// lane with a global load "one step ahead" -- but vmcnt counts the mask loads and the table gathers in ONE in-order queue, and with
+// a data-dependent number of gathers between two mask loads the compiler can only wait for a mask load with vmcnt(0)/(1): every step
+// drained the gather it had just issued, and (the load sitting inside `if (in range)`) waited for its own prefetch as well.  Neither
+// the "gather flies under the next step's compaction" nor the prefetch ever happened: ~28 exposed L2 round trips per wave.  With the
+// mask bytes on the LDS counter the only vector-memory loads left in the loop are the gathers, and the wait in front of `finish` is
+// the only one.  The queue holds 16-bit entries (step of the chunk << 10 | bit of the step) to make room for the stage; the carry is
+// flushed as a partial batch at the end of a chunk (1080p: one chunk per wave).
+template <bool RECORDS, int NWAVES, bool HASHED = false, bool WHOLE = false>
+__device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mask /* wave-uniform */, uint64_t row_bytes /* the row pitch: bytes that may be read */, uint64_t n,
+                                                 const FrameDev &fd, const uint4 *__restrict__ table, const Seeds &seeds,
                                                  uint32_t *filt, uint32_t tile_bit0, uint32_t tile_bits, uint2 *__restrict__ records, uint32_t rpos,
-                                                 uint32_t *q, uint64_t g0, uint64_t g1, uint32_t lane, uint32_t wave)
+                                                 uint32_t *wave_lds /* IT_WAVE_LDS_BYTES of this wave */, uint64_t g0, uint64_t g1, uint32_t lane, uint32_t wave)
 {
-    const uint64_t nbytes = (n + 7) >> 3;
+    static_assert((NWAVES & (NWAVES - 1)) == 0, "a power of two");
+    uint16_t *q = reinterpret_cast<uint16_t *>(wave_lds);
+    const uint32_t stage = __builtin_amdgcn_readfirstlane(lds_addr_of(wave_lds) + IT_QUEUE * 2);      // LDS byte address of the staged steps
     uint32_t qn = 0;                                               // wave-uniform queue length
     const uint32_t m = vgpr_copy(__builtin_amdgcn_readfirstlane(fd.m));
     const uint32_t fk = __builtin_amdgcn_readfirstlane(fd.floor_k);
     const double ninv = __builtin_bit_cast(double, fd.M);
     const uint64_t T = fd.T;
     auto set_bit = [&](uint32_t pos) {
+        if (WHOLE) { atomicOr(&filt[pos >> 5], msb_bit(pos)); return; }
         const uint32_t rel = pos - tile_bit0;                      // unsigned: out-of-tile positions wrap high
         if (rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
     };
@@ -99,8 +104,10 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     // consumed (`finish`) when the next batch is ready -- or at the end -- so the gather latency hides under compaction
     uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
     uint32_t pending = 0;                                          // keys of the batch in flight (wave-uniform)
+    uint32_t cb = 0;                                               // first step of the chunk being walked
     auto fetch = [&](uint32_t first, uint32_t count) {
-        const uint32_t idx = lane < count ? q[first + lane] : 0u;  // idle lanes read entry 0 (always there)
+        const uint32_t e = lane < count ? q[first + lane] : 0u;    // idle lanes read the chunk's first pixel's entry (always there)
+        const uint32_t idx = ((cb + (e >> 10) * NWAVES) << 10) + (e & 1023u);
         if (HASHED) {
             const Hash3 h = hash3_index(idx, lane < count, seeds);      // wave-uniform call (it votes on the key length)
             const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h.h1), d2 = __builtin_bit_cast(uint64_t, (double)h.h2);
@@ -131,48 +138,76 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
         pending = 0;
     };
 
-    // my two bytes of wave step g as 16 bits in natural order (bit j = pixel 16 * lane + j of the step); rows are padded to
-    // 8 bytes, so the 2-byte load never leaves the row
-    auto load_bits = [&](uint64_t g) -> uint32_t {
-        const uint64_t byte = g * IT_STEP_BYTES + lane * 2;
-        if (g >= g1 || byte >= nbytes) return 0u;
-        const uint32_t v = *reinterpret_cast<const uint16_t *>(mask + byte);      // byte 0 = pixels 0..7 MSB-first, byte 1 = pixels 8..15
-        const uint32_t x = __builtin_bitreverse32(v) >> 16;                       // bits 8..15 = byte 0 reversed, bits 0..7 = byte 1 reversed
-        uint32_t b = ((x & 0xFFu) << 8) | (x >> 8);
-        const uint64_t rem = n - byte * 8;
-        if (rem < 16) b &= (1u << rem) - 1u;                      // ignore pad bits
-        return b;
+    const uint32_t nbytes32 = (uint32_t)((n + 7) >> 3), n32 = (uint32_t)n, row32 = (uint32_t)row_bytes;      // n < 2^32 (rbf_plan_batch)
+    const uint32_t gend = (uint32_t)g1;
+    // my two bytes of step `s` of the chunk as 16 bits in natural order (bit j = pixel 16 * lane + j of the step)
+    auto staged = [&](uint32_t s) -> uint32_t {
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(stage + s * IT_STEP_BYTES + lane * 2u));
     };
-    uint32_t nxt = load_bits(g0 + wave);
-    for (uint64_t g = g0 + wave; g < g1; g += NWAVES) {
-        uint32_t bits = nxt;
-        nxt = load_bits(g + NWAVES);                               // prefetch
-        // exclusive prefix of the per-lane counts (0..16): six DPP adds (the five ballots + ten mbcnt of k_insert_lds were a
-        // third of this loop's skeleton)
-        const uint32_t c = __popc(bits);
-        const uint32_t incl = wave_inclusive_scan(c);
-        const uint32_t excl = incl - c;
-        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        uint32_t off = qn + excl;
-        const uint32_t base = (uint32_t)((g * IT_STEP_BYTES + lane * 2) << 3);
-        while (bits) {
-            q[off++] = base + __builtin_ctz(bits);
-            bits &= bits - 1u;
+    auto decode = [&](uint32_t v, uint32_t g) -> uint32_t {        // byte 0 = pixels 0..7 MSB-first, byte 1 = pixels 8..15
+        const uint32_t byte = g * IT_STEP_BYTES + lane * 2u;
+        const uint32_t x = __builtin_bitreverse32(v) >> 16;        // bits 8..15 = byte 0 reversed, bits 0..7 = byte 1 reversed
+        uint32_t b = ((x & 0xFFu) << 8) | (x >> 8);
+        const uint32_t rem = n32 - byte * 8u;
+        if (rem < 16u) b &= (1u << rem) - 1u;                      // ignore pad bits
+        return (g < gend && byte < nbytes32) ? b : 0u;             // (steps past the slice and bytes past the row were not staged)
+    };
+    for (uint32_t chunk = __builtin_amdgcn_readfirstlane((uint32_t)g0 + wave); chunk < gend; chunk += NWAVES * IT_CHUNK_STEPS) {
+        cb = chunk;                                                // (the entries still queued after the loop belong to the last chunk)
+        // stage the chunk: instruction i brings steps 2i and 2i + 1 (lanes 0-31 / 32-63, a dword each); rows are padded to 8 bytes and
+        // `row_bytes` is a multiple of 8, so a dword that starts inside the row ends inside it
+        wave_lds_fence();                                          // the previous chunk's reads are done
+#pragma unroll
+        for (int i = 0; i < IT_CHUNK_STEPS / 2; ++i) {
+            const uint32_t g = cb + (2u * i + (lane >> 5)) * NWAVES;
+            const uint32_t off = g * IT_STEP_BYTES + (lane & 31u) * 4u;
+            if (g < gend && off < row32) {
+                const uint32_t dst = stage + (uint32_t)i * 256u;
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "s"(dst), "v"(off), "s"(mask) : "memory");
+            }
         }
-        qn += total;
+        dma_wait_all();                                            // (also the batch in flight: once per chunk)
         wave_lds_fence();
-        while (qn >= WAVE) {                                       // full waves only; order is irrelevant (OR)
-            qn -= WAVE;
-            finish();
-            fetch(qn, WAVE);
+        uint32_t nxt = staged(0);
+        for (uint32_t s = 0; s < IT_CHUNK_STEPS && cb + s * NWAVES < gend; ++s) {
+            const uint32_t g = cb + s * NWAVES;
+            uint32_t bits = decode(nxt, g);
+            nxt = staged(s + 1 < IT_CHUNK_STEPS ? s + 1 : s);
+            // exclusive prefix of the per-lane counts (0..16): six DPP adds (the five ballots + ten mbcnt of k_insert_lds were a
+            // third of this loop's skeleton)
+            const uint32_t c = __popc(bits);
+            const uint32_t incl = wave_inclusive_scan(c);
+            const uint32_t excl = incl - c;
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            uint32_t off = qn + excl;
+            const uint32_t ebase = (s << 10) | (lane << 4);
+            while (bits) {
+                q[off++] = (uint16_t)(ebase + __builtin_ctz(bits));
+                bits &= bits - 1u;
+            }
+            qn += total;
+            wave_lds_fence();
+            while (qn >= WAVE) {                                   // full waves only; order is irrelevant (OR)
+                qn -= WAVE;
+                finish();
+                fetch(qn, WAVE);
+            }
+            wave_lds_fence();                                      // queue reads done before it is refilled
         }
-        wave_lds_fence();                                          // queue reads done before it is refilled
+        if (cb + NWAVES * IT_CHUNK_STEPS < gend && qn) {           // another chunk follows: its entries count from a new `cb`
+            finish();
+            fetch(0, qn);
+            qn = 0;
+            wave_lds_fence();
+        }
     }
     finish();
     if (qn) { fetch(0, qn); finish(); }
 }
 
-template <bool HASHED = false>
+template <bool HASHED = false, bool WHOLE = false>
 __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     const uint8_t *__restrict__ masks, uint64_t mask_stride_bytes, uint64_t n,
     const FrameTable tab, const uint4 *__restrict__ table /* unused when HASHED: the set positions are hashed on the spot */, Seeds seeds,
@@ -182,7 +217,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     // workgroup -> (tile, frame, slice) exactly as in k_insert_lds (one-dimensional grid, slice fastest)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *filt = lds;                                         // [tile_words]
-    uint32_t *queues = lds + tile_words;                          // [IL_WAVES][IT_QUEUE]
+    uint32_t *queues = lds + tile_words;                          // [IL_WAVES][IT_WAVE_LDS_BYTES]: queue + staged mask bytes per wave (tile_words is a multiple of 4)
     const uint32_t tile = blockIdx.x / per_tile;
     uint32_t s = blockIdx.x - tile * per_tile, f = 0;
     while (s >= slices.n[f]) { s -= slices.n[f]; ++f; }
@@ -201,8 +236,8 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_tab(
     const uint64_t gper = (groups + S - 1) / S;
     const uint64_t g0 = (uint64_t)s * gper;
     const uint64_t g1 = g0 + gper < groups ? g0 + gper : groups;
-    insert_tab_steps<false, IL_WAVES, HASHED>(masks + (uint64_t)f * mask_stride_bytes, n, fd, table, seeds, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
-                                           queues + wave * IT_QUEUE, g0, g1, lane, wave);
+    insert_tab_steps<false, IL_WAVES, HASHED, WHOLE>(masks + (uint64_t)f * mask_stride_bytes, mask_stride_bytes, n, fd, table, seeds, filt, tile0 << 5, tile_words << 5, nullptr, 0u,
+                                                     queues + wave * (IT_WAVE_LDS_BYTES / 4), g0, g1, lane, wave);
     __syncthreads();
     uint32_t *part = partials + ((uint64_t)f * Smax + s) * part_stride_words32 + tile0;
     const uint32_t mine = fwords - tile0 < tile_words ? fwords - tile0 : tile_words;
@@ -235,7 +270,7 @@ __global__ __launch_bounds__(IP_THREADS) void k_insert_positions(
     const FrameTable tab /* M = bits of -1.0 / m, floor_k = index of the frame's first record */, const uint4 *__restrict__ table /* unused when HASHED */, Seeds seeds,
     uint2 *__restrict__ records, uint32_t *__restrict__ counters /* zeroed; records appended per frame */)
 {
-    __shared__ uint32_t queues[IP_WAVES * IT_QUEUE];
+    __shared__ __attribute__((aligned(16))) uint32_t queues[IP_WAVES * (IT_WAVE_LDS_BYTES / 4)];
     const uint32_t f = blockIdx.y, s = blockIdx.x, S = gridDim.x;
     const FrameDev fd = tab.f[f];
     if (fd.m == 0) return;
@@ -273,8 +308,8 @@ __global__ __launch_bounds__(IP_THREADS) void k_insert_positions(
     __syncthreads();
     uint32_t rpos = wg_base;
     for (uint32_t k = 0; k < wave; ++k) rpos += wcount[k];
-    insert_tab_steps<true, IP_WAVES, HASHED>(mask, n, fd, table, seeds, nullptr, 0u, 0u, records + fd.floor_k, (uint32_t)__builtin_amdgcn_readfirstlane((int)rpos),
-                                          queues + wave * IT_QUEUE, g0, g1, lane, wave);
+    insert_tab_steps<true, IP_WAVES, HASHED>(mask, mask_stride_bytes, n, fd, table, seeds, nullptr, 0u, 0u, records + fd.floor_k, (uint32_t)__builtin_amdgcn_readfirstlane((int)rpos),
+                                             queues + wave * (IT_WAVE_LDS_BYTES / 4), g0, g1, lane, wave);
 }
 
 constexpr int IR_UNROLL = 4;                        // records in flight per lane

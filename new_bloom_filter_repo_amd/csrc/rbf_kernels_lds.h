@@ -546,124 +546,115 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_tiled(
 // One lane per 64-pixel word: its bits are pext(mask word, pass word) placed at
 // seg_off[segment] + (passes of the segment's earlier words) in the pre-zeroed packed witness.
 // ------------------------------------------------------------------------------------------
-constexpr int CW_CHUNKS = 1;                      // chunks of WG_THREADS words per workgroup (8 measured slower: 25 vs 20 us -- parallelism wins)
-static_assert(CW_CHUNKS == 1, "only the one-chunk configuration is covered by the tests (a 2-chunk build did not get through bench.py in round 2)");
+struct __attribute__((packed, aligned(4))) SegCounts4 { uint32_t x, y, z, w; };      // four segment counts: rows of seg_cnt are only dword-aligned
 
 __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
     const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n,
     uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32, uint64_t *__restrict__ stats)
 {
-    // A workgroup owns WG_THREADS consecutive words (= whole segments).  Their witness bits form one
-    // contiguous bit range starting at (passes of all earlier segments): the range is assembled in
-    // LDS with LDS atomics and written with plain coalesced stores; only its first and last dword
-    // are shared with the neighbouring workgroups (atomicOr).  No separate scan kernel: the start
-    // is a block reduction over the earlier segment counts, the offsets inside the chunk a block scan.
+    // A workgroup owns WG_THREADS consecutive words (= whole segments).  Their witness bits form one contiguous bit range starting at
+    // (passes of all earlier segments): the range is assembled in LDS with LDS atomics and written with plain coalesced stores; only
+    // its first and last dword are shared with the neighbouring workgroups (atomicOr).  No separate scan kernel: the start is a block
+    // reduction over the earlier segment counts, the offsets inside the chunk a block scan.
+    //
+    // The step is bound by instruction issue, so this kernel is written for a short instruction stream (round 3: ~415
+    // VALU wave-instructions per 64 words, now ~250): the earlier counts are read four to a load, all loads of a thread are in flight
+    // before the first wait, both block-wide sums cross ONE barrier, the wave scans are DPP adds, and the two halves of the software
+    // pext run in one loop of two independent chains.
     __shared__ uint32_t buf[WG_THREADS * 2 + 2];
-    __shared__ unsigned long long red[WG_WAVES];
-    __shared__ uint32_t wsum[WG_WAVES];
+    __shared__ uint32_t red[WG_WAVES], wsum[WG_WAVES];
     const uint32_t f = blockIdx.y;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t nwords = (n + 63) >> 6;
-    const uint64_t total = nseg * words_per_seg;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwords = (uint32_t)((n + 63) >> 6);                        // n < 2^32 (rbf_plan_batch)
+    const uint32_t total = (uint32_t)nseg * words_per_seg;
     const uint64_t *pwf = pass_words + (uint64_t)f * total;
     const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
     uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
-    // a workgroup walks CW_CHUNKS consecutive chunks and carries the running bit offset, so the
-    // reduction over the earlier segment counts is paid once per workgroup, not once per chunk
-    const uint64_t wbeg = (uint64_t)blockIdx.x * (WG_THREADS * CW_CHUNKS);
-    const uint64_t wend = wbeg + WG_THREADS * CW_CHUNKS < total ? wbeg + WG_THREADS * CW_CHUNKS : total;
-    uint64_t start = 0;
-    {
-        const uint64_t seg0 = wbeg / words_per_seg;
-        // eight independent loads in flight per thread (clamped index, no branch): written as `for (s ...) part += cnt[s]` the
-        // loop waits for every load before issuing the next -- up to 16 L2 round trips in a row at 1080p, 64 at 2160p, which
-        // was a fifth of this kernel's time (1080p: 19.3 -> 16.0 us, 2160p: 37 -> 23; sixteen in flight, or also hoisting the
-        // pass / mask word loads above this loop, measured no better)
-        unsigned long long part = 0;
-        for (uint64_t s0 = threadIdx.x; s0 < seg0; s0 += (uint64_t)WG_THREADS * 8) {
-            uint32_t v[8];
+    const uint32_t wbeg = blockIdx.x * WG_THREADS;
+    const uint32_t w = wbeg + threadIdx.x;
+    // my word (packed -> bit b = position 64w + b) and its mask word: requested before anything waits
+    const bool have = w < total && w < nwords;
+    const uint64_t pw_raw = have ? pwf[w] : 0ull;
+    const uint64_t mk_raw = have ? masks[(uint64_t)f * mask_stride_words64 + w] : 0ull;
+    // passes of the earlier segments: four counts per load, four loads in flight per thread (a thread of the last workgroup of a
+    // 1080p frame used to issue sixteen single-count loads behind 64-bit index arithmetic: a third of this kernel's instructions)
+    const uint32_t seg0 = wbeg / words_per_seg;
+    uint32_t part = 0;
+    if ((seg0 & 3u) == 0) {                                                   // (workgroup-uniform) whole quads only: segments of <= 64 words
+        for (uint32_t q0 = threadIdx.x; 4u * q0 < seg0; q0 += WG_THREADS * 4) {
+            SegCounts4 v[4];
+            bool in[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint64_t sk = s0 + (uint64_t)k * WG_THREADS;
-                v[k] = cnt[sk < seg0 ? sk : 0];
-                if (sk >= seg0) v[k] = 0;
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = 4u * (q0 + (uint32_t)k * WG_THREADS);
+                in[k] = i < seg0;
+                v[k] = *reinterpret_cast<const SegCounts4 *>(cnt + (in[k] ? i : 0u));
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) part += v[k];
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t q = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+                part += in[k] ? q : 0u;
+            }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) part += __shfl_down(part, d);
-        if (lane == 0) red[wave] = part;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < WG_WAVES; ++k) start += red[k];
+    } else {
+        for (uint32_t s0 = threadIdx.x; s0 < seg0; s0 += WG_THREADS) part += cnt[s0];
     }
-    for (uint64_t w0 = wbeg; w0 < wend; w0 += WG_THREADS) {
-        for (uint32_t i = threadIdx.x; i < WG_THREADS * 2 + 2; i += WG_THREADS) buf[i] = 0;
-        // my word and the block-exclusive scan of the pass counts
-        const uint64_t w = w0 + threadIdx.x;
-        const uint64_t pw = (w < total && w < nwords) ? flip_bytes64(pwf[w]) : 0ull;     // packed -> bit b = position 64w + b
-        const uint32_t c = __popcll(pw);
-        uint32_t incl = c;
+    buf[threadIdx.x] = 0;
+    buf[threadIdx.x + WG_THREADS] = 0;
+    if (threadIdx.x < 2) buf[threadIdx.x + 2 * WG_THREADS] = 0;
+    const uint64_t pw = flip_bytes64(pw_raw);
+    const uint32_t pw_lo = (uint32_t)pw, pw_hi = (uint32_t)(pw >> 32);
+    const uint32_t c_lo = __popc(pw_lo), c = c_lo + __popc(pw_hi);
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t psum = wave_sum_to_lane63(part);
+    if (lane == WAVE - 1) { wsum[wave] = incl; red[wave] = psum; }
+    __syncthreads();
+    uint32_t start32 = 0, before = 0, chunk_total = 0;
 #pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if (lane >= (uint32_t)d) incl += t;
-        }
-        if (lane == WAVE - 1) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t before = 0, chunk_total = 0;
-#pragma unroll
-        for (int k = 0; k < WG_WAVES; ++k) {
-            if ((uint32_t)k < wave) before += wsum[k];
-            chunk_total += wsum[k];
-        }
-        const uint64_t obase = start & ~31ull;                     // dword-aligned start of my LDS image
-        const uint64_t o = start + before + incl - c;
-        if (pw) {
-            const uint64_t tp = pw & flip_bytes64(masks[(uint64_t)f * mask_stride_words64 + w]);   // passes whose mask bit is 1
-            // pext(mask, pw), LSB = first passing position, as two 32-bit halves: a pass at bit b of a half lands at
-            // popc(the half's passes below b); the high half's result is then shifted up by the low half's pass count.
-            // (One 64-bit loop cost ~18 instructions per set bit, a 32-bit one 7; the wave runs as long as its busiest lane.)
-            const uint32_t pw_lo = (uint32_t)pw, pw_hi = (uint32_t)(pw >> 32);
-            uint32_t t_lo = (uint32_t)tp, t_hi = (uint32_t)(tp >> 32), o_lo = 0, o_hi = 0;
-            while (t_lo) {
-                const uint32_t lsb = t_lo & (0u - t_lo);
-                o_lo |= 1u << __popc(pw_lo & (lsb - 1u));
-                t_lo ^= lsb;
-            }
-            while (t_hi) {
-                const uint32_t lsb = t_hi & (0u - t_hi);
-                o_hi |= 1u << __popc(pw_hi & (lsb - 1u));
-                t_hi ^= lsb;
-            }
-            const uint64_t out = (uint64_t)o_lo | ((uint64_t)o_hi << __popc(pw_lo));
-            if (out) {
-                const uint32_t rel = (uint32_t)(o - obase);
-                const uint32_t sh = rel & 31u, word = rel >> 5;
-                const uint32_t lo = (uint32_t)out, hi = (uint32_t)(out >> 32);
-                const uint32_t d0 = lo << sh;
-                const uint32_t d1 = sh ? ((lo >> (32u - sh)) | (hi << sh)) : hi;
-                const uint32_t d2 = sh ? (hi >> (32u - sh)) : 0u;
-                if (d0) atomicOr(&buf[word], d0);
-                if (d1) atomicOr(&buf[word + 1], d1);
-                if (d2) atomicOr(&buf[word + 2], d2);
-            }
-        }
-        __syncthreads();
-        const uint64_t oend = start + chunk_total;
-        const uint32_t ndw = (uint32_t)(((oend - obase) + 31) >> 5);
-        for (uint32_t i = threadIdx.x; i < ndw; i += WG_THREADS) {
-            const uint32_t v = buf[i];
-            if (!v) continue;
-            if (i == 0 || i + 1 == ndw) atomicOr(&wit[(obase >> 5) + i], flip_bytes32(v));
-            else wit[(obase >> 5) + i] = flip_bytes32(v);
-        }
-        if (threadIdx.x == 0 && w0 + WG_THREADS >= total) stats[(uint64_t)f * 4 + 0] = oend;   // len(witness)
-        start = oend;
-        __syncthreads();
+    for (int k = 0; k < WG_WAVES; ++k) {
+        start32 += red[k];
+        if ((uint32_t)k < wave) before += wsum[k];
+        chunk_total += wsum[k];
     }
+    const uint32_t obase = start32 & ~31u;                                    // dword-aligned start of my LDS image
+    const uint32_t o = start32 + before + incl - c;
+    // pext(mask, pw), LSB = first passing position, as two 32-bit halves in one loop: a pass at bit b of a half lands at
+    // popc(the half's passes below b) -- v_ffbl, v_bfe (the passes below b), v_bcnt, v_lshl_or -- and the high half's result is then
+    // shifted up by the low half's pass count.  The wave runs as long as its busiest lane's busier half (~9 rounds at k* = 2.3).
+    const uint64_t tp = pw & flip_bytes64(mk_raw);                            // passes whose mask bit is 1
+    uint32_t t_lo = (uint32_t)tp, t_hi = (uint32_t)(tp >> 32), o_lo = 0, o_hi = 0;
+    auto ffbl = [](uint32_t x) { uint32_t b; asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"(x)); return b; };          // -1 for 0 (the builtin is undefined there)
+    auto one_if = [](uint32_t x) { uint32_t r; asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(x)); return r; };      // (the compiler's choice: a borrow + v_cndmask through VCC)
+    while (t_lo | t_hi) {
+        const uint32_t r_lo = __popc(__builtin_amdgcn_ubfe(pw_lo, 0u, ffbl(t_lo))), r_hi = __popc(__builtin_amdgcn_ubfe(pw_hi, 0u, ffbl(t_hi)));
+        o_lo |= one_if(t_lo) << r_lo;                                         // an exhausted half adds nothing (its v_bfe takes 31 bits: harmless)
+        o_hi |= one_if(t_hi) << r_hi;
+        t_lo &= t_lo - 1u;
+        t_hi &= t_hi - 1u;
+    }
+    const uint64_t out = (uint64_t)o_lo | ((uint64_t)o_hi << c_lo);
+    if (out) {
+        const uint32_t rel = o - obase;
+        const uint32_t sh = rel & 31u, word = rel >> 5;
+        const uint32_t lo = (uint32_t)out, hi = (uint32_t)(out >> 32);
+        const uint32_t d0 = lo << sh;
+        const uint32_t d1 = sh ? ((lo >> (32u - sh)) | (hi << sh)) : hi;
+        const uint32_t d2 = sh ? (hi >> (32u - sh)) : 0u;
+        if (d0) atomicOr(&buf[word], d0);
+        if (d1) atomicOr(&buf[word + 1], d1);
+        if (d2) atomicOr(&buf[word + 2], d2);
+    }
+    __syncthreads();
+    const uint32_t oend = start32 + chunk_total;
+    const uint32_t ndw = ((oend - obase) + 31u) >> 5;
+    for (uint32_t i = threadIdx.x; i < ndw; i += WG_THREADS) {
+        const uint32_t v = buf[i];
+        if (!v) continue;
+        if (i == 0 || i + 1 == ndw) atomicOr(&wit[(obase >> 5) + i], flip_bytes32(v));
+        else wit[(obase >> 5) + i] = flip_bytes32(v);
+    }
+    if (threadIdx.x == 0 && wbeg + WG_THREADS >= total) stats[(uint64_t)f * 4 + 0] = oend;   // len(witness)
 }
 
 // A6 expand: out[i] = witness[rank(i)] where position i passes, else 0 (:299-304).  One lane per 64-position
@@ -805,18 +796,6 @@ struct MaskFinish {
     uint4 *clear_b; uint64_t quads_b;
 };
 
-// sum over the wave's 64 lanes, valid in lane 63: quad swaps, row rotates, then the rows' totals broadcast forward
-__device__ __forceinline__ uint32_t mask_wave_sum_to_lane63(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true);     // row_ror:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);     // row_ror:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);     // row_bcast:15 -> rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);     // row_bcast:31 -> rows 2 and 3
-    return v;
-}
-
 template <typename SAMPLE, int PIXEL_BYTES, bool NT = false, bool THR0 = false>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t nframes, uint64_t nsegs /* of 1024 px */,
@@ -857,7 +836,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
             }
             out[(uint64_t)(f - 1) * mask_stride_u16] = (uint16_t)bits;
             // the wave's count of the pair: six DPP adds, total in lane 63 (six __shfl_down were six ds_bpermute round trips per step)
-            const uint32_t c = mask_wave_sum_to_lane63(__popc(bits));
+            const uint32_t c = wave_sum_to_lane63(__popc(bits));
             if (lane == 63u && c) atomicAdd(&cnt[f - 1], c);
         };
         // unrolled by four so that the rotation prev <- cur <- nxt <- nxt2 costs no register moves

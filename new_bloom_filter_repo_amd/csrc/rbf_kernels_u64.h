@@ -115,17 +115,7 @@ struct RowDmaC {
     }
 };
 
-// sum over the wave of a packed pair of 16-bit counts (each total <= 512): lane 63 holds both totals afterwards
-__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true);     // row_ror:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);     // row_ror:8   (every lane of a row: the row's sum)
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);     // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);     // row_bcast:31 into rows 2 and 3
-    return v;
-}
+// (the pass counts of two frames are summed over the wave as a packed pair of 16-bit counts, each total <= 512: wave_sum_to_lane63)
 
 // FrameTable as this kernel reads it (host: query_table_u64, rbf_api.hip) -- COMPACTED over the coded frames and ORDERED BY CLASS
 // (floor(k*) = 1, 2, 3, 4, 5, then the rest):
