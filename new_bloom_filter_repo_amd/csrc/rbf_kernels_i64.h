@@ -95,6 +95,10 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     const double ninv = __builtin_bit_cast(double, fd.M);
     const uint64_t T = fd.T;
     auto set_bit = [&](uint32_t pos) {
+#if defined(RBF_INSERT_ABLATE) && RBF_INSERT_ABLATE == 3      // no LDS atomics
+        if (pos == 0xFFFFFFFFu) filt[0] = 1;
+        return;
+#endif
         if (WHOLE) { atomicOr(&filt[pos >> 5], msb_bit(pos)); return; }
         const uint32_t rel = pos - tile_bit0;                      // unsigned: out-of-tile positions wrap high
         if (rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
@@ -113,7 +117,27 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
             const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h.h1), d2 = __builtin_bit_cast(uint64_t, (double)h.h2);
             e0 = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));    // the table's entry format
             e1 = make_uint4((uint32_t)h.h1, (uint32_t)h.h2, (uint32_t)h.ha, (uint32_t)(h.ha >> 32));
-        } else { const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = table[2 * slot + 1]; }
+        } else {
+#if !defined(RBF_INSERT_ABLATE)
+            const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = table[2 * slot + 1];
+#elif RBF_INSERT_ABLATE == 1      // (timing experiments only, wrong results: tools/r04_insert_ablate.sh)  one gather instruction per key
+            const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = make_uint4(e0.y, e0.w, e0.x, e0.z);
+#elif RBF_INSERT_ABLATE == 2      // no gather
+            e0 = make_uint4(idx * 2654435761u, 0x43e00000u | (idx & 0xFFFFu), idx * 40503u, 0x43e00000u | (idx >> 4 & 0xFFFFu)); e1 = make_uint4(e0.x, e0.z, e0.x ^ e0.z, e0.z);
+#elif RBF_INSERT_ABLATE == 4      // index-major entries (64 keys of ~640 consecutive pixels: ~20 KB instead of 1-2 segments of 16 KB, two keys per 64 bytes possible)
+            const uint64_t slot = idx; e0 = table[2 * slot]; e1 = table[2 * slot + 1];
+#elif RBF_INSERT_ABLATE == 7      // 16-byte entries + 8 bytes from a second index-major array
+            const uint64_t slot = idx; e0 = table[slot]; const uint2 x = reinterpret_cast<const uint2 *>(table + (1u << 21))[slot]; e1 = make_uint4(e0.y, e0.w, x.x, x.y);
+#elif RBF_INSERT_ABLATE == 8      // 16-byte entries + 1 byte from a second index-major array
+            const uint64_t slot = idx; e0 = table[slot]; const uint32_t x = reinterpret_cast<const uint8_t *>(table + (1u << 21))[slot]; e1 = make_uint4(e0.y, e0.w, x, x << 24);
+#elif RBF_INSERT_ABLATE == 9      // 16-byte entries, slot-major
+            const uint64_t slot = hash_table_slot(idx); e0 = table[slot]; e1 = make_uint4(e0.y, e0.w, e0.x, e0.z);
+#elif RBF_INSERT_ABLATE == 6      // 16-byte entries, index-major
+            const uint64_t slot = idx; e0 = table[slot]; e1 = make_uint4(e0.y, e0.w, e0.x, e0.z);
+#else
+            const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = table[2 * slot + 1];
+#endif
+        }
         pending = count;
     };
     auto finish = [&]() {
