@@ -46,10 +46,8 @@ __global__ __launch_bounds__(HT_THREADS) void k_hash_table(uint64_t n, Seeds see
             h1[it] = h.h1; h2[it] = h.h2; ha[it] = h.ha;
         }
     }
-    // slot-major inside the segment (hash_table_slot): every store pair of the wave covers 2 KiB contiguously.  Entries past
-    // the end of the frame are written too (the table is padded to whole segments): they are never read.
-#pragma unroll
-    for (int it = 0; it < QL_P; ++it) hash_table_store(table, seg, lane, it, h1[it], h2[it], ha[it]);
+    // entries past the end of the frame are written too (the table is padded to whole segments): they are never read
+    hash_table_store8(table, n, seg, lane, h1, h2, ha);
 }
 
 constexpr int IT_STEP_BYTES = 128;                 // mask bytes per wave step: a lane owns 16 pixels (two bytes)
@@ -95,10 +93,6 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
     const double ninv = __builtin_bit_cast(double, fd.M);
     const uint64_t T = fd.T;
     auto set_bit = [&](uint32_t pos) {
-#if defined(RBF_INSERT_ABLATE) && RBF_INSERT_ABLATE == 3      // no LDS atomics
-        if (pos == 0xFFFFFFFFu) filt[0] = 1;
-        return;
-#endif
         if (WHOLE) { atomicOr(&filt[pos >> 5], msb_bit(pos)); return; }
         const uint32_t rel = pos - tile_bit0;                      // unsigned: out-of-tile positions wrap high
         if (rel < tile_bits) atomicOr(&filt[rel >> 5], msb_bit(pos));
@@ -106,7 +100,11 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
 
     // one batch of <= 64 keys in flight: its table entries are requested (`fetch`) when the batch leaves the queue and
     // consumed (`finish`) when the next batch is ready -- or at the end -- so the gather latency hides under compaction
-    uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+    const HashTable tv(const_cast<uint4 *>(table), n);
+    const uint32_t Ttag = (uint32_t)(T >> 48);
+    uint4 e0 = make_uint4(0, 0, 0, 0);                             // h1, h2 of my key of the batch in flight
+    uint32_t tag = 0, slot_kept = 0;                               // h_act >> 48 | where the full h_act is
+    uint64_t ha_kept = 0;                                          // (HASHED: the full h_act itself)
     uint32_t pending = 0;                                          // keys of the batch in flight (wave-uniform)
     uint32_t cb = 0;                                               // first step of the chunk being walked
     auto fetch = [&](uint32_t first, uint32_t count) {
@@ -114,48 +112,32 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
         const uint32_t idx = ((cb + (e >> 10) * NWAVES) << 10) + (e & 1023u);
         if (HASHED) {
             const Hash3 h = hash3_index(idx, lane < count, seeds);      // wave-uniform call (it votes on the key length)
-            const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h.h1), d2 = __builtin_bit_cast(uint64_t, (double)h.h2);
-            e0 = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));    // the table's entry format
-            e1 = make_uint4((uint32_t)h.h1, (uint32_t)h.h2, (uint32_t)h.ha, (uint32_t)(h.ha >> 32));
+            e0 = make_uint4((uint32_t)h.h1, (uint32_t)(h.h1 >> 32), (uint32_t)h.h2, (uint32_t)(h.h2 >> 32));    // the table's entry format
+            tag = (uint32_t)(h.ha >> 48);
+            ha_kept = h.ha;
         } else {
-#if !defined(RBF_INSERT_ABLATE)
-            const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = table[2 * slot + 1];
-#elif RBF_INSERT_ABLATE == 1      // (timing experiments only, wrong results: tools/r04_insert_ablate.sh)  one gather instruction per key
-            const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = make_uint4(e0.y, e0.w, e0.x, e0.z);
-#elif RBF_INSERT_ABLATE == 2      // no gather
-            e0 = make_uint4(idx * 2654435761u, 0x43e00000u | (idx & 0xFFFFu), idx * 40503u, 0x43e00000u | (idx >> 4 & 0xFFFFu)); e1 = make_uint4(e0.x, e0.z, e0.x ^ e0.z, e0.z);
-#elif RBF_INSERT_ABLATE == 4      // index-major entries (64 keys of ~640 consecutive pixels: ~20 KB instead of 1-2 segments of 16 KB, two keys per 64 bytes possible)
-            const uint64_t slot = idx; e0 = table[2 * slot]; e1 = table[2 * slot + 1];
-#elif RBF_INSERT_ABLATE == 7      // 16-byte entries + 8 bytes from a second index-major array
-            const uint64_t slot = idx; e0 = table[slot]; const uint2 x = reinterpret_cast<const uint2 *>(table + (1u << 21))[slot]; e1 = make_uint4(e0.y, e0.w, x.x, x.y);
-#elif RBF_INSERT_ABLATE == 8      // 16-byte entries + 1 byte from a second index-major array
-            const uint64_t slot = idx; e0 = table[slot]; const uint32_t x = reinterpret_cast<const uint8_t *>(table + (1u << 21))[slot]; e1 = make_uint4(e0.y, e0.w, x, x << 24);
-#elif RBF_INSERT_ABLATE == 9      // 16-byte entries, slot-major
-            const uint64_t slot = hash_table_slot(idx); e0 = table[slot]; e1 = make_uint4(e0.y, e0.w, e0.x, e0.z);
-#elif RBF_INSERT_ABLATE == 6      // 16-byte entries, index-major
-            const uint64_t slot = idx; e0 = table[slot]; e1 = make_uint4(e0.y, e0.w, e0.x, e0.z);
-#else
-            const uint64_t slot = hash_table_slot(idx); e0 = table[2 * slot]; e1 = table[2 * slot + 1];
-#endif
+            slot_kept = hash_table_slot(idx);
+            e0 = tv.pos[slot_kept];
+            tag = tv.tag[idx];
         }
         pending = count;
     };
     auto finish = [&]() {
         if (!pending) return;
         if (lane < pending) {
-            const double hd1 = __builtin_bit_cast(double, ((uint64_t)e0.y << 32) | e0.x), hd2 = __builtin_bit_cast(double, ((uint64_t)e0.w << 32) | e0.z);
-            const uint64_t ha = ((uint64_t)e1.w << 32) | e1.z;
-            uint32_t pos = mod_m_f64(hd1, e1.x, ninv, m);
-            const uint32_t step = mod_m_f64(hd2, e1.y, ninv, m);
+            uint32_t pos = mod_m_f64(rn_double(e0.x, e0.y), e0.x, ninv, m);
+            const uint32_t step = mod_m_f64(rn_double(e0.z, e0.w), e0.z, ninv, m);
+            bool act = tag < Ttag;
+            if (tag == Ttag) act = (HASHED ? ha_kept : tv.act[slot_kept]) < T;      // 2^-16 of the keys
             if (RECORDS) {
-                records[rpos + lane] = make_uint2(pos, step | (ha < T ? 0x80000000u : 0u));
+                records[rpos + lane] = make_uint2(pos, step | (act ? 0x80000000u : 0u));
             } else {
                 for (uint32_t j = 0; j < fk; ++j) {
                     set_bit(pos);
                     const uint32_t s2 = pos + step;
                     pos = min(s2, s2 - m);
                 }
-                if (ha < T) set_bit(pos);
+                if (act) set_bit(pos);
             }
         }
         if (RECORDS) rpos += pending;

@@ -84,21 +84,46 @@ __device__ __forceinline__ uint32_t select_or_ones(uint64_t mask, uint32_t if_se
 }
 
 // ---- the pixel-index hash table ----------------------------------------------------------------------------------
-// 32 bytes per index: RN(h1), RN(h2) as doubles | low dwords of h1, h2 | h_act -- what k_insert_tab gathers from
-// (rbf_kernels_i64.h).  Inside a 512-index segment the entries are stored SLOT-MAJOR -- the entry of index
-// seg * 512 + lane * 8 + it sits at seg * 512 + it * 64 + lane -- because that is the order in which the kernels that produce it
-// (a lane owns 8 consecutive indices) can store it with fully coalesced 2 KiB wave stores.
+// What k_insert_tab gathers instead of hashing (rbf_kernels_i64.h): three arrays over the frame's indices, padded to whole 512-index
+// segments (`hash_table_entries`), 26 bytes per index inside an allocation of 32:
+//     pos[slot]   16 bytes: h1, h2                 -- ONE 16-byte load per key.  Rounds 2 and 3 kept 32-byte entries (RN(h1), RN(h2) as
+//                                                    doubles | low dwords | h_act) and read them with two loads: the texture addresser
+//                                                    walks the 64 scattered lanes of every load instruction, and the second one cost 6 of
+//                                                    the kernel's 36 us (profiles/r04_insert_gather_ablation.txt).  RN(h) is rebuilt from
+//                                                    h with two v_cvt_f64_u32 and one fma (one rounding: the same double).
+//     tag[index]  2 bytes: h_act >> 48             -- "h_act < T" is decided by the tags unless they are equal (2^-16 of the keys) ...
+//     act[slot]   8 bytes: h_act                   -- ... and only then read in full.
+// pos and act are SLOT-MAJOR inside a 512-index segment -- the entry of index seg * 512 + lane * 8 + it sits at seg * 512 + it * 64 +
+// lane -- because that is the order in which the kernels that produce the table (a lane owns 8 consecutive indices) can store it with
+// fully coalesced wave stores; the tags are index-major (a lane stores its eight as one 16-byte piece).
 __device__ __forceinline__ uint32_t hash_table_slot(uint32_t index)
 {
     return (index & ~511u) | ((index & 7u) << 6) | ((index >> 3) & 63u);
 }
-__device__ __forceinline__ void hash_table_store(uint4 *__restrict__ table, uint64_t seg, uint32_t lane, int it, uint64_t h1, uint64_t h2, uint64_t ha)
+__host__ __device__ __forceinline__ uint64_t hash_table_entries(uint64_t n) { return (n + (QL_SEG_PIXELS - 1)) & ~(uint64_t)(QL_SEG_PIXELS - 1); }
+struct HashTable {
+    uint4 *pos; uint64_t *act; uint16_t *tag;
+    __device__ __forceinline__ HashTable(uint4 *table, uint64_t n)
+        : pos(table), act(reinterpret_cast<uint64_t *>(table + hash_table_entries(n))), tag(reinterpret_cast<uint16_t *>(act + hash_table_entries(n))) {}
+};
+// the eight entries of lane `lane` of segment `seg` (indices seg * 512 + lane * 8 + 0..7)
+__device__ __forceinline__ void hash_table_store8(uint4 *__restrict__ table, uint64_t n, uint64_t seg, uint32_t lane, const uint64_t (&h1)[QL_P], const uint64_t (&h2)[QL_P], const uint64_t (&ha)[QL_P])
 {
-    const uint64_t d1 = __builtin_bit_cast(uint64_t, (double)h1), d2 = __builtin_bit_cast(uint64_t, (double)h2);
-    uint4 *e = table + 2 * (seg * QL_SEG_PIXELS + (uint32_t)it * 64u + lane);
-    e[0] = make_uint4((uint32_t)d1, (uint32_t)(d1 >> 32), (uint32_t)d2, (uint32_t)(d2 >> 32));
-    e[1] = make_uint4((uint32_t)h1, (uint32_t)h2, (uint32_t)ha, (uint32_t)(ha >> 32));
+    static_assert(QL_P == 8, "eight 16-bit tags are one 16-byte store");
+    const HashTable t(table, n);
+#pragma unroll
+    for (int it = 0; it < QL_P; ++it) {
+        const uint64_t slot = seg * QL_SEG_PIXELS + (uint32_t)it * 64u + lane;
+        t.pos[slot] = make_uint4((uint32_t)h1[it], (uint32_t)(h1[it] >> 32), (uint32_t)h2[it], (uint32_t)(h2[it] >> 32));
+        t.act[slot] = ha[it];
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = (uint32_t)(ha[2 * k] >> 48) | ((uint32_t)(ha[2 * k + 1] >> 48) << 16);
+    *reinterpret_cast<uint4 *>(t.tag + seg * QL_SEG_PIXELS + lane * QL_P) = make_uint4(w[0], w[1], w[2], w[3]);
 }
+// RN(h) as a double from the two halves of h: both conversions and the product are exact, the sum is rounded once
+__device__ __forceinline__ double rn_double(uint32_t lo, uint32_t hi) { return __builtin_fma((double)hi, 0x1p32, (double)lo); }
 
 // ---- LDS-DMA of an image row -------------------------------------------------------------------------------------
 // `words` dwords of `row` -> LDS at lds_byte_addr, 1 KiB (one 16-byte piece per lane) per wave and step, the row pointer in an SGPR

@@ -173,10 +173,7 @@ __device__ __forceinline__ void query_u64_body(
             hd1[it] = (double)h1[it]; hl1[it] = (uint32_t)h1[it];
             hd2[it] = (double)h2[it]; hl2[it] = (uint32_t)h2[it];
         }
-        if (table_out && live) {
-#pragma unroll
-            for (int it = 0; it < QL_P; ++it) hash_table_store(table_out, seg, lane, it, h1[it], h2[it], ha[it]);
-        }
+        if (table_out && live) hash_table_store8(table_out, n, seg, lane, h1, h2, ha);
         if (threadIdx.x < 2u * MAX_BATCH) {
             const uint32_t t = threadIdx.x;
             tl[t] = t < nactive ? fd_mine.T : ~0ull;
