@@ -939,8 +939,11 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         uint32_t nactive; uint64_t empty[2];
         const FrameTable stab = query_table_s64(tab, nframes, &nactive, empty);
         if (quiet_passthrough) empty[0] = empty[1] = 0;
-        if (int r = allow_big_lds((const void *)k_query_s64t)) return r;
-        hipLaunchKernelGGL(k_query_s64t, dim3((uint32_t)bx), dim3(QL_THREADS), s64t_lds_bytes(pl.query_tile_words), ctx->stream,
+        bool general = false;                                       // a coded frame whose floor(k*) is not 1 or 2: the kernel with every case compiled in
+        for (uint32_t f = 0; f < nframes; ++f) general = general || (tab.f[f].m && (tab.f[f].floor_k < 1 || tab.f[f].floor_k > 2));
+        auto qkern = general ? k_query_s64t<true> : k_query_s64t<false>;
+        if (int r = allow_big_lds((const void *)qkern)) return r;
+        hipLaunchKernelGGL(qkern, dim3((uint32_t)bx), dim3(QL_THREADS), s64t_lds_bytes(pl.query_tile_words), ctx->stream,
                            n, nactive, stab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
                            ctx->seg_cnt, pl.nseg, ctx->pass_words, empty[0], empty[1]);
     } else if (pl.query_kind == 1 && pl.f64_mod) {

@@ -340,6 +340,12 @@ __device__ __forceinline__ uint32_t tiled_frame(const double (&hd1)[QL_P], const
 }
 
 // (120 registers: one wave of the mask / compaction kernels per SIMD runs underneath it, as under k_query_u64)
+// GENERAL = false: every coded frame of the launch has floor(k*) 1 or 2 (the host checks) -- the kernel of BASELINE config 4 and of
+// every other batch at k* ~ 2.3.  GENERAL = true: any floor(k*) (0..S64T_MAX_FK with their own instantiation of the frame, above that
+// the positions are walked per tile).  Two kernels because the register allocator sizes a kernel for its hungriest path: with the
+// cases for 0, 3, 4 probes and the walk compiled in, the floor(k*) = 2 frames spilled (146 bytes of scratch, 111 MB of scratch writes
+// per 2160p launch, 227 -> 342 us: profiles/r04_config4_2160p_lds_tile_sweep.txt of the first collection against r03's).
+template <bool GENERAL>
 __attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) void k_query_s64t(
     uint64_t n, uint32_t nactive, const FrameTable tab /* host: query_table_s64 */, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t tile_words /* multiple of 4 */,
@@ -447,13 +453,17 @@ __attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) vo
         // meet in phi nodes between them and the register allocator spills the hashes.
         uint32_t pbf;
 #define RBF_S64T_FRAME(FKV) tiled_frame<FKV>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, fk, row, fwords, tile_words, lds_base, fbase, wave, lane, flush)
-        switch (fk) {
-        case 0: pbf = RBF_S64T_FRAME(0); break;
-        case 1: pbf = RBF_S64T_FRAME(1); break;
-        case 2: pbf = RBF_S64T_FRAME(2); break;
-        case 3: pbf = RBF_S64T_FRAME(3); break;
-        case 4: pbf = RBF_S64T_FRAME(4); break;
-        default: pbf = RBF_S64T_FRAME(-1); break;
+        if constexpr (GENERAL) {
+            switch (fk) {
+            case 0: pbf = RBF_S64T_FRAME(0); break;
+            case 1: pbf = RBF_S64T_FRAME(1); break;
+            case 2: pbf = RBF_S64T_FRAME(2); break;
+            case 3: pbf = RBF_S64T_FRAME(3); break;
+            case 4: pbf = RBF_S64T_FRAME(4); break;
+            default: pbf = RBF_S64T_FRAME(-1); break;
+            }
+        } else {
+            if (fk == 1) pbf = RBF_S64T_FRAME(1); else pbf = RBF_S64T_FRAME(2);
         }
 #undef RBF_S64T_FRAME
         out_pb = ~(pbf | invalid_byte) & 0xFFu; out_f = f; out_pending = true;

@@ -78,36 +78,49 @@ __host__ inline FrameTable query_table_u64(const FrameTable &tab, uint32_t nfram
 template <bool ON>
 struct RowDmaC {
     const uint8_t *image;           // the batch's probe images (the kernel argument: saddr addressing)
-    uint32_t src;                   // byte offset of the row to stage + wave * 1024 + lane * 16 (the image block is < 4 GB)
-    uint32_t dst_m0;                // LDS byte address of the destination buffer + wave * 1024 (uniform: SGPR)
+    uint32_t src;                   // byte offset of the row to stage + wave * 5120 + lane * 16 + 2048 (the image block is < 4 GB)
+    uint32_t dst_m0;                // LDS byte address of the destination buffer + wave * 5120 + 2048 (uniform: SGPR)
     uint64_t mask[5];               // lanes of piece i inside the row (uniform)
+    bool full;                      // all five pieces of this wave lie inside the row (uniform): no exec masks
 
+    // A wave stages FIVE CONSECUTIVE KiB of the row.  The instruction's immediate offset moves the global AND the LDS address, so the
+    // five pieces are one M0 value and the offsets -2048 ... +2048 (13 signed bits): 3 scalar instructions per frame and wave.  (Until
+    // round 4 a wave's pieces lay 16 KiB apart -- piece = wave + 16 i -- which cost an s_add of M0, an exec mask and a v_add of the
+    // source per piece: 14 SALU + 4 VALU per frame and wave in a loop that is bound by instruction issue.)
     __device__ __forceinline__ void issue() const
     {
         uint32_t keep; uint64_t keepx;
-        const uint32_t v1 = src + 1u * (QL_WAVES * 1024u), v2 = src + 2u * (QL_WAVES * 1024u), v3 = src + 3u * (QL_WAVES * 1024u), v4 = src + 4u * (QL_WAVES * 1024u);
+        if (full) {
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %1\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %2, %3 offset:-2048\n\t"
+                         "global_load_lds_dwordx4 %2, %3 offset:-1024\n\t"
+                         "global_load_lds_dwordx4 %2, %3\n\t"
+                         "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %2, %3 offset:2048\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst_m0), "v"(src), "s"(image) : "memory");
+            return;
+        }
         asm volatile("s_mov_b32 %0, m0\n\t"
                      "s_mov_b64 %1, exec\n\t"
                      "s_mov_b32 m0, %2\n\t"
+                     "s_mov_b64 exec, %5\n\t"
+                     "global_load_lds_dwordx4 %3, %4 offset:-2048\n\t"
+                     "s_mov_b64 exec, %6\n\t"
+                     "global_load_lds_dwordx4 %3, %4 offset:-1024\n\t"
+                     "s_mov_b64 exec, %7\n\t"
+                     "global_load_lds_dwordx4 %3, %4\n\t"
+                     "s_mov_b64 exec, %8\n\t"
+                     "global_load_lds_dwordx4 %3, %4 offset:1024\n\t"
                      "s_mov_b64 exec, %9\n\t"
-                     "global_load_lds_dwordx4 %3, %8\n\t"
-                     "s_add_u32 m0, m0, 0x4000\n\t"
-                     "s_mov_b64 exec, %10\n\t"
-                     "global_load_lds_dwordx4 %4, %8\n\t"
-                     "s_add_u32 m0, m0, 0x4000\n\t"
-                     "s_mov_b64 exec, %11\n\t"
-                     "global_load_lds_dwordx4 %5, %8\n\t"
-                     "s_add_u32 m0, m0, 0x4000\n\t"
-                     "s_mov_b64 exec, %12\n\t"
-                     "global_load_lds_dwordx4 %6, %8\n\t"
-                     "s_add_u32 m0, m0, 0x4000\n\t"
-                     "s_mov_b64 exec, %13\n\t"
-                     "global_load_lds_dwordx4 %7, %8\n\t"
+                     "global_load_lds_dwordx4 %3, %4 offset:2048\n\t"
                      "s_mov_b64 exec, %1\n\t"
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep), "=&s"(keepx)
-                     : "s"(dst_m0), "v"(src), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "s"(image), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]), "s"(mask[3]), "s"(mask[4])
-                     : "memory", "scc");
+                     : "s"(dst_m0), "v"(src), "s"(image), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]), "s"(mask[3]), "s"(mask[4])
+                     : "memory");
     }
     __device__ __forceinline__ void at(int g)
     {
@@ -225,17 +238,19 @@ __device__ __forceinline__ void query_u64_body(
 
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     const uint32_t pitch_bytes = (uint32_t)image_stride_words32 * 4u;
-    const uint32_t off0 = wave * 1024u + lane * 16u;
+    const uint32_t off0 = wave * 5120u + lane * 16u;             // a wave stages five consecutive KiB (RowDmaC)
     RowDmaC<!(AB & 8)> dm;
     dm.image = reinterpret_cast<const uint8_t *>(image);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) dm.mask[i] = __ballot(off0 + (uint32_t)i * (QL_WAVES * 1024u) + 16u <= pitch_bytes);
+    for (int i = 0; i < 5; ++i) dm.mask[i] = __ballot(off0 + (uint32_t)i * 1024u + 16u <= pitch_bytes);
+    dm.full = dm.mask[4] == ~0ull;
+    const uint32_t off0b = off0 + 2048u, wave_dst = wave * 5120u + 2048u;
     const uint32_t buf_sum = lds0 + lds0 + bufwords * 4u;        // buffer 0 + buffer 1: the other buffer of b is buf_sum - b
     uint32_t fbase = vgpr_copy(lds0);                             // the buffer the pass probes (the stager fills the other one)
     {   // the first frame's image into buffer 0 (its row is in the record behind the last one); waited for at the head of the first frame
         const uint32_t *w = reinterpret_cast<const uint32_t *>(geo);
-        dm.src = w[8u * nactive + 4u] + off0;
-        dm.dst_m0 = lds0 + wave * 1024u;
+        dm.src = w[8u * nactive + 4u] + off0 + 2048u;
+        dm.dst_m0 = lds0 + wave * 5120u + 2048u;
         dm.at(0);
     }
     const uint32_t safe_v = vgpr_copy(safe_pos);
@@ -276,8 +291,8 @@ __device__ __forceinline__ void query_u64_body(
             uint32_t x[4] = {0, 0, 0, 0};
             const bool rows = FK > 0 && whole_wave;
             if (rows) rows_reduce4(0, hd1, hl1, hd2, hl2, m_v, ninv, x);          // needs no image: in front of the barrier
-            dm.src = gb.x + off0;                                                      // (a uniform value used from the VGPR the read returned)
-            dm.dst_m0 = (uint32_t)__builtin_amdgcn_readfirstlane(buf_sum - fbase) + wave * 1024u;
+            dm.src = gb.x + off0b;                                                     // (a uniform value used from the VGPR the read returned)
+            dm.dst_m0 = (uint32_t)__builtin_amdgcn_readfirstlane(buf_sum - fbase) + wave_dst;
             if (!(AB & 8)) dma_wait_all();        // my pieces of THIS frame's image (issued during the previous pass, or by the prologue) have landed
             out_row = (uint32_t)__builtin_amdgcn_readfirstlane(gb.w);                 // output row of the PREVIOUS frame (shifted by the prologue)
             if (!(AB & 32)) __syncthreads();      // everyone's writes of the buffer I probe have landed; nobody probes the other one any more
