@@ -500,7 +500,7 @@ def main():
 
 def decode_leg(torch, nat, coders, host_gops, n, pairs, G_res, reps=40):
     """A6 (improved_video_compressor.py:268-307) over the step's own records: every pipeline decodes the (filter, witness, k, l) rows its
-    last encode left in HBM back into masks -- query + segment scan + expansion, rbf_bloom_decode_batch -- `reps` times on its own
+    last encode left in HBM back into masks -- query + expansion, rbf_bloom_decode_batch -- `reps` times on its own
     stream; the decoded masks are compared with the masks the encoder saw AND with the CPU oracle's masks of the host frames."""
     import ctypes
     from oracle import oracle as orc
@@ -547,7 +547,7 @@ def decode_leg(torch, nat, coders, host_gops, n, pairs, G_res, reps=40):
                 raise SystemExit("decode leg: pipeline %d frame %d differs from the CPU oracle's mask" % (k, f))
             frames += 1
     return {"value": round(pairs * n / dt / 1e6, 1), "unit": "Mpixel/s", "ms_per_gop": round(dt * 1e3, 4), "pipelines": len(coders), "gops_timed": reps * len(coders),
-            "kernels_ms_per_gop_alone": alone, "what": "rbf_bloom_decode_batch over the 29 records of a headline step (query + scan + expand), records resident in HBM",
+            "kernels_ms_per_gop_alone": alone, "what": "rbf_bloom_decode_batch over the 29 records of a headline step (query + expand: two launches), records resident in HBM",
             "verified_vs_oracle": {"frames": frames, "fields": "decoded mask == encoder's mask == oracle's mask"}}
 
 

@@ -1523,11 +1523,11 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
     const uint32_t wps = pl.words_per_seg;                                            // pass words per segment
     FrameTable tab;
     if (int r = fill_table(params, nframes, &tab)) return r;
-    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4)) return r;
-    if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
+    if (WG_THREADS % wps) return fail(RBF_EINVAL, "segments of %u words do not tile a workgroup's chunk", wps);
+    if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4 + 16)) return r;      // + 16: the counts are read four to a load
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * wps * 8)) return r;
     const Seeds sd{seeds->h1, seeds->h2, seeds->act};
-    // mixed batch (see encode_chunk): the query runs twice over disjoint frame sets, the scan and the expansion once
+    // mixed batch (see encode_chunk): the query runs twice over disjoint frame sets, the expansion once
     bool split = false;
     {
         uint32_t in_range = 0, out_of_range = 0;
@@ -1553,16 +1553,11 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
         }
     }
     if (!split) if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, false)) return r;
-    {
-        LaunchTimer t(ctx, RBF_K_SCAN);
-        hipLaunchKernelGGL(k_scan_segments, dim3(nframes), dim3(1024), 0, ctx->stream, ctx->seg_cnt, ctx->seg_off, pl.nseg,
-                           (uint64_t *)nullptr, 0u);
-    }
-    {
-        const uint64_t bx = ((n + 63) / 64 + WG_THREADS - 1) / WG_THREADS;       // one lane per 64-position word
+    {   // one lane per 64-position word; the kernel sums the earlier segment counts itself (until round 4: k_scan_segments + k_expand_mask_p)
+        const uint64_t bx = (pl.nseg * wps + WG_THREADS - 1) / WG_THREADS;
         LaunchTimer t(ctx, RBF_K_EXPAND);
-        hipLaunchKernelGGL(k_expand_mask_p, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
-                           ctx->pass_words, ctx->seg_off, pl.nseg, wps, (const uint32_t *)witnesses_dev, witness_stride_bytes / 4,
+        hipLaunchKernelGGL(k_expand_mask, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           ctx->pass_words, ctx->seg_cnt, pl.nseg, wps, (const uint32_t *)witnesses_dev, witness_stride_bytes / 4,
                            (uint64_t *)masks_dev, mask_stride_bytes / 8, n);
     }
     HIP_TRY(hipGetLastError());

@@ -548,38 +548,11 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_tiled(
 // ------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) SegCounts4 { uint32_t x, y, z, w; };      // four segment counts: rows of seg_cnt are only dword-aligned
 
-__global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
-    const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
-    const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n,
-    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32, uint64_t *__restrict__ stats)
+// This thread's share of cnt[0] + ... + cnt[seg0 - 1] (sum the shares over the workgroup): four counts per load, four loads in flight
+// per thread.  (A thread of the last workgroup of a 1080p frame used to issue sixteen single-count loads behind 64-bit index
+// arithmetic: a third of k_compact_witness's instructions.)  The loads may run up to 12 bytes past seg0: the allocation is padded.
+__device__ __forceinline__ uint32_t counts_before_share(const uint32_t *__restrict__ cnt, uint32_t seg0)
 {
-    // A workgroup owns WG_THREADS consecutive words (= whole segments).  Their witness bits form one contiguous bit range starting at
-    // (passes of all earlier segments): the range is assembled in LDS with LDS atomics and written with plain coalesced stores; only
-    // its first and last dword are shared with the neighbouring workgroups (atomicOr).  No separate scan kernel: the start is a block
-    // reduction over the earlier segment counts, the offsets inside the chunk a block scan.
-    //
-    // The step is bound by instruction issue (DESIGN.md 5), so this kernel is written for a short instruction stream (round 3: ~415
-    // VALU wave-instructions per 64 words, now ~250): the earlier counts are read four to a load, all loads of a thread are in flight
-    // before the first wait, both block-wide sums cross ONE barrier, the wave scans are DPP adds, and the two halves of the software
-    // pext run in one loop of two independent chains.
-    __shared__ uint32_t buf[WG_THREADS * 2 + 2];
-    __shared__ uint32_t red[WG_WAVES], wsum[WG_WAVES];
-    const uint32_t f = blockIdx.y;
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t nwords = (uint32_t)((n + 63) >> 6);                        // n < 2^32 (rbf_plan_batch)
-    const uint32_t total = (uint32_t)nseg * words_per_seg;
-    const uint64_t *pwf = pass_words + (uint64_t)f * total;
-    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
-    uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
-    const uint32_t wbeg = blockIdx.x * WG_THREADS;
-    const uint32_t w = wbeg + threadIdx.x;
-    // my word (packed -> bit b = position 64w + b) and its mask word: requested before anything waits
-    const bool have = w < total && w < nwords;
-    const uint64_t pw_raw = have ? pwf[w] : 0ull;
-    const uint64_t mk_raw = have ? masks[(uint64_t)f * mask_stride_words64 + w] : 0ull;
-    // passes of the earlier segments: four counts per load, four loads in flight per thread (a thread of the last workgroup of a
-    // 1080p frame used to issue sixteen single-count loads behind 64-bit index arithmetic: a third of this kernel's instructions)
-    const uint32_t seg0 = wbeg / words_per_seg;
     uint32_t part = 0;
     if ((seg0 & 3u) == 0) {                                                   // (workgroup-uniform) whole quads only: segments of <= 64 words
         for (uint32_t q0 = threadIdx.x; 4u * q0 < seg0; q0 += WG_THREADS * 4) {
@@ -600,6 +573,89 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     } else {
         for (uint32_t s0 = threadIdx.x; s0 < seg0; s0 += WG_THREADS) part += cnt[s0];
     }
+    return part;
+}
+
+// Software pext / pdep through a 256-byte LDS table of their 4-bit forms, entry [p4 << 4 | x4] (thread t of a 256-thread workgroup
+// writes entry t): pext4 = the bits of x4 at the set positions of p4, packed low; pdep4 = the low popc(p4) bits of x4 dealt out to the
+// set positions of p4.  A 64-bit word is sixteen independent look-ups -- a lane reads one byte, lanes reading the same dword are served
+// by one broadcast and the table covers each of the 64 banks once, so there are no bank conflicts -- against a loop that ran as long as
+// the busiest lane of the wave (~9 rounds of 19 instructions for the compaction, ~22 of 14 for the expansion).
+static_assert(WG_THREADS == 256, "one table entry per thread");
+__device__ __forceinline__ uint32_t pext4_entry(uint32_t t)
+{
+    const uint32_t p4 = t >> 4, x4 = t & 15u;
+    uint32_t r = 0, k = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b)
+        if ((p4 >> b) & 1u) { r |= ((x4 >> b) & 1u) << k; ++k; }
+    return r;
+}
+__device__ __forceinline__ uint32_t pdep4_entry(uint32_t t)
+{
+    const uint32_t p4 = t >> 4, x4 = t & 15u;
+    uint32_t r = 0, k = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b)
+        if ((p4 >> b) & 1u) { r |= ((x4 >> k) & 1u) << b; ++k; }
+    return r;
+}
+// pext(x, p) of a 32-bit half: <= popc(p) <= 32 bits, LSB = the first set position of p
+__device__ __forceinline__ uint32_t pext32_lut(const uint8_t *lut, uint32_t x, uint32_t p)
+{
+    uint32_t out = 0, off = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t p4 = __builtin_amdgcn_ubfe(p, 4u * j, 4u), x4 = __builtin_amdgcn_ubfe(x, 4u * j, 4u);
+        out |= (uint32_t)lut[(p4 << 4) | x4] << (off & 31u);       // (off + popc(p4) <= 32, the entry has popc(p4) bits; off = 32 only with nothing left)
+        off += __popc(p4);
+    }
+    return out;
+}
+// pdep(w, p) of a 32-bit half: the low popc(p) bits of w (stream order, LSB first) dealt out to the set positions of p
+__device__ __forceinline__ uint32_t pdep32_lut(const uint8_t *lut, uint32_t w, uint32_t p)
+{
+    uint32_t out = 0, off = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t p4 = __builtin_amdgcn_ubfe(p, 4u * j, 4u), w4 = __builtin_amdgcn_ubfe(w, off, 4u);     // (off = 32 only when nothing is left to deal out)
+        out |= (uint32_t)lut[(p4 << 4) | w4] << (4u * j);
+        off += __popc(p4);
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
+    const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
+    const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n,
+    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32, uint64_t *__restrict__ stats)
+{
+    // A workgroup owns WG_THREADS consecutive words (= whole segments).  Their witness bits form one contiguous bit range starting at
+    // (passes of all earlier segments): the range is assembled in LDS with LDS atomics and written with plain coalesced stores; only
+    // its first and last dword are shared with the neighbouring workgroups (atomicOr).  No separate scan kernel: the start is a block
+    // reduction over the earlier segment counts, the offsets inside the chunk a block scan.
+    //
+    // The step is bound by instruction issue (DESIGN.md 5), so this kernel is written for a short instruction stream (round 3: ~415
+    // VALU wave-instructions per 64 words, now ~230): the earlier counts are read four to a load, all loads of a thread are in flight
+    // before the first wait, both block-wide sums cross ONE barrier, the wave scans are DPP adds, and the pext is sixteen look-ups.
+    __shared__ uint32_t buf[WG_THREADS * 2 + 2];
+    __shared__ uint32_t red[WG_WAVES], wsum[WG_WAVES];
+    __shared__ __attribute__((aligned(4))) uint8_t lut[256];
+    const uint32_t f = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwords = (uint32_t)((n + 63) >> 6);                        // n < 2^32 (rbf_plan_batch)
+    const uint32_t total = (uint32_t)nseg * words_per_seg;
+    const uint64_t *pwf = pass_words + (uint64_t)f * total;
+    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
+    uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
+    const uint32_t wbeg = blockIdx.x * WG_THREADS;
+    const uint32_t w = wbeg + threadIdx.x;
+    // my word (packed -> bit b = position 64w + b) and its mask word: requested before anything waits
+    const bool have = w < total && w < nwords;
+    const uint64_t pw_raw = have ? pwf[w] : 0ull;
+    const uint64_t mk_raw = have ? masks[(uint64_t)f * mask_stride_words64 + w] : 0ull;
+    const uint32_t part = counts_before_share(cnt, wbeg / words_per_seg);
+    lut[threadIdx.x] = (uint8_t)pext4_entry(threadIdx.x);
     buf[threadIdx.x] = 0;
     buf[threadIdx.x + WG_THREADS] = 0;
     if (threadIdx.x < 2) buf[threadIdx.x + 2 * WG_THREADS] = 0;
@@ -619,20 +675,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     }
     const uint32_t obase = start32 & ~31u;                                    // dword-aligned start of my LDS image
     const uint32_t o = start32 + before + incl - c;
-    // pext(mask, pw), LSB = first passing position, as two 32-bit halves in one loop: a pass at bit b of a half lands at
-    // popc(the half's passes below b) -- v_ffbl, v_bfe (the passes below b), v_bcnt, v_lshl_or -- and the high half's result is then
-    // shifted up by the low half's pass count.  The wave runs as long as its busiest lane's busier half (~9 rounds at k* = 2.3).
-    const uint64_t tp = pw & flip_bytes64(mk_raw);                            // passes whose mask bit is 1
-    uint32_t t_lo = (uint32_t)tp, t_hi = (uint32_t)(tp >> 32), o_lo = 0, o_hi = 0;
-    auto ffbl = [](uint32_t x) { uint32_t b; asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"(x)); return b; };          // -1 for 0 (the builtin is undefined there)
-    auto one_if = [](uint32_t x) { uint32_t r; asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(x)); return r; };      // (the compiler's choice: a borrow + v_cndmask through VCC)
-    while (t_lo | t_hi) {
-        const uint32_t r_lo = __popc(__builtin_amdgcn_ubfe(pw_lo, 0u, ffbl(t_lo))), r_hi = __popc(__builtin_amdgcn_ubfe(pw_hi, 0u, ffbl(t_hi)));
-        o_lo |= one_if(t_lo) << r_lo;                                         // an exhausted half adds nothing (its v_bfe takes 31 bits: harmless)
-        o_hi |= one_if(t_hi) << r_hi;
-        t_lo &= t_lo - 1u;
-        t_hi &= t_hi - 1u;
-    }
+    // pext(mask, pw), LSB = first passing position, as two 32-bit halves; the high half's result is shifted up by the low half's pass count
+    const uint64_t mk = flip_bytes64(mk_raw);
+    const uint32_t o_lo = pext32_lut(lut, (uint32_t)mk, pw_lo), o_hi = pext32_lut(lut, (uint32_t)(mk >> 32), pw_hi);
     const uint64_t out = (uint64_t)o_lo | ((uint64_t)o_hi << c_lo);
     if (out) {
         const uint32_t rel = o - obase;
@@ -657,42 +702,54 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     if (threadIdx.x == 0 && wbeg + WG_THREADS >= total) stats[(uint64_t)f * 4 + 0] = oend;   // len(witness)
 }
 
-// A6 expand: out[i] = witness[rank(i)] where position i passes, else 0 (:299-304).  One lane per 64-position
-// word: its witness bits are the `popc(pass)` stream bits starting at seg_off + (passes of the segment's earlier
-// words); they are fetched as one left-aligned 64-bit window and dealt out to the set bits of the pass word
-// from the lowest position up (a software pdep; ~18 iterations at k* = 2.3).  Reads never leave the row.
-__global__ __launch_bounds__(WG_THREADS) void k_expand_mask_p(
-    const uint64_t *__restrict__ pass_words, const uint64_t *__restrict__ seg_off, uint64_t nseg, uint32_t words_per_seg,
+// A6 expand: out[i] = witness[rank(i)] where position i passes, else 0 (:299-304).  One lane per 64-position word, a workgroup per
+// WG_THREADS consecutive words (= whole segments), offsets as in k_compact_witness: the start is a block reduction over the earlier
+// segment counts, the offsets inside the chunk a block scan (until round 4 a separate scan kernel wrote segment offsets and every lane
+// summed the pass words in front of it in its segment with up to seven dependent loads).  The lane's popc(pass) stream bits are fetched
+// as one 64-bit window and dealt out to the set bits of the pass word through the pdep table.  Reads never leave the row.
+__global__ __launch_bounds__(WG_THREADS) void k_expand_mask(
+    const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
     const uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32,
     uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n)
 {
+    __shared__ uint32_t red[WG_WAVES], wsum[WG_WAVES];
+    __shared__ __attribute__((aligned(4))) uint8_t lut[256];
     const uint32_t f = blockIdx.y;
-    const uint64_t nwords = (n + 63) >> 6;
-    const uint64_t w = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x;      // words of consecutive segments are consecutive
-    if (w >= nwords) return;
-    const uint64_t seg = w / words_per_seg;
-    const uint64_t *pwf = pass_words + (uint64_t)f * nseg * words_per_seg;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwords = (uint32_t)((n + 63) >> 6);
+    const uint32_t total = (uint32_t)nseg * words_per_seg;
+    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
     const uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
-    uint64_t o = seg_off[(uint64_t)f * nseg + seg];
-    for (uint64_t j = seg * words_per_seg; j < w; ++j) o += __popcll(pwf[j]);
-    uint64_t p = flip_bytes64(pwf[w]);                           // packed -> bit b = position 64w + b
+    const uint32_t wbeg = blockIdx.x * WG_THREADS;
+    const uint32_t w = wbeg + threadIdx.x;
+    const bool have = w < total && w < nwords;
+    const uint64_t pw_raw = have ? pass_words[(uint64_t)f * total + w] : 0ull;
+    const uint32_t part = counts_before_share(cnt, wbeg / words_per_seg);
+    lut[threadIdx.x] = (uint8_t)pdep4_entry(threadIdx.x);
+    const uint64_t p = flip_bytes64(pw_raw);                      // packed -> bit b = position 64w + b
+    const uint32_t p_lo = (uint32_t)p, p_hi = (uint32_t)(p >> 32);
+    const uint32_t c_lo = __popc(p_lo), c = c_lo + __popc(p_hi);
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t psum = wave_sum_to_lane63(part);
+    if (lane == WAVE - 1) { wsum[wave] = incl; red[wave] = psum; }
+    __syncthreads();
+    uint32_t o = incl - c;
+#pragma unroll
+    for (int k = 0; k < WG_WAVES; ++k) {
+        o += red[k];
+        if ((uint32_t)k < wave) o += wsum[k];
+    }
+    if (w >= nwords) return;
     uint64_t out = 0;
-    if (p) {
-        const uint32_t c = __popcll(p);
-        const uint64_t d0 = o >> 5, dl = (o + c - 1) >> 5;
-        // bswap turns a packed (MSB-first per byte) dword into "stream bit b at bit 31 - b"
-        const uint64_t x0 = d0 < witness_stride_words32 ? flip_order32(wit[d0]) : 0u;
-        const uint64_t x1 = (d0 + 1 <= dl && d0 + 1 < witness_stride_words32) ? flip_order32(wit[d0 + 1]) : 0u;
-        const uint64_t x2 = (d0 + 2 <= dl && d0 + 2 < witness_stride_words32) ? flip_order32(wit[d0 + 2]) : 0u;
-        const uint32_t r = (uint32_t)o & 31u;
-        uint64_t win = ((x0 << 32) | x1) << r;                    // stream bit o + t at bit 63 - t
-        win |= r ? x2 >> (32 - r) : 0ull;
-        while (p) {
-            const uint64_t lsb = p & (0 - p);
-            out |= (int64_t)win < 0 ? lsb : 0ull;
-            win <<= 1;
-            p ^= lsb;
-        }
+    if (c) {
+        // stream bits o ... o + c - 1 as a window with bit t = stream bit o + t (flip_bytes32: packed dword -> stream bit b at bit b)
+        const uint32_t d0 = o >> 5, dl = (o + c - 1u) >> 5, r = o & 31u;
+        const uint64_t x0 = d0 < witness_stride_words32 ? flip_bytes32(wit[d0]) : 0u;
+        const uint64_t x1 = (d0 + 1 <= dl && d0 + 1 < witness_stride_words32) ? flip_bytes32(wit[d0 + 1]) : 0u;
+        const uint64_t x2 = (d0 + 2 <= dl && d0 + 2 < witness_stride_words32) ? flip_bytes32(wit[d0 + 2]) : 0u;
+        uint64_t win = (x0 | (x1 << 32)) >> r;
+        win |= r ? x2 << (64u - r) : 0ull;
+        out = (uint64_t)pdep32_lut(lut, (uint32_t)win, p_lo) | ((uint64_t)pdep32_lut(lut, (uint32_t)(win >> c_lo), p_hi) << 32);
     }
     masks[(uint64_t)f * mask_stride_words64 + w] = flip_bytes64(out);
 }
