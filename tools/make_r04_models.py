@@ -109,9 +109,14 @@ def price(blocks, cost):
         if len(key) >= 2 and key in seen:
             continue
         seen.add(key)
+        # the image's LDS-DMA is compiled twice (RowDmaC::issue): five loads under one M0 for a wave whose five KiB lie inside the row,
+        # five loads with an exec mask each for the one wave that holds the row's end -- the second form is not what 15 of 16 waves run
+        ragged_dma = b.count("global_load_lds_dwordx4") >= 5 and b.count("s_mov_b64 exec") >= 5
         w = 0.5 if ("_dpp" in b or "s_and_saveexec_b64" in b or "global_store_dword " in b) else 1.0      # the packed pass counts are reduced and stored every second frame
         for ln in b.split("\n"):
             t = ln.strip()
+            if ragged_dma and re.match(r"^(global_load_lds_dwordx4|s_mov_b64 exec|s_mov_b64 s\[\d+:\d+\], exec|s_mov_b32 m0|s_mov_b32 s\d+, m0)", t):
+                continue
             m = re.match(r"^((?:v|s|ds|global|buffer)_[a-z0-9_]+)\s*(.*)$", t)
             if not m:
                 continue
