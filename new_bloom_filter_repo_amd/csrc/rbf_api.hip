@@ -561,7 +561,7 @@ struct Plan {
     uint32_t image_stride_words;  // row pitch of the probe image (dwords, multiple of 4)
 };
 
-constexpr size_t HASH_TABLE_CACHE_BYTES = (size_t)96 << 20;    // k_insert_positions: a pixel-index table larger than this is not worth gathering from (1440p, 118 MB: step 454 -> 425 us hashed; 2160p, 265 MB: insert 124 -> 97)
+constexpr size_t HASH_TABLE_CACHE_BYTES = (size_t)96 << 20;    // k_insert_positions: a pixel-index table larger than this is not worth gathering from (1440p, 118 MB: step 454 -> 425 us hashed; 2160p, 265 MB: insert 124 -> 97; re-measured with the 26-byte table of round 4: 1440p equal, 2160p 207 -> 192 Gpixel/s gathered, profiles/r04_bigtable.txt)
 constexpr uint32_t MAX_INSERT_TILES = 7, MAX_QUERY_TILES = 3;     // measured crossovers, see make_plan
 
 static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n, bool have_ones = false)
