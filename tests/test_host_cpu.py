@@ -294,3 +294,9 @@ def test_activation_rank_is_equivalent_to_the_threshold_compare():
             assert rank <= 128
             for f in range(nfr):
                 assert (h < ts[f]) == (rank <= c[f]), (h, ts[f], rank, c[f])
+
+
+def test_graft_entry_build_check_follows_the_header():
+    """__graft_entry__.build() compares the library's ABI version with include/rbf.h (round 4: a literal 2 survived the bump to 3)."""
+    src = open(os.path.join(REPO, "__graft_entry__.py"), encoding="utf-8").read()
+    assert "RBF_ABI_VERSION" in src and "rbf_version() ==" not in src
