@@ -968,7 +968,7 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         // the 111-register kernel (two waves of a neighbour pipeline's mask / compaction kernels fit next to it on every SIMD) unless the
         // batch has floor(k*) = 4 or 5, which only the 118-register one passes in rows
         const bool wide = cls.n[3] + cls.n[4] > 0;                 // (always the wide one: measured, no better -- profiles/r04_feed_sweep2.txt)
-        auto kern64 = wide ? k_query_u64w<0> : k_query_u64<0>;
+        auto kern64 = wide ? k_query_u64w : k_query_u64;
         if (int r = allow_big_lds((const void *)kern64)) return r;
         hipLaunchKernelGGL(kern64, dim3((uint32_t)bx), dim3(QL_THREADS), pl.query_lds_bytes + u64_geo_bytes(nactive), ctx->stream,
                            n, nactive, utab, cls, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.fwords_max,

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstring>
 #include "../new_bloom_filter_repo_amd/csrc/rbf_kernels_u64.h"
+#include "legacy/rbf_kernels_u64_ab.h"                           // k_query_u64 / u64w with their measurement variants (namespace rbf::ab); AB = 0 runs the LIBRARY's kernels
 #include "legacy/rbf_kernels_s64.h"                              // round 3's k_query_s64 / s64w (namespace rbf::legacy): the reference of the comparison
 using namespace rbf;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -44,13 +45,17 @@ static float run(uint64_t n, uint32_t F, const FrameTable &tab, Seeds sd, uint64
     auto launch = [&]() {
         if constexpr (K == S64) legacy::k_query_s64<AB><<<bx, QL_THREADS, lds, 0>>>(n, nactive, qt, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, nullptr, empty[0], empty[1]);
         else if constexpr (K == S64W) legacy::k_query_s64w<AB><<<bx, QL_THREADS, lds, 0>>>(n, nactive, qt, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, nullptr, empty[0], empty[1]);
-        else if constexpr (K == U64) k_query_u64<AB><<<bx, QL_THREADS, lds, 0>>>(n, nactive, qt, cls, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, nullptr, empty[0], empty[1]);
-        else k_query_u64w<AB><<<bx, QL_THREADS, lds, 0>>>(n, nactive, qt, cls, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, nullptr, empty[0], empty[1]);
+        else if constexpr (K == U64 && AB == 0) k_query_u64<<<bx, QL_THREADS, lds, 0>>>(n, nactive, qt, cls, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, nullptr, empty[0], empty[1]);
+        else if constexpr (K == U64) ab::k_query_u64<AB><<<bx, QL_THREADS, lds, 0>>>(n, nactive, qt, cls, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, nullptr, empty[0], empty[1]);
+        else if constexpr (AB == 0) k_query_u64w<<<bx, QL_THREADS, lds, 0>>>(n, nactive, qt, cls, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, nullptr, empty[0], empty[1]);
+        else ab::k_query_u64w<AB><<<bx, QL_THREADS, lds, 0>>>(n, nactive, qt, cls, sd, g_image, fstride, fwmax, seg_cnt, nseg, pwords, nullptr, empty[0], empty[1]);
     };
     if constexpr (K == S64) CK(hipFuncSetAttribute((const void *)legacy::k_query_s64<AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     else if constexpr (K == S64W) CK(hipFuncSetAttribute((const void *)legacy::k_query_s64w<AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    else if constexpr (K == U64) CK(hipFuncSetAttribute((const void *)k_query_u64<AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    else CK(hipFuncSetAttribute((const void *)k_query_u64w<AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else if constexpr (K == U64 && AB == 0) CK(hipFuncSetAttribute((const void *)k_query_u64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else if constexpr (K == U64) CK(hipFuncSetAttribute((const void *)ab::k_query_u64<AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else if constexpr (AB == 0) CK(hipFuncSetAttribute((const void *)k_query_u64w, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else CK(hipFuncSetAttribute((const void *)ab::k_query_u64w<AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int w = 0; w < 3; ++w) launch();
     CK(hipDeviceSynchronize());

@@ -27,5 +27,5 @@ bash tools/r04_sensitivity.sh > /dev/null 2>&1; cp gpurun_out/r04i/sensitivity.t
 python tools/decode_bench.py > $O/decode_bench.txt 2>&1; python tools/decode_bench.py 3840 2160 9 >> $O/decode_bench.txt 2>&1
 ./build/bench_query5 2 > $O/query_u64_harness.txt 2>&1
 python -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1
-timeout 200 python tools/fuzz_soak.py 90 > $O/fuzz_soak.txt 2>&1
+timeout 400 python tools/fuzz_soak.py 240 > $O/fuzz_soak.txt 2>&1
 ls -la $O

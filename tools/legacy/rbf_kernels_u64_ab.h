@@ -1,80 +1,12 @@
-// rbf_kernels_u64.h -- k_query_u64: round 4's frames-inner FP64 query kernel (filters of 2^15 <= m < 2^23 bits that fit LDS twice:
-// BASELINE config 2).  Same outputs and the same arithmetic as k_query_s64 (rbf_kernels_s64.h; reference semantics
-// improved_video_compressor.py:116-138, :245-253) -- the frame pass itself IS k_query_s64's (frame_pass_rows / frame_pass_plain).
-// What is new is everything AROUND the pass.  Round 3's stamps showed a wave spending 45 % of a frame outside the pass, and the
-// disassembly showed why: ~75 scalar and ~50 vector instructions per wave and frame of loop head (next geometry -> SGPRs, the
-// stager's address arithmetic, a switch over floor(k*)) and of deferred outputs (four ballots, scalar adds, two 64-bit address
-// multiplies, two exec-masked stores), all of them issued by all sixteen waves at the same moment, right behind the frame's barrier,
-// through the CU's ONE scalar unit (tools/opbench2.hip, profiles/r04_opbench2.txt: a scalar instruction costs a SIMD ~3 issue cycles
-// next to its VALU stream, and sixteen waves issuing scalar code together get one instruction per 16 cycles each).  Here:
-//
-//  1. FRAME RECORDS IN LDS, 32 bytes, written once by the prologue: {m, c, -1/m} for the pass of frame j, and -- already shifted to
-//     where the loop needs them -- the image row of frame j + 1 (what the stager fetches during pass j) and the output row of frame
-//     j - 1 (what leaves during pass j).  The loop head is two broadcast LDS reads and three v_readfirstlane (-1/m, the output row); m,
-//     c and the image row's offset are USED FROM THE VGPRS THE READ RETURNS -- no scalar arithmetic at all.
-//  2. THE HOST ORDERS THE CODED FRAMES BY floor(k*) (the compacted table may be in any order: every record names its output row), and
-//     the kernel runs one loop per class: no switch inside the frame loop.
-//  3. THE NEXT IMAGE RIDES IN BY LDS-DMA (global_load_lds_dwordx4), all five pieces of a wave issued at the top of the pass and
-//     waited for once, in front of the next barrier: no register slots (the kernel drops from 119 to 111 VGPRs), no ds_write
-//     instructions, no load a pass waits for.  Round 2's LDS-DMA kernel (k_query_f64) lost against register staging; in THIS loop it
-//     wins 6 us per launch (profiles/r04_query_u64.txt).  Every row is staged at the batch's row pitch (the rows are padded to it
-//     anyway), so offsets and the lane mask of the last piece are launch constants.
-//  4. Pass counts: a lane adds popc(verdict byte) of two consecutive frames into one packed register; every second frame ONE
-//     six-step DPP reduction yields both wave totals in lane 63, which stores them.  No ballots, no scalar adds.
-//  5. Outputs are addressed as base + 32-bit offset (one v_lshl_add per store) from the output row in the record.
+// tools/legacy/rbf_kernels_u64_ab.h -- k_query_u64 / k_query_u64w of round 4 WITH their measurement variants (template parameter AB:
+// 4 = no pass counts, 8 = no staging, 32 = no barrier (wrong results), 64 = no outputs, 2048 = no wave priorities), in namespace
+// rbf::ab, for tools/bench_query5.hip.  The library's own kernels (csrc/rbf_kernels_u64.h) carry no such branches; AB = 0 here is
+// the same code.  Frozen when the branches left csrc/; not built into librbf_hip.so.
 #pragma once
-#include "rbf_kernels_s64.h"
-#include <algorithm>
-#include <cstring>
-#include <type_traits>
+#include "../../new_bloom_filter_repo_amd/csrc/rbf_kernels_u64.h"      // the live header: U64Classes, query_table_u64, and through it the frame pass
 
-namespace rbf {
+namespace rbf { namespace ab {
 
-constexpr uint32_t U64_REC_BYTES = 32;
-__host__ __device__ constexpr uint32_t u64_geo_bytes(uint32_t nactive) { return (nactive + 1u) * U64_REC_BYTES; }   // LDS behind the two image buffers: one record per coded frame + 1
-constexpr int U64_CLASSES = 6;                                    // floor(k*) = 1, 2, 3, 4, 5 in rows, then everything else (plain pass)
-
-struct U64Classes { uint32_t n[U64_CLASSES]; };                  // coded frames per class, in the order of the compacted table
-
-// Host: the FrameTable k_query_u64 reads (see the kernel) from the batch's plain table (m, floor_k, T per frame; m == 0: not coded).
-__host__ inline FrameTable query_table_u64(const FrameTable &tab, uint32_t nframes, uint32_t *nactive, U64Classes *cls, uint64_t (&empty)[2])
-{
-    FrameTable q;
-    memset(&q, 0, sizeof q);
-    memset(cls, 0, sizeof *cls);
-    empty[0] = empty[1] = 0;
-    uint64_t sorted[MAX_BATCH];
-    uint32_t coded = 0;
-    for (uint32_t f = 0; f < nframes; ++f) {
-        if (tab.f[f].m) sorted[coded++] = tab.f[f].T;
-        else empty[f >> 6] |= 1ull << (f & 63);
-    }
-    std::sort(sorted, sorted + coded);
-    uint32_t j = 0;
-    for (int k = 0; k < U64_CLASSES; ++k)
-        for (uint32_t f = 0; f < nframes; ++f) {
-            if (!tab.f[f].m) continue;
-            const uint32_t fk = tab.f[f].floor_k;
-            const int kf = fk >= 1u && fk <= 5u ? (int)fk - 1 : 5;
-            if (kf != k) continue;
-            const double ninv = -1.0 / (double)tab.f[f].m;
-            q.f[j].m = tab.f[f].m;
-            memcpy(&q.f[j].M, &ninv, 8);
-            q.f[j].floor_k = (fk & 0xFFu) | ((uint32_t)(std::lower_bound(sorted, sorted + coded, tab.f[f].T) - sorted) << 8) | (f << 16);
-            q.f[j].T = sorted[j];
-            ++cls->n[k];
-            ++j;
-        }
-    *nactive = coded;
-    return q;
-}
-
-// Next frame's image -> the other LDS buffer by LDS-DMA (global_load_lds_dwordx4: a lane's 16 bytes land at M0 + lane * 16): no
-// register slots, no ds_write, nothing of the pass waits for a load -- all five 16 KiB piece rows of a workgroup (a wave: 1 KiB of
-// each) are issued at the top of the pass (the buffer is free behind the frame's barrier) and the wave waits for them once, in
-// front of the next barrier.  M0 = LDS address of the wave's piece; saved and restored around the block (a reserved register, not a
-// clobber).  Every piece runs under a launch-constant lane mask (rows are staged at the batch's pitch: lanes past its end must not
-// write behind the buffer; a piece wholly past it runs with no lanes).
 template <bool ON>
 struct RowDmaC {
     const uint8_t *image;           // the batch's probe images (the kernel argument: saddr addressing)
@@ -138,8 +70,9 @@ struct RowDmaC {
 // `cls.n[k]`: frames of class k.  `empty_lo / empty_hi`: bit f set = frame f of the batch is not coded and this launch writes its
 // (empty) outputs.  Dynamic LDS: two image buffers of ((fwords_max + 3) & ~3) + 4 dwords, then u64_geo_bytes(nactive).
 // `image_stride_words32` is also what is staged per frame: rows must be readable over their whole pitch (the library's are).
-// (The measurement variants of this body -- no staging, no barrier, no outputs, no priorities -- live in tools/legacy/rbf_kernels_u64_ab.h.)
-template <bool WIDE>
+// AB: measurement variants for tools/bench_query5.hip (the library instantiates 0, where every test below folds away): 4 = no pass
+// counts, 8 = no staging, 32 = no barrier (wrong results), 64 = no outputs, 2048 = no wave priorities.
+template <int AB, bool WIDE>
 __device__ __forceinline__ void query_u64_body(
     uint64_t n, uint32_t nactive, const FrameTable &tab, const U64Classes &cls, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t fwords_max,
@@ -238,7 +171,7 @@ __device__ __forceinline__ void query_u64_body(
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     const uint32_t pitch_bytes = (uint32_t)image_stride_words32 * 4u;
     const uint32_t off0 = wave * 5120u + lane * 16u;             // a wave stages five consecutive KiB (RowDmaC)
-    RowDmaC<true> dm;
+    RowDmaC<!(AB & 8)> dm;
     dm.image = reinterpret_cast<const uint8_t *>(image);
 #pragma unroll
     for (int i = 0; i < 5; ++i) dm.mask[i] = __ballot(off0 + (uint32_t)i * 1024u + 16u <= pitch_bytes);
@@ -263,13 +196,13 @@ __device__ __forceinline__ void query_u64_body(
     // outputs of the previous frame, run from inside the current frame's pass once its first reads are in flight
     auto flush = [&]() {
         if (!out_pending) return;
-        if (live) pass_bytes[(out_row << 6) + seg_lane] = (uint8_t)out_pb;        // one v_lshl_add_u32, one store
-        {
+        if (!(AB & 64) && live) pass_bytes[(out_row << 6) + seg_lane] = (uint8_t)out_pb;        // one v_lshl_add_u32, one store
+        if (!(AB & 4)) {
             cnt2 = __builtin_amdgcn_alignbit(__popc(out_pb), cnt2, 16);   // (cnt << 16) | (cnt2 >> 16)
             row_prev2 = row_prev; row_prev = out_row;
             if (have_two) {
                 const uint32_t tot = wave_sum_to_lane63(cnt2);
-                if (live && lane == 63u) {
+                if (!(AB & 64) && live && lane == 63u) {
                     seg_cnt[row_prev2 + seg] = tot & 0xFFFFu;
                     seg_cnt[row_prev + seg] = tot >> 16;
                 }
@@ -292,12 +225,12 @@ __device__ __forceinline__ void query_u64_body(
             if (rows) rows_reduce4(0, hd1, hl1, hd2, hl2, m_v, ninv, x);          // needs no image: in front of the barrier
             dm.src = gb.x + off0b;                                                     // (a uniform value used from the VGPR the read returned)
             dm.dst_m0 = (uint32_t)__builtin_amdgcn_readfirstlane(buf_sum - fbase) + wave_dst;
-            dma_wait_all();                   // my pieces of THIS frame's image (issued during the previous pass, or by the prologue) have landed
+            if (!(AB & 8)) dma_wait_all();        // my pieces of THIS frame's image (issued during the previous pass, or by the prologue) have landed
             out_row = (uint32_t)__builtin_amdgcn_readfirstlane(gb.w);                 // output row of the PREVIOUS frame (shifted by the prologue)
-            __syncthreads();                  // everyone's writes of the buffer I probe have landed; nobody probes the other one any more
+            if (!(AB & 32)) __syncthreads();      // everyone's writes of the buffer I probe have landed; nobody probes the other one any more
             uint32_t pbf = 0;
             if (rows) {
-                if constexpr (FK > 0) frame_pass_rows<FK, (FK < 5), true>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, dm, flush);
+                if constexpr (FK > 0) frame_pass_rows<FK, (FK < 5), !(AB & 2048)>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, fbase, safe_v, m_v, ninv, x, pbf, dm, flush);
             } else {
                 flush();
                 const uint32_t fk = FK > 0 ? (uint32_t)FK : (uint32_t)__builtin_amdgcn_readfirstlane(gb.z);
@@ -318,21 +251,24 @@ __device__ __forceinline__ void query_u64_body(
     // the last frame's outputs: its row is in the record behind the last one
     out_row = (uint32_t)__builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(geo)[8u * nactive + 7u]);
     flush();
-    if (have_two) {                                  // an odd number of frames: one count is still packed
+    if (!(AB & 4) && have_two) {                                  // an odd number of frames: one count is still packed
         const uint32_t tot = wave_sum_to_lane63(cnt2);
-        if (live && lane == 63u) seg_cnt[row_prev + seg] = tot >> 16;
+        if (!(AB & 64) && live && lane == 63u) seg_cnt[row_prev + seg] = tot >> 16;
     }
 }
 
 #define RBF_U64_PARAMS uint64_t n, uint32_t nactive, const FrameTable tab, const U64Classes cls, Seeds seeds, const uint32_t *__restrict__ image, uint64_t image_stride_words32, \
     uint32_t fwords_max, uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint64_t *__restrict__ pass_words, uint4 *__restrict__ table_out, uint64_t empty_lo, uint64_t empty_hi
 #define RBF_U64_ARGS n, nactive, tab, cls, seeds, image, image_stride_words32, fwords_max, seg_cnt, nseg, pass_words, table_out, empty_lo, empty_hi
-// k_query_u64 is capped at 120 registers (it needs 110): registers are handed out in eights, so two waves of a neighbour pipeline's mask
-// or compaction kernel fit next to its four on every SIMD.  (Padding it to 119 / 127 so that fewer fit costs the four-pipeline step 1-3 %:
-// profiles/r04_coresidency.txt.)
-__attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) void k_query_u64(RBF_U64_PARAMS) { query_u64_body<false>(RBF_U64_ARGS); }
-__global__ __launch_bounds__(QL_THREADS) void k_query_u64w(RBF_U64_PARAMS) { query_u64_body<true>(RBF_U64_ARGS); }
+// (120 VGPRs as k_query_s64: one wave of the planar mask kernel or of k_compact_witness per SIMD runs underneath it)
+template <int AB = 0>
+__attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) void k_query_u64(RBF_U64_PARAMS)
+{
+    query_u64_body<AB, false>(RBF_U64_ARGS);
+}
+template <int AB = 0>
+__global__ __launch_bounds__(QL_THREADS) void k_query_u64w(RBF_U64_PARAMS) { query_u64_body<AB, true>(RBF_U64_ARGS); }
 #undef RBF_U64_PARAMS
 #undef RBF_U64_ARGS
 
-}  // namespace rbf
+} }  // namespace rbf::ab

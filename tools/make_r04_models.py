@@ -160,7 +160,7 @@ def query_traffic(summary):
         alg = b["roofline"]["algorithmic_bytes_per_launch"]
     except Exception:
         pass
-    t = {"kernel": "k_query_u64<0>", "workload": "1920x1080 YUV444 8-bit, 30-frame GOP (29 inter-frames per launch), k*=2.3, planar Y resident",
+    t = {"kernel": "k_query_u64", "workload": "1920x1080 YUV444 8-bit, 30-frame GOP (29 inter-frames per launch), k*=2.3, planar Y resident",
          "source": "tools/profile.sh r04final (tools/collect_r04.sh): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace only "
                    "(profiles/r04_rocprofv3_summary.txt); passes pmc5/pmc6 (force bit 15: no table rewrite, as in the default four-pipeline run), mean of %d / %d launches"
                    % (q5.get("_launches", 0), q6.get("_launches", 0)),
@@ -189,7 +189,7 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "rbf_api.hip")],
                               stderr=subprocess.DEVNULL)
         asm = open(out).read()
-    rows = price(frame_loop_blocks(asm, "_ZN3rbf11k_query_u64ILi0E", 24), cost)
+    rows = price(frame_loop_blocks(asm, "_ZN3rbf11k_query_u64E", 24), cost)
     kinds = collections.Counter()
     cyc = collections.Counter()
     for label, (cnt, c) in rows.items():
@@ -199,7 +199,7 @@ def main():
     valu_cycles, salu_cycles = cyc["VALU"], cyc["SALU"]
     per_frame_simd = (valu_cycles + salu_cycles) * WAVES_PER_SIMD
     model = {
-        "kernel": "k_query_u64<0>", "workload": "1920x1080, 29 coded frames, floor(k*) = 2",
+        "kernel": "k_query_u64", "workload": "1920x1080, 29 coded frames, floor(k*) = 2",
         "source": "tools/make_r04_models.py: ISA of the in-tree library's frame loop (the whole-wave path) x per-opcode issue cost of profiles/r04_opbench2.txt at 4 waves per SIMD",
         "shader_clock_ghz": clock, "simds": SIMDS, "waves_per_simd": WAVES_PER_SIMD,
         "instructions_per_wave_and_frame": {k: round(v, 1) for k, v in kinds.items()},
