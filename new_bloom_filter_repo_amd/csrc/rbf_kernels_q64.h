@@ -95,7 +95,9 @@ __device__ __forceinline__ uint32_t select_or_ones(uint64_t mask, uint32_t if_se
 //     act[slot]   8 bytes: h_act                   -- ... and only then read in full.
 // pos and act are SLOT-MAJOR inside a 512-index segment -- the entry of index seg * 512 + lane * 8 + it sits at seg * 512 + it * 64 +
 // lane -- because that is the order in which the kernels that produce the table (a lane owns 8 consecutive indices) can store it with
-// fully coalesced wave stores; the tags are index-major (a lane stores its eight as one 16-byte piece).
+// fully coalesced wave stores; the tags are index-major (a lane stores its eight as one 16-byte piece).  (pos / act index-major as well, so
+// that neighbouring set pixels share cache lines: +0.7 % on the four-pipeline step, -4 % with one pipeline, whose query kernel rewrites
+// the table with uncoalesced stores then -- profiles/r04_insert_gather_ablation.txt, last block; not kept.)
 __device__ __forceinline__ uint32_t hash_table_slot(uint32_t index)
 {
     return (index & ~511u) | ((index & 7u) << 6) | ((index >> 3) & 63u);
