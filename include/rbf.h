@@ -115,10 +115,10 @@ int rbf_timing_enable(rbf_ctx *ctx, int on);
  *   bit 1       LDS fast path without double-buffering the filter (the integer Barrett kernels)
  *   bit 2       per-pixel threshold compare in the GOP mask kernel even for threshold 0
  *   bit 3       Barrett reductions only (never the FP64 h mod m, which is taken when every filter of a batch has 2^15 <= m < 2^23)
- *   bit 4       run k_hash_table (the pixel-index hash table the insert kernel gathers from, 32 bytes per pixel, shared by the
+ *   bit 4       run k_hash_table (the pixel-index hash table the insert kernel gathers from, 26 bytes per pixel in an allocation of 32, shared by the
  *               contexts of a process) for every batch instead of once per (device, frame size, seeds).
  *               FOOTPRINT: the table is process-global device memory -- 32 * (width*height + 512) bytes per (device, frame size,
- *               seeds) in use, e.g. 66 MB at 1080p -- allocated by the first encode of a geometry and released when the last
+ *               seeds) in use, e.g. 66 MB at 1080p (54 MB used) -- allocated by the first encode of a geometry and released when the last
  *               context holding it is destroyed or moves to another geometry (including one that never uses a table).  Geometries
  *               whose table would exceed 96 MB (2560x1440 and up) never get one: their insert kernels hash the set positions instead.
  *   bit 5       never use that table: the insert kernel hashes the set positions itself

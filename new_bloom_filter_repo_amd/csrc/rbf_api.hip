@@ -168,8 +168,8 @@ struct LaunchTimer {
 };
 
 // ------------------------------------------------------------------------------------------
-// The pixel-index hash table (k_hash_table, 32 bytes per pixel) depends on the device, the frame size and the seeds
-// only, so the contexts of one process SHARE it: four pipelines coding 1080p GOPs gather from one 66 MB table that the
+// The pixel-index hash table (k_hash_table, 26 bytes per pixel inside an allocation of 32: rbf_kernels_q64.h) depends on the device, the frame size and the seeds
+// only, so the contexts of one process SHARE it: four pipelines coding 1080p GOPs gather from one 54 MB table that the
 // 256 MB Infinity Cache can keep, instead of four private ones that it cannot (measured: 0.197 -> 0.18x ms per step).
 // Built once by the first context that needs it (on its stream; the others make their streams wait for the `ready`
 // event), freed when the last reference goes.
@@ -950,10 +950,10 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         const uint64_t bx = (pl.nseg + QL_WAVES - 1) / QL_WAVES;
         LaunchTimer t(ctx, RBF_K_QUERY);
         // A context that is the pixel-index hash table's only holder has the kernel -- which hashes every index anyway -- write it again:
-        // 66 MB of identical values whose only purpose is to be in the Infinity Cache when the next batch's insert gathers from them (one
+        // 54 MB of identical values whose only purpose is to be in the Infinity Cache when the next batch's insert gathers from them (one
         // pipeline: insert 47 -> 38 us, step 214 -> 209).  With several holders the table stays cached by being used.  (READING the hashes
-        // from the table instead of computing them was measured in round 4: 73.2 instead of 74.7 us alone, nothing in the step, and 66 MB of
-        // extra traffic per launch -- not kept.)
+        // from the table instead of computing them was measured in round 4: 73.2 instead of 74.7 us alone with the 32-byte entries of
+        // that time, nothing in the step, 66 MB of extra traffic per launch -- not kept.)
         uint4 *table_out = nullptr;
         const SharedHashTable *sh = ctx->hash_shared;
         if (table_for_next && sh && sh->n == n && sh->seeds.h1 == sd.h1 && sh->seeds.h2 == sd.h2 && sh->seeds.act == sd.act && !ctx->no_hash_table) {
@@ -1041,7 +1041,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         // hash table of the pixel indices (k_hash_table): built for this batch, or kept from the last one when the
         // context was told to cache it; without device memory for it the insert kernel hashes for itself
         bool use_tab = pl.insert_tab;
-        // A pixel-index table (32 B per pixel, process-wide, lives until the last context of its geometry goes) that would crowd the
+        // A pixel-index table (an allocation of 32 B per pixel, process-wide, lives until the last context of its geometry goes) that would crowd the
         // 256 MB Infinity Cache is never built: the insert kernels hash their set positions on the spot instead (2160p, 265 MB:
         // 72 us against 96 with the gather) -- whichever insert kernel runs, with or without the masks' set-bit counts.
         const bool table_too_big = ((size_t)n + QL_SEG_PIXELS) * 32 > HASH_TABLE_CACHE_BYTES;

@@ -2,14 +2,14 @@
 //
 //   k_hash_table   the three XXH64 of EVERY pixel index of the frame geometry (they depend on the index and the seeds
 //                  only, not on the frame: improved_video_compressor.py:77-78,94).  Runs for the FIRST batch of a
-//                  geometry; afterwards k_query_f64, which computes the same hashes for its own probes in every batch,
-//                  writes the table for the following batch's insert.  Stored in the form the
-//                  FP64 reduction wants -- 32 bytes per pixel: RN(h1), RN(h2) as doubles, the low dwords of h1 and
-//                  h2, and h_act.  A lane owns 8 consecutive indices, so the decade-prefix sharing of hash3_run8
-//                  applies (~120 instead of ~600 instructions per index), and over a 29-frame batch 93 % of all
-//                  indices are set in at least one frame, so nothing is hashed in vain.
-//   k_insert_tab   k_insert_lds with the hashing replaced by a 32-byte gather from that table: workgroup (slice, frame
-//                  [, tile]) builds a partial filter in LDS from its slice of the mask; set positions are compacted
+//                  geometry; afterwards a context that holds the table alone has k_query_u64, which computes the same hashes for
+//                  its own probes in every batch, write it again for the following batch's insert (to keep it cached).  Layout:
+//                  rbf_kernels_q64.h (16-byte (h1, h2) entries, 16-bit activation tags, the full h_act for ties).  A lane
+//                  owns 8 consecutive indices, so the decade-prefix sharing of hash3_run8 applies (~120 instead of ~600
+//                  instructions per index), and over a 29-frame batch 93 % of all indices are set in at least one frame, so
+//                  nothing is hashed in vain.
+//   k_insert_tab   k_insert_lds with the hashing replaced by ONE 16-byte gather (+ a 2-byte tag) from that table: workgroup
+//                  (slice, frame[, tile]) builds a partial filter in LDS from its slice of the mask; set positions are compacted
 //                  through a per-wave LDS queue so that the gather, the two reductions (mod_m_f64) and the LDS atomics
 //                  always run on full waves; the gather of one batch of 64 keys flies while the next mask bytes are
 //                  compacted.  All workgroups of a slice run on the same XCD (slice = blockIdx % 8 when a frame has 8
@@ -17,7 +17,7 @@
 //                  other frames.
 //
 // In k_insert_lds the three hashes of the p*n set positions cost ~33 of its ~70 us per 1080p x 29 batch (64-bit
-// multiplies: tools/bench_insert.hip ablation); the table costs one ~66 MB write per batch.
+// multiplies: tools/bench_insert.hip ablation); the table costs one ~54 MB write, once.
 #pragma once
 #include "rbf_kernels_q64.h"
 
@@ -66,7 +66,7 @@ static_assert(IT_WAVE_LDS_BYTES % 16 == 0 && (IT_QUEUE * 2) % 16 == 0, "the stag
 // no in-tile test per probe.  RECORDS = true (k_insert_positions): the batch is appended to the frame's list of
 // InsertRecords, 64 contiguous records per batch, starting at records[rpos] (this wave's own range of the list).
 // HASHED: no table -- the batch's three hashes are computed on the spot (hash3_index, as k_insert_lds does).  Cheaper than the
-// gather once the table (32 B per pixel) no longer fits the 256 MB Infinity Cache: at 2160p the gather of a GOP's 5.9 M
+// gather once the table no longer fits the 256 MB Infinity Cache: at 2160p the gather of a GOP's 5.9 M
 // entries costs 58 us of random HBM reads, hashing them ~35.
 //
 // THE MASK BYTES COME THROUGH LDS (round 4).  A wave's steps are staged IT_CHUNK_STEPS at a time by LDS-DMA (eight
