@@ -34,6 +34,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+COMM_DEVICE = None              # where small control tensors of the collectives live: the GPU under RCCL, host memory under gloo (init_dist)
 MIN_REGION_S = 0.060            # shortest timed region that is reported as the headline
 ALONE_LAUNCHES = 50             # launches behind every "alone" per-kernel figure
 
@@ -74,7 +75,14 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=0, help="1 = one host thread per pipeline (each calls rbf_encode_gop for its own context; ctypes drops the GIL) instead of one thread issuing begin / finish in turn")
     ap.add_argument("--side-compact", action="store_true", help="RBF_OPT_SIDE_COMPACT: the witness compaction on a library-owned side stream beside the next GOP's mask / insert / reduce, two output sets per pipeline (measured: no gain, profiles/r04_side_compact.txt)")
     ap.add_argument("--skip-kernels", type=str, default="", help="diagnostic (results WRONG, implies --no-verify): comma list of insert,reduce,query,stitch not to launch -- what does each cost the overlapped step?")
-    ap.add_argument("--no-legs", action="store_true", help="skip the interleaved / config4_2160p / decode_1080p legs behind the headline")
+    ap.add_argument("--no-legs", action="store_true", help="skip the interleaved / config4_2160p / decode_1080p / batched_gops legs behind the headline")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the N > 1 path: nccl (= RCCL over xGMI, the product path) or gloo "
+                    "(records staged through host memory; with --one-device it lets N rank processes share ONE GPU, which is how the sharded path is exercised with the real kernels on a 1-GPU box)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (its own contexts and streams): N processes on one device, for --backend gloo")
+    ap.add_argument("--gops-per-call", type=int, default=1, help="GOPs of --frames frames that ONE call (rbf_encode_runs: one mask / insert / reduce / query / compact launch sequence) codes; "
+                    "a step is then one such call.  1 = the contract line (one GOP per call); the default run adds a `batched_gops` leg with 4")
+    ap.add_argument("--insert-slices", type=int, default=0, help="tuning: RBF_OPT_INSERT_SLICES (0 = auto)")
+    ap.add_argument("--insert-grouped", action="store_true", help="tuning: RBF_OPT_INSERT_GROUPED (round-4 insert grouping for large batches)")
     return ap.parse_args()
 
 
@@ -124,12 +132,28 @@ def init_dist(args):
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    global COMM_DEVICE
+    if args.one_device:
+        if args.backend != "gloo":
+            raise SystemExit("--one-device needs --backend gloo (RCCL wants one GPU per rank)")
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("rank %d: only %d GPU(s) visible" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    COMM_DEVICE = device
     use_dist = world > 1 or args.force_dist
-    if use_dist:
+    if use_dist and args.backend == "gloo":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        COMM_DEVICE = torch.device("cpu")         # control values (timings, counts) and record payloads travel through host memory
+        ones = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(ones)
+        if int(ones.item()) != world:
+            raise SystemExit("gloo saw %d ranks, expected %d" % (int(ones.item()), world))
+    elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -163,9 +187,13 @@ def main():
     from new_bloom_filter_repo_amd.synthetic import make_gop, P_KSTAR_2_3
 
     W, H, F = args.width, args.height, args.frames
-    n, pairs = W * H, F - 1
+    GPC = max(1, args.gops_per_call)              # GOPs per call: a block of GPC * F frames whose frames F, 2F, ... are keyframes (run starts)
+    FB = F * GPC                                  # frames of a block
+    n, pairs = W * H, FB - 1                      # rows per call; GPC - 1 of them are pairs across a keyframe, which are not coded
+    coded_pairs = GPC * (F - 1)
+    run_starts = [F * g for g in range(1, GPC)]
     dtype = np.uint8 if args.bits == 8 else np.uint16
-    use_gather = use_dist and not args.no_gather
+    use_gather = use_dist and not args.no_gather and args.backend == "nccl"      # (the outbox gather posts device tensors: RCCL only; under gloo the weak mode runs without it)
     # `--streams` GOP pipelines: consecutive steps rotate over them, each with its own HIP stream, library
     # context (scratch), resident GOP and output record.  The HBM-bound mask kernel and the latency-bound
     # compaction / reduce kernels of one step then overlap the integer-issue-bound insert / query kernels of its
@@ -180,6 +208,10 @@ def main():
         skip = sum(1 << {"insert": nat.K_INSERT, "reduce": nat.K_REDUCE, "query": nat.K_QUERY, "stitch": nat.K_STITCH}[k] for k in args.skip_kernels.split(","))
         for c in ctxs:
             c.option(nat.OPT_DEBUG_SKIP, skip)
+    if args.insert_slices or args.insert_grouped:
+        for c in ctxs:
+            c.option(nat.OPT_INSERT_SLICES, args.insert_slices)
+            c.option(nat.OPT_INSERT_GROUPED, 1 if args.insert_grouped else 0)
     side = args.side_compact
     out_sets = 2 if side else 1
     if side:
@@ -193,9 +225,9 @@ def main():
     G_res = args.gops_per_pipeline or (3 if planar else 1)      # resident GOPs per pipeline: the inputs stay ~750 MB, well past the Infinity Cache
     coders = []
     for k in range(ncoders):
-        coders.append(GopCoder(ctxs[k], W, H, F, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
+        coders.append(GopCoder(ctxs[k], W, H, FB, channels=3, sample_bytes=args.bits // 8, allocator=torch_allocator(device),
                                out_allocator=arenas[k], frames_block=coders[0].frames if (k and args.shared_gop) else None,
-                               planar_luma=planar, keep_interleaved=not planar, resident_gops=G_res, out_sets=out_sets))
+                               planar_luma=planar, keep_interleaved=not planar, resident_gops=G_res, out_sets=out_sets, run_starts=run_starts))
     coder = coders[0]
     density = args.density or P_KSTAR_2_3
     host_gops = []                                # [pipeline][resident gop] -> (F, H, W, 3) host frames
@@ -203,7 +235,8 @@ def main():
         if k and args.shared_gop:
             host_gops.append(host_gops[0])
             continue
-        host_gops.append([np.stack(make_gop(1000 * 2 + 64 * rank + k + 16 * g, W, H, F, p=density, dtype=dtype)) for g in range(G_res)])
+        host_gops.append([np.concatenate([np.stack(make_gop(1000 * 2 + 64 * rank + k + 16 * g + 4096 * j, W, H, F, p=density, dtype=dtype)) for j in range(GPC)])
+                          for g in range(G_res)])
         for g in range(G_res):
             coders[k].load_frames(host_gops[k][g], g)
     torch.cuda.synchronize(device)
@@ -338,7 +371,7 @@ def main():
                     a = kt.get(name, (0.0, 0))
                     kt[name] = (a[0] + ms, a[1] + cnt)
         if use_dist:
-            te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            te = torch.tensor([elapsed], dtype=torch.float64, device=COMM_DEVICE)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
         return elapsed, kt
@@ -352,7 +385,7 @@ def main():
         est = elapsed_k / args.steps
         nlong = int(MIN_REGION_S * 1.25 / est) + 1
         if use_dist:                               # every rank must run the same number of steps
-            tl = torch.tensor([nlong], dtype=torch.int64, device=device)
+            tl = torch.tensor([nlong], dtype=torch.int64, device=COMM_DEVICE)
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             nlong = int(tl.item())
         short = {"steps": args.steps, "ms_per_step": round(elapsed_k / args.steps * 1e3, 4), "region_ms": round(elapsed_k * 1e3, 2)}
@@ -383,7 +416,7 @@ def main():
             checked.append((host_gops[k][g], coders[k].results()))
     res_all = [rows for _, rows in checked]
     res = res_all[0]
-    pixels_per_step = pairs * n * world
+    pixels_per_step = coded_pairs * n * world
     value = pixels_per_step * steps_timed / elapsed / 1e6
 
     out = {
@@ -396,9 +429,11 @@ def main():
         "host_feed": ("one thread per pipeline, each calling rbf_encode_gop on its own context" if (args.host_threads and not gather and ncoders > 1) else
                       "one thread: rbf_encode_gop_begin of step s+%d is enqueued before rbf_encode_gop_finish of step s" % ahead if ahead else
                       "one thread, one blocking rbf_encode_gop per step"),
-        "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP (%d inter-frames/step/GPU), %s, threshold 0, %s"
-                               % (W, H, args.bits, F, pairs, "p=%g" % args.density if args.density else "k*=2.3",
+        "config": {"workload": "%dx%d YUV444 %d-bit synthetic %d-frame GOP%s (%d inter-frames/step/GPU), %s, threshold 0, %s"
+                               % (W, H, args.bits, F, "" if GPC == 1 else " x %d GOPs batched into ONE launch sequence per step (rbf_encode_runs)" % GPC, coded_pairs,
+                                  "p=%g" % args.density if args.density else "k*=2.3",
                                   "planar Y resident (the mask stage reads luma only)" if planar else "interleaved YUV444 resident"),
+                   "gops_per_call": GPC,
                    "layout": "planar Y" if planar else "interleaved", "resident_gops_per_pipeline": G_res,
                    "inputs": "resident in HBM before the timed region: %s; the timed step starts at the mask kernel"
                              % ("Y planes extracted from the YUV444 frames on the host and uploaded once (the `interleaved_yuv444` leg keeps whole frames resident instead)" if planar else "whole interleaved YUV444 frames, uploaded once"),
@@ -413,7 +448,8 @@ def main():
                    "stages": "residual mask -> host params -> insert -> query+witness",
                    "witness_compaction": "on a library-owned side stream behind the query (RBF_OPT_SIDE_COMPACT), beside the next GOP's mask / insert / reduce; two output sets per pipeline" if side else "on the pipeline's stream",
                    "launcher": os.environ.get("RBF_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process"),
-                   "rccl_ranks": world if use_dist else 0,
+                   "rccl_ranks": world if (use_dist and args.backend == "nccl") else 0, "backend": args.backend if use_dist else None,
+                   "ranks_share_one_device": bool(args.one_device),
                    "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by gloo world-2 tests (incl. the self-spawn launcher) and nccl world-1 tests"},
     }
     if short:
@@ -424,18 +460,18 @@ def main():
         l_sum = sum(r["l"] for r in res)
         w_sum = sum(r["witness_bits"] for r in res)
         # ALGORITHMIC bytes of the A5 stage: packed mask in + filter in + witness out
-        alg_bytes = pairs * n / 8 + l_sum / 8 + w_sum / 8
+        alg_bytes = coded_pairs * n / 8 + l_sum / 8 + w_sum / 8
         q_alone = (breakdown or {}).get("query")
         if q_alone:
             achieved = alg_bytes / (q_alone * 1e-3) / 1e9
-            default_shape = (W, H, F, args.bits) == (1920, 1080, 30, 8)
+            default_shape = (W, H, F, args.bits, GPC) == (1920, 1080, 30, 8, 1)
             qname = "k_query_u64" if default_shape else "query kernel of this geometry (DESIGN.md 4)"
             rf = {"bound": "hbm", "kernel": qname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                   "avg_launch_ms": q_alone, "launches_averaged": ALONE_LAUNCHES,
                   "timing": "HIP events on the launching stream, one pipeline alone (nothing co-running), after the timed region",
-                  "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": round(alg_bytes / (pairs * n), 4)}
-            rf.update(measured_traffic(W, H, F, args.bits, bool(args.density)))
+                  "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_pixel": round(alg_bytes / (coded_pairs * n), 4)}
+            rf.update(measured_traffic(W, H, F, args.bits, bool(args.density) or GPC != 1))
             if ktimes and ktimes.get("query", (0, 0))[1]:
                 rf["latency_under_overlap_ms"] = round(ktimes["query"][0] / ktimes["query"][1], 4)   # event pair inside the timed region: includes queueing behind the other pipelines
             c_alone = (breakdown or {}).get("stitch")
@@ -444,10 +480,10 @@ def main():
                 rf["stage_a5"] = {"kernels": [qname, "k_compact_witness"], "ms": round(st, 4),
                                   "achieved": round(alg_bytes / (st * 1e-3) / 1e9, 2), "frac": round(alg_bytes / (st * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
             # the whole fused path priced as SURVEY 8d does: 2 luma reads + packed mask, filter and witness per pixel
-            b_px = 2.0 * (args.bits // 8) + alg_bytes / (pairs * n)
+            b_px = 2.0 * (args.bits // 8) + alg_bytes / (coded_pairs * n)
             rf["end_to_end"] = {"bytes_per_pixel": round(b_px, 3), "achieved": round(value / world * 1e6 * b_px / 1e9, 1),
                                 "unit": "GB/s per GPU", "frac": round(value / world * 1e6 * b_px / 1e9 / HBM_PEAK_GBPS, 4)}
-            rf["issue"] = None if args.density else issue_roofline(W, H, F, args.bits, breakdown)
+            rf["issue"] = None if (args.density or GPC != 1) else issue_roofline(W, H, F, args.bits, breakdown)
             out["roofline"] = rf
             out["kernels_ms_per_step_alone"] = breakdown
             if args.streams > 1:
@@ -457,9 +493,9 @@ def main():
         else:
             out["roofline"] = None
         if world == 1:
-            out["pcie_inclusive_mpixels_per_s"] = pcie_inclusive(torch, nat, coder, host_gops[0][0], pairs * n, elapsed / steps_timed)
+            out["pcie_inclusive_mpixels_per_s"] = pcie_inclusive(torch, nat, coder, host_gops[0][0], coded_pairs * n, elapsed / steps_timed)
             if G_res >= 2 and planar:
-                out["pcie_overlapped_mpixels_per_s"] = pcie_overlapped(torch, device, coder, streams[0], host_gops[0], pairs * n)
+                out["pcie_overlapped_mpixels_per_s"] = pcie_overlapped(torch, device, coder, streams[0], host_gops[0], coded_pairs * n)
         if not args.no_verify:
             out["verified_vs_oracle"] = verify_all([h for h, _ in checked], res_all, n, len(checked))
             out["verified_vs_oracle"]["pipelines"] = 1 if args.shared_gop else ncoders
@@ -468,7 +504,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(res, n, args.cpu_frames)
     # ---- further legs of the same line (rank 0 of a single-GPU run only): the interleaved layout next to the planar headline, BASELINE
     #      configs[3] (3840x2160) and the decode direction (A6) of the headline's own records
-    if world == 1 and rank == 0 and not args.no_legs and (W, H, F, args.bits) == (1920, 1080, 30, 8) and not args.density:
+    if world == 1 and rank == 0 and not args.no_legs and (W, H, F, args.bits, GPC) == (1920, 1080, 30, 8, 1) and not args.density:
         out["decode_1080p"] = decode_leg(torch, nat, coders, host_gops, n, pairs, G_res)
         if planar:
             out["interleaved_yuv444"] = pipelines_leg(torch, nat, device, local_rank, W, H, F, 8, False, 1, ncoders, density, ahead, 160, host_gops=[[h[0]] for h in host_gops], verify=not args.no_verify, side=side)
@@ -756,9 +792,13 @@ def verify_all(host_gops, res_all, n, npipes):
     with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as pool:
         for k in range(npipes):
             gop, res = host_gops[k], res_all[k]
-            jobs = [(np.ascontiguousarray(gop[f][..., 0]), np.ascontiguousarray(gop[f + 1][..., 0]), n) for f in range(len(res))]
+            jobs = [(np.ascontiguousarray(gop[f][..., 0]), np.ascontiguousarray(gop[f + (0 if res[f].get("skipped") else 1)][..., 0]), n) for f in range(len(res))]
             for f, (mask, kk, l, bit_array, witness) in enumerate(pool.map(_oracle_frame, jobs)):
                 r = res[f]
+                if r.get("skipped"):               # a pair across a keyframe of a multi-GOP block: not coded -- zero mask row, nothing else
+                    if r["mask"].any() or r["witness_bits"] or r["ones"]:
+                        raise SystemExit("pipeline %d pair %d is marked skipped but has outputs" % (k, f))
+                    continue
                 ok = np.array_equal(np.unpackbits(r["mask"])[:n], mask) and (r["k"], r["l"]) == (kk, l)
                 if ok and l:
                     ok = (np.array_equal(np.unpackbits(r["filter"])[:l], bit_array) and r["witness_bits"] == len(witness)
@@ -776,7 +816,7 @@ def cpu_baseline(res, n, nframes):
     from oracle import oracle as orc
     L = orc.lib()
     seeds = (ctypes.c_uint64 * 3)(*orc.SEEDS_VIDEO)
-    frames = [r for r in res[:nframes or len(res)] if r["l"]]
+    frames = [r for r in res[:nframes or len(res)] if r["l"] and not r.get("skipped")]
     masks = [np.unpackbits(r["mask"])[:n] for r in frames]
     t_total, px, passes = 0.0, 0, 0
     while t_total < 10.0 and passes < 6:
@@ -908,7 +948,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
         barrier()
         elapsed = time.perf_counter() - t0
         if use_dist:
-            te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            te = torch.tensor([elapsed], dtype=torch.float64, device=COMM_DEVICE)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
         return elapsed, got
@@ -922,7 +962,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
         host = [[shard[f0 - first + j] for j in range(cnt)] for f0, cnt in pieces]
         res_all = [c.results() for c in coders]
         v = verify_all([np.stack(h) for h in host], res_all, n, len(coders)) if coders else {"frames": 0}
-        cnt_t = torch.tensor([v["frames"]], dtype=torch.int64, device=device)
+        cnt_t = torch.tensor([v["frames"]], dtype=torch.int64, device=COMM_DEVICE)
         if use_dist:
             dist.all_reduce(cnt_t)
         verified = {"frames": int(cnt_t.item()), "of": total_pairs, "fields": "mask, k, l, filter, witness"}

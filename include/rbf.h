@@ -38,7 +38,7 @@ extern "C" {
 #define RBF_EIO      (-5)   /* a HIP runtime call failed; see rbf_last_error() */
 #define RBF_ERANGE  (-34)
 
-#define RBF_ABI_VERSION 3
+#define RBF_ABI_VERSION 4
 
 typedef struct rbf_ctx rbf_ctx;
 
@@ -145,6 +145,11 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
  * the next rbf_encode_gop_begin runs beside the compaction only if its masks / witnesses / stats buffers are not the previous GOP's
  * (a caller that alternates two output sets), and waits for it otherwise. */
 #define RBF_OPT_SIDE_COMPACT 3
+/* Tuning knobs of the single-tile insert (k_insert_tab).  RBF_OPT_INSERT_SLICES: mask slices (= partial filters) per frame, 0 = auto.
+ * RBF_OPT_INSERT_GROUPED (0 / 1): 1 = batches of more than 32 coded frames are inserted in groups of 32 frames, one launch each (the
+ * round-4 form), instead of one launch for the whole batch. */
+#define RBF_OPT_INSERT_SLICES 4
+#define RBF_OPT_INSERT_GROUPED 5
 int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value);
 int rbf_timing_reset(rbf_ctx *ctx);
 int rbf_timing_read(rbf_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
@@ -265,6 +270,40 @@ int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_st
                          void *filters_dev, uint64_t filter_stride_bytes,
                          void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev);
 int rbf_encode_gop_poll(rbf_ctx *ctx, int *ready);
+
+/* SEVERAL keyframe-delimited runs of one clip in ONE launch sequence (SURVEY.md 8b `rbf_encode_batch ... GOP batching`).  The reference
+ * codes frame by frame (improved_video_compressor.py:198-266) and has no GOP loop (:1236-1268); a caller that holds a clip whose frame t
+ * is a keyframe iff t % keyframe_interval == 0 hands over up to a few hundred consecutive frames at once and every fixed cost of the
+ * launch sequence -- the query kernel's hashing prologue, the mask kernel's ramp and tail, five launches -- is paid once per block
+ * instead of once per GOP.
+ *   run_starts   HOST array of nframes bytes, nullable (= one run, rbf_encode_gop_begin).  run_starts[t] != 0 for t >= 1: frame t is a
+ *                keyframe of the caller's stream, it starts a new run, and PAIR t-1 (frame t against frame t-1) IS NOT CODED: its mask
+ *                row is written as zeros, ones_dev[t-1] = 0, its witness row and stats are cleared, its filter row is not touched,
+ *                params_out[t-1] = {m = 0, floor_k = RBF_PAIR_SKIPPED, 0}, k_out[t-1] = 0, and rbf_pack_records gives it a header row
+ *                with no payload.  run_starts[0] is ignored.  No frame of a run is read by the mask stage of another run.
+ * Everything else as rbf_encode_gop_begin / rbf_encode_gop; rbf_encode_gop_poll / rbf_encode_gop_finish complete either kind of begin.
+ * Both begins check EVERY argument before they touch the stream or the caller's buffers, including
+ * filter_stride_bytes >= rbf_filter_stride_min(width * height): the filters are planned in the second half, so the stride must cover
+ * the largest filter the planner can produce for the frame size (l <= 0.31606 n for every density, :181-193). */
+#define RBF_PAIR_SKIPPED 0xFFFFFFFFu
+uint64_t rbf_filter_stride_min(uint64_t n);
+int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                          uint32_t nframes, uint32_t width, uint32_t height,
+                          uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                          uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                          const uint8_t *run_starts, const rbf_seeds *seeds,
+                          void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                          void *filters_dev, uint64_t filter_stride_bytes,
+                          void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev);
+int rbf_encode_runs(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                    uint32_t nframes, uint32_t width, uint32_t height,
+                    uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                    uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                    const uint8_t *run_starts, const rbf_seeds *seeds,
+                    void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                    void *filters_dev, uint64_t filter_stride_bytes,
+                    void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
+                    rbf_filter_params *params_out, double *k_out);
 int rbf_encode_gop_finish(rbf_ctx *ctx, rbf_filter_params *params_out, double *k_out);
 
 /* ---- exact-size record of a batch (what the gather to rank 0 moves) ------------- */

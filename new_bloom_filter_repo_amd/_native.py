@@ -18,6 +18,8 @@ RBF_ERANGE = -34
 K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_REDUCE, K_SCAN, K_NOISE, K_PACK, K_HASHTAB = range(13)
 KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack", "hashtab"]
 STATS_PER_FRAME = 4
+PAIR_SKIPPED = 0xFFFFFFFF                 # params[p].floor_k of a pair across a keyframe (rbf_encode_runs)
+OPT_INSERT_SLICES, OPT_INSERT_GROUPED = 4, 5
 OPT_SEPARATE_FINISH, OPT_SIDE_COMPACT, OPT_DEBUG_SKIP = 2, 3, 99    # rbf_ctx_option keys (include/rbf.h); key 1 (round 3: the round-2 query kernel) is gone with that kernel
 
 
@@ -63,6 +65,11 @@ _PROTOS = {
     "rbf_encode_gop_begin": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, ctypes.POINTER(Seeds),
                                     _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp]),
     "rbf_encode_gop_poll": (_int, [_vp, ctypes.POINTER(_int)]),
+    "rbf_filter_stride_min": (_u64, [_u64]),
+    "rbf_encode_runs_begin": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, _vp, ctypes.POINTER(Seeds),
+                                     _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp]),
+    "rbf_encode_runs": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, _vp, ctypes.POINTER(Seeds),
+                               _vp, _u64, _vp, _vp, _u64, _vp, _u64, _vp, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
     "rbf_encode_gop_finish": (_int, [_vp, ctypes.POINTER(FilterParams), ctypes.POINTER(ctypes.c_double)]),
     "rbf_residual_mask_batch": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u64, _u32, _u32, _i32, _i32p, _vp, _u64, _vp]),
     "rbf_record_max_bytes": (_u64, [_u32, _u64]),

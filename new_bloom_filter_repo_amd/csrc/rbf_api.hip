@@ -74,6 +74,8 @@ struct rbf_ctx {
     const void *side_stats = nullptr; size_t side_stats_bytes = 0;
     uint32_t debug_skip = 0;                                      // RBF_OPT_DEBUG_SKIP: bit RBF_K_* = do not launch that kernel of the encode path (WRONG results: sensitivity measurements only)
     int no_fused_finish = 0;                                      // 1 = always the separate k_finish_ones launch (rbf_ctx_option RBF_OPT_SEPARATE_FINISH)
+    uint32_t insert_slices = 0;                                   // tuning (RBF_OPT_INSERT_SLICES): mask slices per frame of the single-tile insert, 0 = auto
+    int insert_grouped = 0;                                       // tuning (RBF_OPT_INSERT_GROUPED): 1 = large batches are inserted in groups of 32 frames (round 4)
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
     int32_t *thr_tab = nullptr;      size_t thr_tab_cap = 0;      // per-pair thresholds of the mask kernels
@@ -98,7 +100,9 @@ struct rbf_ctx {
         const void *masks_dev = nullptr; uint64_t mask_stride_bytes = 0;
         void *filters_dev = nullptr; uint64_t filter_stride_bytes = 0;
         void *witnesses_dev = nullptr; uint64_t witness_stride_bytes = 0; uint64_t *stats_dev = nullptr;
+        bool has_skip = false;                   // ctx->run_skip[p] != 0: pair p crosses a keyframe and is not coded
     } gop;
+    std::vector<uint8_t> run_skip;
     std::vector<rbf_filter_params> plan;
     std::vector<double> plan_k;
     // timing
@@ -416,6 +420,8 @@ int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value)
     switch (option) {
     case RBF_OPT_SEPARATE_FINISH: ctx->no_fused_finish = value ? 1 : 0; return RBF_OK;
     case RBF_OPT_DEBUG_SKIP: ctx->debug_skip = (uint32_t)value; return RBF_OK;
+    case RBF_OPT_INSERT_SLICES: ctx->insert_slices = value < 0 ? 0u : (uint32_t)value; return RBF_OK;
+    case RBF_OPT_INSERT_GROUPED: ctx->insert_grouped = value ? 1 : 0; return RBF_OK;
     case RBF_OPT_SIDE_COMPACT: {
         if (int r = set_device(ctx)) return r;                    // (joins an outstanding compaction before the mode changes)
         if (value && !ctx->side_stream) {
@@ -642,6 +648,16 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     uint32_t base = units / group;
     if (base < 1) base = 1;
     if (base > 32) base = 32;
+    // A batch of several GOPs (rbf_encode_runs: up to 128 coded frames) whose filters are single tiles goes through ONE insert launch
+    // -- the CUs take the next (frame, slice) workgroup as they come free, no drain between groups of 32 frames -- with
+    // `insert_slices` slices per frame (RBF_OPT_INSERT_SLICES; 0 = auto).
+    if (p.insert_tiles == 1 && !p.insert_two_phase && active > group && !ctx->insert_grouped) {
+        group = active;
+        base = ctx->insert_slices ? ctx->insert_slices : INSERT_SLICES;
+        if (base > 32) base = 32;
+    } else if (ctx->insert_slices && p.insert_tiles == 1 && !p.insert_two_phase) {
+        base = ctx->insert_slices > 32 ? 32 : ctx->insert_slices;
+    }
     p.insert_group = group;
     p.S = base;
     p.per_tile = 0;
@@ -787,9 +803,11 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
                               uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
                               uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
                               void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev, bool finish,
-                              const MaskFinish *gop_tail = nullptr /* rbf_encode_gop: publish + clears; fused into the mask kernel when it covers the frame */)
+                              const MaskFinish *gop_tail = nullptr /* rbf_encode_gop: publish + clears; fused into the mask kernel when it covers the frame */,
+                              const uint8_t *skip = nullptr /* rbf_encode_runs: skip[p] != 0 = pair p is not coded (zero row, zero count) */,
+                              bool join = true /* false: rbf_encode_runs_begin has decided whether an outstanding side-stream compaction must be waited for */)
 {
-    if (int r = set_device(ctx)) return r;
+    if (int r = set_device(ctx, join)) return r;
     if (int r = check_mask_args(frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
                                 thr_floors, masks_dev, mask_stride_bytes, ones_dev)) return r;
     const uint64_t n = (uint64_t)width * height;
@@ -807,19 +825,6 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
     }
     ctx->ones_acc_dirty = true;                                   // until k_finish_ones has been enqueued
     uint64_t *const acc = ctx->ones_acc;
-    const int32_t *thr_tab = nullptr;
-    if (thr_floors) {
-        // Kernel arguments are captured at launch, so the caller's array is free as soon as we return.
-        if (int r = grow((void **)&ctx->thr_tab, &ctx->thr_tab_cap, (size_t)pairs * 4)) return r;
-        for (uint32_t base = 0; base < pairs; base += ThrChunk::N) {
-            ThrChunk c{};
-            const uint32_t cnt = pairs - base < ThrChunk::N ? pairs - base : ThrChunk::N;
-            for (uint32_t i = 0; i < cnt; ++i) c.v[i] = thr_floors[base + i];
-            hipLaunchKernelGGL(k_store_thresholds, dim3(1), dim3(ThrChunk::N), 0, ctx->stream, c, ctx->thr_tab + base, cnt);
-        }
-        HIP_TRY(hipGetLastError());
-        thr_tab = ctx->thr_tab;
-    }
     const uint64_t nwords = (n + 63) / 64;
     bool fused = false;
     // Fast path: flat frames, 16-byte aligned, whole 1024-pixel segments; the generic kernel does the rest.
@@ -830,15 +835,72 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
     if (!ctx->force_generic && flat && known && frame_stride_bytes % 16 == 0 && ((uintptr_t)frames_dev % 16) == 0 &&
         (size_t)pairs * 4 <= 48 * 1024)
         fast_segs = n / 1024;
+    // temporal chunks of the fast kernel: enough waves to fill the chip (>= ~32 per CU) without re-reading much
+    MaskChunks mc{};
+    uint32_t chunks = 1;
+    bool skip_in_table = false;                // the chunk table cuts the block at its keyframes: the fast kernel needs no threshold trick
+    if (fast_segs) {
+        uint32_t coded = pairs;
+        if (skip) { coded = 0; for (uint32_t i = 0; i < pairs; ++i) coded += skip[i] ? 0u : 1u; }
+        chunks = ctx->mask_chunks ? ctx->mask_chunks : (uint32_t)((6500 + fast_segs - 1) / fast_segs);   // 4 at 1080p (measured best)
+        if (chunks > coded) chunks = coded;
+        if (chunks < 1) chunks = 1;
+        uint32_t ppc = (coded + chunks - 1) / chunks;
+        if (ppc < 1) ppc = 1;
+        if (!skip) {
+            chunks = (pairs + ppc - 1) / ppc;
+            mc.ppc = ppc;
+        } else if (nframes < MASK_CHUNK_SKIP) {
+            uint32_t cnt = 0;
+            bool fits = true;
+            for (uint32_t a = 0; a < pairs && fits;) {
+                uint32_t b = a;
+                while (b < pairs && (skip[b] != 0) == (skip[a] != 0)) ++b;
+                const uint32_t len = b - a;
+                if (skip[a]) {
+                    if (cnt >= MASK_MAX_CHUNKS) { fits = false; break; }
+                    mc.first[cnt] = (uint16_t)a; mc.pairs[cnt] = (uint16_t)(len | MASK_CHUNK_SKIP); ++cnt;
+                } else {
+                    const uint32_t c = (len + ppc - 1) / ppc, per = (len + c - 1) / c;     // this run in c chunks of about ppc pairs
+                    for (uint32_t x = a; x < b; x += per) {
+                        if (cnt >= MASK_MAX_CHUNKS) { fits = false; break; }
+                        mc.first[cnt] = (uint16_t)x; mc.pairs[cnt] = (uint16_t)(b - x < per ? b - x : per); ++cnt;
+                    }
+                }
+                a = b;
+            }
+            if (fits && cnt) { mc.count = cnt; chunks = cnt; skip_in_table = true; }
+        }
+        if (skip && !skip_in_table) {           // (a block of more runs than the table holds) uniform chunks over everything, the skipped pairs through their thresholds
+            mc = MaskChunks{};
+            chunks = ctx->mask_chunks ? ctx->mask_chunks : (uint32_t)((6500 + fast_segs - 1) / fast_segs);
+            if (chunks > pairs) chunks = pairs;
+            ppc = (pairs + chunks - 1) / chunks;
+            chunks = (pairs + ppc - 1) / ppc;
+            mc.ppc = ppc;
+        }
+    }
+    // Per-pair thresholds travel as kernel arguments into a device table.  A skipped pair that a kernel WITHOUT the chunk table sees
+    // (the generic kernel behind a ragged frame tail or an unaligned layout; the fast kernel of a block with more runs than the table holds)
+    // gets the threshold INT32_MAX: `abs(diff) > thr` is then never true -- a zero row and a zero count, like the table's.
+    const bool generic_runs = fast_segs * 16 < nwords;
+    const int32_t *thr_tab = nullptr, *thr_tab_fast = nullptr;
+    if (thr_floors || (skip && (generic_runs || !skip_in_table))) {
+        // Kernel arguments are captured at launch, so the caller's array is free as soon as we return.
+        if (int r = grow((void **)&ctx->thr_tab, &ctx->thr_tab_cap, (size_t)pairs * 4)) return r;
+        for (uint32_t base = 0; base < pairs; base += ThrChunk::N) {
+            ThrChunk c{};
+            const uint32_t cnt = pairs - base < ThrChunk::N ? pairs - base : ThrChunk::N;
+            for (uint32_t i = 0; i < cnt; ++i) c.v[i] = (skip && skip[base + i]) ? 0x7FFFFFFF : thr_floors ? thr_floors[base + i] : thr_floor;
+            hipLaunchKernelGGL(k_store_thresholds, dim3(1), dim3(ThrChunk::N), 0, ctx->stream, c, ctx->thr_tab + base, cnt);
+        }
+        HIP_TRY(hipGetLastError());
+        thr_tab = ctx->thr_tab;
+        if (thr_floors || (skip && !skip_in_table)) thr_tab_fast = ctx->thr_tab;
+    }
     if (fast_segs) {
         const uint32_t bx = (uint32_t)((fast_segs + WG_WAVES - 1) / WG_WAVES);
         const size_t lds = (size_t)pairs * 4;
-        // temporal chunks: enough waves to fill the chip (>= ~32 per CU) without re-reading much
-        uint32_t chunks = ctx->mask_chunks ? ctx->mask_chunks : (uint32_t)((6500 + fast_segs - 1) / fast_segs);   // 4 at 1080p (measured best)
-        if (chunks > pairs) chunks = pairs;
-        if (chunks < 1) chunks = 1;
-        const uint32_t ppc = (pairs + chunks - 1) / chunks;
-        chunks = (pairs + ppc - 1) / ppc;
         // the pass's tail (counts out, clears) rides in this launch when it is the only mask launch of the pass
         MaskFinish fin{};
         if (gop_tail && !ctx->no_fused_finish && fast_segs * 16 == nwords && !(((uintptr_t)gop_tail->clear_a | (uintptr_t)gop_tail->clear_b) & 15)) {
@@ -855,10 +917,10 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
         }
         LaunchTimer t(ctx, RBF_K_MASK);
 #define RBF_MASK_GOP(S, PB, Z) hipLaunchKernelGGL((k_residual_mask_gop<S, PB, false, Z>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
-                               (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, thr_tab, (uint16_t *)masks_dev, \
-                               mask_stride_bytes / 2, acc, ppc, fin)
+                               (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, thr_tab_fast, (uint16_t *)masks_dev, \
+                               mask_stride_bytes / 2, acc, mc, fin)
 #define RBF_MASK_GOP2(S, PB) do { if (thr0) RBF_MASK_GOP(S, PB, true); else RBF_MASK_GOP(S, PB, false); } while (0)
-        const bool thr0 = !thr_tab && thr_floor == 0 && !(ctx->force_generic_mask_bits);     // "luma changed": no per-pixel extraction
+        const bool thr0 = !thr_tab_fast && thr_floor == 0 && !(ctx->force_generic_mask_bits);     // "luma changed": no per-pixel extraction
         if (sample_bytes == 1 && pixel_stride_bytes == 1) RBF_MASK_GOP2(uint8_t, 1);
         else if (sample_bytes == 1) RBF_MASK_GOP2(uint8_t, 3);
         else if (pixel_stride_bytes == 2) RBF_MASK_GOP2(uint16_t, 2);
@@ -1348,14 +1410,21 @@ int rbf_extract_luma_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_
 // enqueued and the call returns; finish: wait for the counts the mask kernel's last workgroup publishes into pinned host memory, the
 // float64 parameter math, then insert / reduce / query / compaction are enqueued.  One GOP per context is between the two at a time;
 // a caller with several contexts issues begin(k + 1) before finish(k), so that its thread never stands still while a mask kernel runs.
-int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
-                         uint32_t nframes, uint32_t width, uint32_t height,
-                         uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
-                         uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
-                         const rbf_seeds *seeds,
-                         void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
-                         void *filters_dev, uint64_t filter_stride_bytes,
-                         void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev)
+uint64_t rbf_filter_stride_min(uint64_t n)
+{
+    // l = int(p n k / ln 2) with k = log2((1 - p) ln(2)^2 / p) peaks at p = 0.13183 with l = 0.316053 n (improved_video_compressor.py:181-193)
+    const uint64_t lmax = (uint64_t)(0.3161 * (double)n) + 2;
+    return (lmax + 63) / 64 * 8;
+}
+
+int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                          uint32_t nframes, uint32_t width, uint32_t height,
+                          uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                          uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                          const uint8_t *run_starts, const rbf_seeds *seeds,
+                          void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                          void *filters_dev, uint64_t filter_stride_bytes,
+                          void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev)
 {
     if (!ctx) return fail(RBF_EINVAL, "null context");
     if (ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_begin: the previous GOP of this context has not been finished");
@@ -1368,6 +1437,16 @@ int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_st
     const uint64_t n = (uint64_t)width * height;
     if (witness_stride_bytes % 8 || witness_stride_bytes < ((n + 63) / 64) * 8) return fail(RBF_EINVAL, "witness stride too small or misaligned");
     if (filter_stride_bytes % 8) return fail(RBF_EINVAL, "filter stride must be a multiple of 8");
+    // the filters are planned in the second half, from the counts: the stride has to cover whatever the planner can produce for n pixels
+    if (filter_stride_bytes < rbf_filter_stride_min(n))
+        return fail(RBF_EINVAL, "filter stride %llu < rbf_filter_stride_min(%llu) = %llu", (unsigned long long)filter_stride_bytes,
+                    (unsigned long long)n, (unsigned long long)rbf_filter_stride_min(n));
+    bool has_skip = false;
+    if (run_starts) {
+        try { ctx->run_skip.assign(pairs, 0); } catch (...) { return fail(RBF_ENOMEM, "out of host memory for %u pairs", pairs); }
+        for (uint32_t p2 = 0; p2 < pairs; ++p2)
+            if (run_starts[p2 + 1]) { ctx->run_skip[p2] = 1; has_skip = true; }
+    }
     if (pairs > ctx->host_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->ones_pinned) HIP_TRY(hipHostFree(ctx->ones_pinned));
@@ -1405,10 +1484,11 @@ int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_st
         tail.clear_a = nullptr; tail.quads_a = 0;
     }
     if (int r = residual_mask_impl(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
-                                   pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, false, &tail))
+                                   pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, false, &tail,
+                                   has_skip ? ctx->run_skip.data() : nullptr, false))
         return r;
     rbf_ctx::PendingGop &g = ctx->gop;
-    g.active = true; g.token = token; g.n = n; g.pairs = pairs; g.seeds = *seeds;
+    g.active = true; g.token = token; g.n = n; g.pairs = pairs; g.seeds = *seeds; g.has_skip = has_skip;
     g.masks_dev = masks_dev; g.mask_stride_bytes = mask_stride_bytes;
     g.filters_dev = filters_dev; g.filter_stride_bytes = filter_stride_bytes;
     g.witnesses_dev = witnesses_dev; g.witness_stride_bytes = witness_stride_bytes; g.stats_dev = stats_dev;
@@ -1440,14 +1520,50 @@ int rbf_encode_gop_finish(rbf_ctx *ctx, rbf_filter_params *params_out, double *k
         }
         __builtin_ia32_pause();
     }
+    if (g.has_skip)                                               // (zero by construction: a skipped pair's row is written as zeros and never counted)
+        for (uint32_t p = 0; p < g.pairs; ++p) if (ctx->run_skip[p]) ctx->ones_pinned[1 + p] = 0;
     if (int r = rbf_plan_batch(g.n, ctx->ones_pinned + 1, g.pairs, 1, ctx->plan.data(), ctx->plan_k.data())) return r;
-    if (params_out) memcpy(params_out, ctx->plan.data(), (size_t)g.pairs * sizeof(rbf_filter_params));
+    if (params_out) {
+        memcpy(params_out, ctx->plan.data(), (size_t)g.pairs * sizeof(rbf_filter_params));
+        if (g.has_skip) for (uint32_t p = 0; p < g.pairs; ++p) if (ctx->run_skip[p]) params_out[p].floor_k = RBF_PAIR_SKIPPED;
+    }
     if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)g.pairs * sizeof(double));
     ctx->side_ok = true;
     const int rc = encode_batch_impl(ctx, g.masks_dev, g.mask_stride_bytes, g.n, g.pairs, ctx->plan.data(), &g.seeds,
                                      g.filters_dev, g.filter_stride_bytes, g.witnesses_dev, g.witness_stride_bytes, g.stats_dev, true, ctx->ones_pinned + 1);
     ctx->side_ok = false;
     return rc;
+}
+
+int rbf_encode_gop_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                         uint32_t nframes, uint32_t width, uint32_t height,
+                         uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                         uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                         const rbf_seeds *seeds,
+                         void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                         void *filters_dev, uint64_t filter_stride_bytes,
+                         void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev)
+{
+    return rbf_encode_runs_begin(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
+                                 thr_floor, thr_floors, nullptr, seeds, masks_dev, mask_stride_bytes, ones_dev, filters_dev, filter_stride_bytes,
+                                 witnesses_dev, witness_stride_bytes, stats_dev);
+}
+
+int rbf_encode_runs(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,
+                    uint32_t nframes, uint32_t width, uint32_t height,
+                    uint64_t row_pitch_bytes, uint32_t pixel_stride_bytes,
+                    uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
+                    const uint8_t *run_starts, const rbf_seeds *seeds,
+                    void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev,
+                    void *filters_dev, uint64_t filter_stride_bytes,
+                    void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev,
+                    rbf_filter_params *params_out, double *k_out)
+{
+    if (int r = rbf_encode_runs_begin(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
+                                      thr_floor, thr_floors, run_starts, seeds, masks_dev, mask_stride_bytes, ones_dev, filters_dev, filter_stride_bytes,
+                                      witnesses_dev, witness_stride_bytes, stats_dev))
+        return r;
+    return rbf_encode_gop_finish(ctx, params_out, k_out);
 }
 
 int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,

@@ -117,7 +117,7 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
             ha_kept = h.ha;
         } else {
             slot_kept = hash_table_slot(idx);
-            e0 = tv.pos[slot_kept];
+            e0 = tv.pos[slot_kept];                                // (a non-temporal gather was measured in round 5: insert 33 -> 55 us alone, profiles/r05_sweep1.txt)
             tag = tv.tag[idx];
         }
         pending = count;

@@ -853,23 +853,45 @@ struct MaskFinish {
     uint4 *clear_b; uint64_t quads_b;
 };
 
+// The temporal chunks of one launch (blockIdx.y).  count == 0: uniform chunks of `ppc` pairs over the whole block (one run).  Otherwise
+// chunk y reads frames first[y] .. first[y] + pairs[y] and writes the mask rows first[y] .. first[y] + pairs[y] - 1 -- so a block that
+// holds SEVERAL keyframe-delimited runs (rbf_encode_runs) is cut at the keyframes: no chunk reads across one, the pair in front of a
+// keyframe is never diffed.  pairs[y] & MASK_CHUNK_SKIP: those pairs are NOT coded; their rows are written as zeros, nothing is counted.
+constexpr uint32_t MASK_MAX_CHUNKS = 256, MASK_CHUNK_SKIP = 0x8000u;
+struct MaskChunks {
+    uint32_t count, ppc;
+    uint16_t first[MASK_MAX_CHUNKS], pairs[MASK_MAX_CHUNKS];
+};
+
 template <typename SAMPLE, int PIXEL_BYTES, bool NT = false, bool THR0 = false>
 __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
     const uint8_t *__restrict__ frames, uint64_t frame_stride, uint32_t nframes, uint64_t nsegs /* of 1024 px */,
     int32_t thr_all, const int32_t *__restrict__ thr_tab /* nullable: per pair */,
     uint16_t *__restrict__ masks, uint64_t mask_stride_u16, uint64_t *__restrict__ ones,
-    uint32_t pairs_per_chunk, const MaskFinish fin)
+    const MaskChunks chunks, const MaskFinish fin)
 {
-    // blockIdx.y = temporal chunk: frames [f0, f1] (f1 - f0 pairs); chunks overlap by one frame, which
+    // blockIdx.y = temporal chunk: frames [f0, f1] (f1 - f0 pairs); chunks of one run overlap by one frame, which
     // buys gridDim.y times more waves in flight for ~gridDim.y/nframes extra reads
     extern __shared__ uint32_t cnt[];                          // [nframes-1] per-workgroup ones
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t seg = (uint64_t)blockIdx.x * WG_WAVES + wave;
-    const uint32_t f0 = blockIdx.y * pairs_per_chunk;
-    const uint32_t f1 = f0 + pairs_per_chunk < nframes - 1 ? f0 + pairs_per_chunk : nframes - 1;
+    uint32_t f0, f1;
+    bool skipped = false;
+    if (chunks.count) {
+        const uint32_t c = chunks.pairs[blockIdx.y];
+        f0 = chunks.first[blockIdx.y];
+        f1 = f0 + (c & (MASK_CHUNK_SKIP - 1u));
+        skipped = (c & MASK_CHUNK_SKIP) != 0u;
+    } else {
+        f0 = blockIdx.y * chunks.ppc;
+        f1 = f0 + chunks.ppc < nframes - 1 ? f0 + chunks.ppc : nframes - 1;
+    }
     for (uint32_t i = threadIdx.x; i + 1 < nframes; i += WG_THREADS) cnt[i] = 0;
     __syncthreads();
-    if (seg < nsegs && f0 < f1) {
+    if (skipped) {
+        if (seg < nsegs)
+            for (uint32_t f = f0; f < f1; ++f) masks[seg * 64 + lane + (uint64_t)f * mask_stride_u16] = 0;
+    } else if (seg < nsegs && f0 < f1) {
         using LP = LanePixels<SAMPLE, PIXEL_BYTES>;
         const uint64_t lane_off = (seg * 1024 + (uint64_t)lane * 16) * PIXEL_BYTES;
         const uint8_t *p = frames + lane_off;

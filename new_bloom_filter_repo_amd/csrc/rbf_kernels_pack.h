@@ -9,7 +9,9 @@
 //       m  floor_k  threshold  k (float64 bits)  witness_bits  filter_ones  filter_offset  witness_offset
 //   then the payload rows, each 8-byte aligned at its byte offset from the block start:
 //       filter  ceil(m/64)*8 bytes            (m == 0, a frame the reference does not Bloom-code
-//                                              (:215-225): the packed mask itself, ceil(n/64)*8 bytes)
+//                                              (:215-225): the packed mask itself, ceil(n/64)*8 bytes;
+//                                              m == 0 and floor_k == 0xFFFFFFFF, a pair across a keyframe
+//                                              of a multi-run block (rbf_encode_runs): nothing)
 //       witness ceil(witness_bits/64)*8 bytes
 #pragma once
 #include "rbf_device.h"
@@ -19,6 +21,7 @@ namespace rbf {
 constexpr uint64_t RECORD_MAGIC = 0x3130434552464252ull;        // "RBFREC01"
 constexpr int RECORD_HEADER_WORDS = 4, RECORD_ROW_WORDS = 8;
 constexpr int PACK_BATCH = 128;
+constexpr uint32_t PACK_PAIR_SKIPPED = 0xFFFFFFFFu;             // = RBF_PAIR_SKIPPED (include/rbf.h), in the floor_k field of a row with m == 0
 
 struct PackRow {
     uint32_t m, floor_k;
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(256) void k_pack_records(
     if (t < count) {
         wbits = stats[(uint64_t)(first + t) * 4 + 0];
         const uint32_t m = tab.r[t].m;
-        fbytes = ((m ? (uint64_t)m : n) + 63) / 64 * 8;
+        const bool skipped = m == 0 && tab.r[t].floor_k == PACK_PAIR_SKIPPED;    // rbf_encode_runs: a pair across a keyframe has no payload at all
+        fbytes = skipped ? 0 : ((m ? (uint64_t)m : n) + 63) / 64 * 8;
         wbytes = (wbits + 63) / 64 * 8;
     }
     uint64_t incl = fbytes + wbytes;

@@ -75,6 +75,10 @@ def unpack_device_record(buf, n):
     for m, floor_k, thr, kbits, wbits, fones, foff, woff in rows.tolist():
         k = struct.unpack("<d", struct.pack("<Q", kbits))[0]
         rec = {"l": m, "floor_k": floor_k, "threshold": thr, "k": k, "witness_bits": wbits, "filter_ones": fones}
+        if m == 0 and floor_k == 0xFFFFFFFF:       # a pair across a keyframe of a multi-run block (rbf_encode_runs): header row only
+            rec["skipped"] = True
+            out.append(rec)
+            continue
         if m:
             rec["filter"] = raw[foff:foff + (m + 7) // 8].copy()
         else:
@@ -376,6 +380,8 @@ def gather_device_records(records, device, dst=0, group=None, max_records=None):
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    if dist.get_backend(group) == "gloo":          # gloo moves host memory: sizes and payloads are staged through the CPU (what arrives on
+        device = torch.device("cpu")               # dst from a peer is a host tensor then; dst's own records stay where they are)
     damaged = 0
     if records:
         heads = torch.stack([r[:4] for r in records]).cpu().numpy().view(np.uint64)
@@ -408,7 +414,7 @@ def gather_device_records(records, device, dst=0, group=None, max_records=None):
                 inbox[r] = torch.empty(sum(sizes[r]), dtype=torch.uint8, device=device)
                 ops.append(dist.P2POp(dist.irecv, inbox[r], peer(r), group))
     elif used:
-        payload = torch.cat(own)
+        payload = torch.cat(own).to(device)
         ops.append(dist.P2POp(dist.isend, payload, peer(dst), group))
     if ops:
         for w in dist.batch_isend_irecv(ops):

@@ -60,7 +60,7 @@ class GopCoder:
 
     def __init__(self, ctx, width, height, nframes, channels=3, sample_bytes=1, seeds=P.SEEDS_VIDEO,
                  allocator=None, threshold=0.0, out_allocator=None, frames_block=None, adaptive=None,
-                 planar_luma=False, keep_interleaved=True, resident_gops=1, luma_block=None, out_sets=1):
+                 planar_luma=False, keep_interleaved=True, resident_gops=1, luma_block=None, out_sets=1, run_starts=None):
         """allocator: device memory source (default: library-owned); out_allocator: separate source for
         the output record (filters, witnesses, stats); frames_block: share another coder's frame buffer.
         threshold=None with adaptive=(noise_tolerance, min_thr, max_thr): per-frame noise-adaptive
@@ -70,6 +70,9 @@ class GopCoder:
         interleaved frames are then needed by gather_values() only (keep_interleaved=False: luma alone is resident,
         3x more GOPs per byte of HBM).  resident_gops: room for that many GOPs of frames; encode(gop=g) codes the g-th.
         luma_block: share an existing block of Y planes (like frames_block).
+        run_starts: frame indices (within the block of `nframes` frames) that are KEYFRAMES of the caller's stream: each starts a new run,
+        and the pair in front of it is not coded (rbf_encode_runs: several GOPs in ONE launch sequence; results() marks those pairs
+        `skipped`).  The reference codes frame by frame (improved_video_compressor.py:198-266); batching whole GOPs is this package's.
         out_sets: complete sets of per-GOP buffers (masks, ones, filters, witnesses, stats, params) that consecutive encodes rotate over.
         With 2, and the context's OPT_SIDE_COMPACT on, a GOP's witness compaction runs beside the next GOP's mask / insert / reduce
         (include/rbf.h); results(), pack() and gather_values() always refer to the GOP encoded last."""
@@ -83,6 +86,16 @@ class GopCoder:
         self.thr = 0 if threshold is None else threshold_floor(threshold)
         self.adaptive = adaptive if threshold is None else None
         self.thr_tab = None
+        self.run_starts = None
+        self.skipped = [False] * self.pairs
+        if run_starts:
+            self.run_starts = (ctypes.c_uint8 * nframes)()
+            for t in run_starts:
+                if not 0 <= int(t) < nframes:
+                    raise ValueError("run start %r outside the block of %d frames" % (t, nframes))
+                if int(t) > 0:
+                    self.run_starts[int(t)] = 1
+                    self.skipped[int(t) - 1] = True
         base_alloc = allocator or owned_allocator(ctx)
         self._blocks = []
 
@@ -215,9 +228,9 @@ class GopCoder:
             src, fstride, pitch, pstride = self.luma.ptr + gop * self.luma_bytes * self.F, self.luma_bytes, self.W * self.sb, self.sb
         else:
             src, fstride, pitch, pstride = self.frames.ptr + gop * self.frame_bytes * self.F, self.frame_bytes, self.W * self.C * self.sb, self.C * self.sb
-        nat.check(nat.lib().rbf_encode_gop_begin(
+        nat.check(nat.lib().rbf_encode_runs_begin(
             self.ctx.handle, src, fstride, self.F, self.W, self.H,
-            pitch, pstride, self.sb, self.thr, self.thr_tab, ctypes.byref(self.seeds),
+            pitch, pstride, self.sb, self.thr, self.thr_tab, self.run_starts, ctypes.byref(self.seeds),
             self.masks.ptr, self.mask_stride, self.ones.ptr,
             self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr))
 
@@ -285,6 +298,10 @@ class GopCoder:
         ones = self.ones.numpy(self.ctx)[:8 * self.pairs].view(np.uint64)
         out = []
         for f in range(self.pairs):
+            if self.skipped[f]:                        # the pair across a keyframe: not coded (its mask row is zeros, ones 0)
+                assert int(self.params[f].m) == 0 and int(self.params[f].floor_k) == nat.PAIR_SKIPPED and int(ones[f]) == 0
+                out.append({"skipped": True, "ones": 0, "k": 0.0, "l": 0, "witness_bits": int(stats[f, 0]), "mask": masks[f, :(self.n + 7) // 8].copy()})
+                continue
             m = int(self.params[f].m)
             wb = int(stats[f, 0])
             out.append({"mask": masks[f, :(self.n + 7) // 8].copy(), "ones": int(ones[f]), "k": float(self.k[f]), "l": m,

@@ -31,10 +31,12 @@ class ImprovedVideoCompressor:
     def __init__(self, noise_tolerance=10.0, keyframe_interval=30, min_diff_threshold=3.0,
                  max_diff_threshold=30.0, bloom_threshold_modifier=1.0, batch_size=30,
                  num_threads=None, use_direct_yuv=False, verbose=False, ctx=None, inter_frames=None,
-                 gop_batching=True):
-        """Reference signature (improved_video_compressor.py:318-327) plus three keyword-only extras:
+                 gop_batching=True, block_frames=None):
+        """Reference signature (improved_video_compressor.py:318-327) plus four keyword-only extras:
         ctx (library context), gop_batching (False: one set of C-ABI calls per inter-frame instead of one
-        per GOP; both write the same bytes) and inter_frames -- None (default): YUV input is coded with
+        per block; both write the same bytes), block_frames (consecutive frames handed to the GPU in ONE
+        rbf_encode_runs launch sequence -- several GOPs, cut at the keyframes; default 4 GOPs, at most 128
+        frames) and inter_frames -- None (default): YUV input is coded with
         Bloom inter-frames ('BFV2' container, which the reference's decompress_video rejects), anything
         else as keyframes; False: always the reference's all-keyframe 'BFVC' container, readable by the
         reference; True: inter-frames for every colour space (lossless fallback to keyframes per frame)."""
@@ -47,12 +49,14 @@ class ImprovedVideoCompressor:
         self.batch_size = batch_size
         self.num_threads = max(1, num_threads or min(32, os.cpu_count() or 1))     # zlib of keyframes / changed values
         self.gop_batching = bool(gop_batching)
+        self.block_frames = max(2, int(block_frames)) if block_frames else min(128, max(2, 4 * self.keyframe_interval))
         self.use_direct_yuv = use_direct_yuv
         self.verbose = verbose
         self.compressor = FixedVideoCompressor(verbose=verbose)
         self._ctx = ctx
         self._inter = None
         self.last_compressed_frames = None       # [(type, record bytes)] of the last compress_video call
+        self.last_timing = None                  # seconds per stage of the last encode_range (bench.py's e2e_surface leg)
         self._gop_coder, self._gop_key = None, None
 
     def close(self):
@@ -94,14 +98,18 @@ class ImprovedVideoCompressor:
         record, _ = self.inter._compress_frame_differences(mask, values)
         return struct.pack("<B", b.dtype.itemsize) + record
 
-    def _encode_gop(self, seg, pool):
-        """Inter-frame records of one GOP in one pass over the GPU: seg[0] is only read (the keyframe, or a
-        shard's halo frame), seg[1:] are coded against their predecessor.  One upload, rbf_encode_gop, one batched gather of the changed
-        values (with the count of changes the luma mask cannot carry); zlib runs in `pool`.
-        Returns a list of futures / None per inter-frame (None = needs a keyframe), or None when the
-        GOP cannot be batched (mixed shapes or dtypes)."""
+    def _encode_block(self, seg, pool, run_starts=()):
+        """Inter-frame records of one block of consecutive frames in one pass over the GPU: seg[0] is only read (a keyframe, or a
+        shard's halo frame), every other frame is coded against its predecessor -- except the frames named in `run_starts` (indices
+        into seg), which are keyframes of the stream: they start a new run and the pair in front of them is not coded.  One upload,
+        ONE rbf_encode_runs launch sequence for all the runs, one batched gather of the changed values (with the count of changes the
+        luma mask cannot carry); zlib runs in `pool`.
+        Returns a list of futures / None per pair (None = needs a keyframe, or is one), or None when the block cannot be batched
+        (mixed shapes or dtypes)."""
         from .gop import GopCoder
         from . import _native as nat
+        tm = self.last_timing if self.last_timing is not None else {}
+        t0 = time.perf_counter()
         data = [frame_data(f) for f in seg]
         a = data[0]
         if a.dtype not in (np.uint8, np.uint16) or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] < 3):
@@ -113,21 +121,31 @@ class ImprovedVideoCompressor:
         if C > 4:                                # rbf_gather_values_batch carries at most 4 samples per pixel
             return [None] * (len(seg) - 1)
         ctx = self._ctx or nat.default_context()
-        key = (W, H, len(seg), C, a.dtype.itemsize)
+        key = (W, H, len(seg), C, a.dtype.itemsize, tuple(run_starts))
         if self._gop_key != key:
             if self._gop_coder is not None:
                 self._gop_coder.close()
-            self._gop_coder, self._gop_key = GopCoder(ctx, W, H, len(seg), channels=C, sample_bytes=a.dtype.itemsize), key
+            self._gop_coder, self._gop_key = GopCoder(ctx, W, H, len(seg), channels=C, sample_bytes=a.dtype.itemsize, run_starts=list(run_starts)), key
         coder = self._gop_coder
-        coder.load_frames(np.stack(data))
+        block = np.stack(data)
+        t1 = time.perf_counter()
+        coder.load_frames(block)
+        ctx.sync()
+        t2 = time.perf_counter()
         coder.encode()
+        ctx.sync()
+        t3 = time.perf_counter()
         res = coder.results()
+        t4 = time.perf_counter()
         values, uncovered = coder.gather_values(check_uncovered=True)
+        t5 = time.perf_counter()
+        for name, dt in (("stack", t1 - t0), ("upload", t2 - t1), ("gpu_encode", t3 - t2), ("download_rows", t4 - t3), ("value_gather", t5 - t4)):
+            tm[name] = tm.get(name, 0.0) + dt
         n = H * W
         inter = self.inter
         out = []
         for f, r in enumerate(res):
-            if int(uncovered[f]):                # chroma moved where luma did not: not representable
+            if r.get("skipped") or int(uncovered[f]):    # the pair in front of a keyframe; or chroma moved where luma did not: not representable
                 out.append(None)
                 continue
             p = np.uint64(r["ones"]) / n
@@ -150,8 +168,12 @@ class ImprovedVideoCompressor:
     def encode_range(self, frames, first_index, start, stop, inter_frames=True):
         """[(type, record)] for the frames with global indices [start, stop); frames[i] is global frame
         first_index + i (a shard passes its halo frame too, dist.halo_start).  Frame t is a keyframe iff
-        t % keyframe_interval == 0; the inter-frames between two keyframes are coded as one GOP."""
+        t % keyframe_interval == 0; the inter-frames are coded in blocks of up to `block_frames` consecutive frames --
+        several GOPs per block, ONE launch sequence on the GPU per block, cut at the keyframes."""
         records = {}
+        I = self.keyframe_interval
+        self.last_timing = tm = {}
+        t_all = time.perf_counter()
         with ThreadPoolExecutor(self.num_threads) as pool:
             pending = {}
 
@@ -159,27 +181,35 @@ class ImprovedVideoCompressor:
                 pending[t] = (KEY, pool.submit(self.compressor.compress_frame, frames[t - first_index]))
             t = start
             while t < stop:
-                if not inter_frames or t % self.keyframe_interval == 0 or t - 1 < first_index:
+                if not inter_frames or t % I == 0 or t - 1 < first_index:
                     key(t)
                     t += 1
                     continue
-                end = min(stop, (t // self.keyframe_interval + 1) * self.keyframe_interval)
-                seg = frames[t - 1 - first_index:end - first_index]          # predecessor + the run t..end-1
-                inter = self._encode_gop(seg, pool) if self.gop_batching else None
+                end = min(stop, t - 1 + self.block_frames)                   # the block reads frames t-1 .. end-1
+                seg = frames[t - 1 - first_index:end - first_index]          # predecessor + the frames t..end-1
+                starts = [u - (t - 1) for u in range(t, end) if u % I == 0]  # keyframes inside the block: new runs
+                inter = self._encode_block(seg, pool, starts) if self.gop_batching else None
                 for j in range(1, len(seg)):
+                    u = t - 1 + j
+                    if u % I == 0:
+                        key(u)
+                        continue
                     fut = inter[j - 1] if inter is not None else None
                     if inter is None:
                         rec = self._encode_inter(seg[j - 1], seg[j])
                         if rec is not None:
-                            records[t - 1 + j] = (INTER, rec)
+                            records[u] = (INTER, rec)
                             continue
                     if fut is not None:
-                        pending[t - 1 + j] = (INTER, fut)
+                        pending[u] = (INTER, fut)
                     else:
-                        key(t - 1 + j)
+                        key(u)
                 t = end
+            t_wait = time.perf_counter()
             for u, (ty, fut) in pending.items():
                 records[u] = (ty, fut.result())
+            tm["zlib_wait"] = time.perf_counter() - t_wait                   # what the host threads' zlib-9 still owed after the last block left the GPU
+        tm["total"] = time.perf_counter() - t_all
         return [records[u] for u in range(start, stop)]
 
     def compress_video(self, frames, output_path=None, input_color_space="BGR"):

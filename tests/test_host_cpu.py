@@ -23,7 +23,7 @@ def test_abi_header_matches_binding_and_library():
     lib = nat.lib()                       # loads librbf_hip.so (needs no GPU)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rbf_version() == 3
+    assert lib.rbf_version() == 4
     assert isinstance(lib.rbf_last_error(), bytes)
     # same number of parameters in the header and in the ctypes prototypes
     clean = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
@@ -218,7 +218,7 @@ def test_c_consumer_links_and_agrees(tmp_path):
     out = subprocess.run([exe] + [str(v) for c in cases for v in c], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
     lines = out.stdout.strip().splitlines()
-    assert lines[0] == "version 3" and lines[-1].startswith("error ") and len(lines[-1]) > 8
+    assert lines[0] == "version 4" and lines[-1].startswith("error ") and len(lines[-1]) > 8
     assert lines[-2] == "record_max %d" % (8 * (4 + 8 * 29) + 29 * 2 * ((2073600 + 63) // 64 * 8))
     for (n, ones), line in zip(cases, lines[1:]):
         f = line.split()
