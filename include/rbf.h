@@ -79,10 +79,6 @@ int rbf_device_count(int *count);
 int rbf_ctx_create(int device, void *hip_stream, rbf_ctx **out);
 int rbf_ctx_destroy(rbf_ctx *ctx);
 int rbf_ctx_sync(rbf_ctx *ctx);                       /* blocks until the stream is idle */
-/* Makes the context's stream wait (on the device, without blocking the host) for everything the library has enqueued BESIDE it --
- * i.e. an outstanding witness compaction under RBF_OPT_SIDE_COMPACT.  Call it before enqueueing non-library work on the same stream
- * that reads a GOP's outputs; every library call on the context (but the two halves of rbf_encode_gop) does it by itself. */
-int rbf_ctx_flush(rbf_ctx *ctx);
 
 /* Device-memory helpers so host code needs no other GPU runtime. */
 int rbf_malloc(rbf_ctx *ctx, size_t bytes, void **out_dev);
@@ -135,21 +131,10 @@ int rbf_ctx_force_generic(rbf_ctx *ctx, int on);
  * separate k_finish_ones launch (default: inside the GOP mask kernel whenever that kernel covers the whole frame).  (Option 1 of ABI 2,
  * the round-2 query kernel, is gone with that kernel: RBF_EINVAL.) */
 #define RBF_OPT_SEPARATE_FINISH 2
-/* RBF_OPT_DEBUG_SKIP (diagnostic, value = bit mask of RBF_K_INSERT / RBF_K_REDUCE / RBF_K_QUERY / RBF_K_STITCH): the encode path does not
- * launch those kernels.  RESULTS ARE WRONG; it exists to measure what each kernel costs the overlapped step (bench.py --skip-kernels). */
-#define RBF_OPT_DEBUG_SKIP 99
-/* RBF_OPT_SIDE_COMPACT (0 / 1): 1 = the witness compaction of rbf_encode_gop(_finish) runs on a second, library-owned stream behind
- * the query kernel, and the context's stream does not wait for it: the NEXT GOP's mask stage, parameter math, insert and reduce run
- * beside it (the compaction costs a four-pipeline step its whole 16 us otherwise: profiles/r04_step_sensitivity.txt).  A GOP's witness
- * rows and stats are then complete after the next library call on the context (rbf_ctx_sync, rbf_ctx_flush, rbf_pack_records, ...);
- * the next rbf_encode_gop_begin runs beside the compaction only if its masks / witnesses / stats buffers are not the previous GOP's
- * (a caller that alternates two output sets), and waits for it otherwise. */
-#define RBF_OPT_SIDE_COMPACT 3
-/* Tuning knobs of the single-tile insert (k_insert_tab).  RBF_OPT_INSERT_SLICES: mask slices (= partial filters) per frame, 0 = auto.
- * RBF_OPT_INSERT_GROUPED (0 / 1): 1 = batches of more than 32 coded frames are inserted in groups of 32 frames, one launch each (the
- * round-4 form), instead of one launch for the whole batch. */
+/* RBF_OPT_INSERT_SLICES (tuning): mask slices (= partial filters) per frame of the single-tile insert kernel; 0 = auto (about one
+ * workgroup per CU for the whole batch).  (Options 3, 5 and 99 of ABI 3 / early ABI 4 -- the side-stream compaction, the grouped insert
+ * and the kernel-skipping diagnostic -- are gone: RBF_EINVAL.) */
 #define RBF_OPT_INSERT_SLICES 4
-#define RBF_OPT_INSERT_GROUPED 5
 int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value);
 int rbf_timing_reset(rbf_ctx *ctx);
 int rbf_timing_read(rbf_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);

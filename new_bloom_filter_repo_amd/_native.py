@@ -19,8 +19,7 @@ K_MASK, K_INSERT, K_QUERY, K_STITCH, K_EXPAND, K_GATHER, K_SCATTER, K_INDEX, K_R
 KERNEL_NAMES = ["mask", "insert", "query", "stitch", "expand", "gather", "scatter", "index", "reduce", "scan", "noise", "pack", "hashtab"]
 STATS_PER_FRAME = 4
 PAIR_SKIPPED = 0xFFFFFFFF                 # params[p].floor_k of a pair across a keyframe (rbf_encode_runs)
-OPT_INSERT_SLICES, OPT_INSERT_GROUPED = 4, 5
-OPT_SEPARATE_FINISH, OPT_SIDE_COMPACT, OPT_DEBUG_SKIP = 2, 3, 99    # rbf_ctx_option keys (include/rbf.h); key 1 (round 3: the round-2 query kernel) is gone with that kernel
+OPT_SEPARATE_FINISH, OPT_INSERT_SLICES = 2, 4    # rbf_ctx_option keys (include/rbf.h); keys 1, 3, 5 and 99 of earlier ABIs are gone with what they selected
 
 
 class FilterParams(ctypes.Structure):
@@ -46,7 +45,6 @@ _PROTOS = {
     "rbf_ctx_create": (_int, [_int, _vp, ctypes.POINTER(_vp)]),
     "rbf_ctx_destroy": (_int, [_vp]),
     "rbf_ctx_sync": (_int, [_vp]),
-    "rbf_ctx_flush": (_int, [_vp]),
     "rbf_malloc": (_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "rbf_free": (_int, [_vp, _vp]),
     "rbf_memset": (_int, [_vp, _vp, _int, ctypes.c_size_t]),
@@ -198,10 +196,6 @@ class Context:
 
     def sync(self):
         check(lib().rbf_ctx_sync(self.handle))
-
-    def flush(self):
-        """The stream waits (device side) for what the library enqueued beside it (OPT_SIDE_COMPACT)."""
-        check(lib().rbf_ctx_flush(self.handle))
 
     def close(self):
         if self.handle:

@@ -61,21 +61,8 @@ struct rbf_ctx {
     int no_table_rewrite = 0;        // 1 = the query kernel never rewrites the hash table, sole holder or not
     uint64_t *ones_acc = nullptr;    size_t ones_acc_cap = 0;     // where the mask kernels count; k_finish_ones hands the counts out and re-zeroes it
     uint32_t *mask_ticket = nullptr;                              // the fused tail of the GOP mask kernel: workgroups done so far (zero between launches)
-    // RBF_OPT_SIDE_COMPACT: the witness compaction of a GOP runs on a second stream, behind an event, so that the context's main stream
-    // goes on with the NEXT GOP's mask stage, parameter math, insert and reduce meanwhile; the main stream waits for it only in front of
-    // the next query launch (which overwrites the pass bytes the compaction reads) or when another call needs its results.
-    int side_compact = 0;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_query = nullptr, ev_compact = nullptr;
-    bool side_ok = false;            // inside rbf_encode_gop_finish: this launch sequence may leave its compaction outstanding
-    bool side_pending = false;       // a compaction has been enqueued on side_stream and the main stream has not waited for it yet
-    const void *side_masks = nullptr; size_t side_masks_bytes = 0;            // what that compaction reads ...
-    const void *side_wit = nullptr; size_t side_wit_bytes = 0;                // ... and writes (caller-owned buffers)
-    const void *side_stats = nullptr; size_t side_stats_bytes = 0;
-    uint32_t debug_skip = 0;                                      // RBF_OPT_DEBUG_SKIP: bit RBF_K_* = do not launch that kernel of the encode path (WRONG results: sensitivity measurements only)
     int no_fused_finish = 0;                                      // 1 = always the separate k_finish_ones launch (rbf_ctx_option RBF_OPT_SEPARATE_FINISH)
     uint32_t insert_slices = 0;                                   // tuning (RBF_OPT_INSERT_SLICES): mask slices per frame of the single-tile insert, 0 = auto
-    int insert_grouped = 0;                                       // tuning (RBF_OPT_INSERT_GROUPED): 1 = large batches are inserted in groups of 32 frames (round 4)
     bool ones_acc_dirty = false;     // a call failed between the mask kernels and k_finish_ones
     uint32_t *qimage = nullptr;      size_t qimage_cap = 0;       // probe image of the batch's filters (FP64 query kernel)
     int32_t *thr_tab = nullptr;      size_t thr_tab_cap = 0;      // per-pair thresholds of the mask kernels
@@ -124,32 +111,17 @@ static int grow(void **ptr, size_t *cap, size_t bytes)
     return RBF_OK;
 }
 
-// The main stream waits (on the device) for the compaction that runs on the side stream, if one is outstanding.
-static int join_side(rbf_ctx *ctx)
-{
-    if (!ctx->side_pending) return RBF_OK;
-    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_compact, 0));
-    ctx->side_pending = false;
-    return RBF_OK;
-}
-static inline bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb)
-{
-    return a && b && (const char *)a < (const char *)b + nb && (const char *)b < (const char *)a + na;
-}
-
-// Every entry point starts here.  `join`: the call may touch what an outstanding side-stream compaction reads or writes (everything
-// but the first half of rbf_encode_gop, which checks its own buffers against the compaction's).
-static int set_device(rbf_ctx *ctx, bool join = true)
+// Every entry point starts here.
+static int set_device(rbf_ctx *ctx)
 {
     if (!ctx) return fail(RBF_EINVAL, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
-    if (join) return join_side(ctx);
     return RBF_OK;
 }
 
 struct LaunchTimer {
     rbf_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;
-    LaunchTimer(rbf_ctx *ctx, int kid, hipStream_t stream = nullptr) : c(ctx), id(kid), on((ctx->timing >> kid) & 1u), st(stream ? stream : ctx->stream)
+    LaunchTimer(rbf_ctx *ctx, int kid) : c(ctx), id(kid), on((ctx->timing >> kid) & 1u), st(ctx->stream)
     {
         if (!on) return;
         auto get = [&]() {
@@ -246,7 +218,6 @@ static int drain_timing(rbf_ctx *ctx)
 {
     if (ctx->pending.empty()) return RBF_OK;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
     for (auto &t : ctx->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
@@ -305,9 +276,6 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (!ctx) return RBF_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
-    if (ctx->ev_query) (void)hipEventDestroy(ctx->ev_query);
-    if (ctx->ev_compact) (void)hipEventDestroy(ctx->ev_compact);
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : ctx->pool) (void)hipEventDestroy(e);
     if (ctx->ones_pinned) (void)hipHostFree(ctx->ones_pinned);
@@ -333,11 +301,6 @@ int rbf_ctx_sync(rbf_ctx *ctx)
     if (int r = set_device(ctx)) return r;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RBF_OK;
-}
-
-int rbf_ctx_flush(rbf_ctx *ctx)
-{
-    return set_device(ctx);                       // joins whatever the library has outstanding beside the context's stream
 }
 
 int rbf_malloc(rbf_ctx *ctx, size_t bytes, void **out_dev)
@@ -419,19 +382,7 @@ int rbf_ctx_option(rbf_ctx *ctx, int option, int64_t value)
     if (!ctx) return fail(RBF_EINVAL, "null context");
     switch (option) {
     case RBF_OPT_SEPARATE_FINISH: ctx->no_fused_finish = value ? 1 : 0; return RBF_OK;
-    case RBF_OPT_DEBUG_SKIP: ctx->debug_skip = (uint32_t)value; return RBF_OK;
     case RBF_OPT_INSERT_SLICES: ctx->insert_slices = value < 0 ? 0u : (uint32_t)value; return RBF_OK;
-    case RBF_OPT_INSERT_GROUPED: ctx->insert_grouped = value ? 1 : 0; return RBF_OK;
-    case RBF_OPT_SIDE_COMPACT: {
-        if (int r = set_device(ctx)) return r;                    // (joins an outstanding compaction before the mode changes)
-        if (value && !ctx->side_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_query, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_compact, hipEventDisableTiming));
-        }
-        ctx->side_compact = value ? 1 : 0;
-        return RBF_OK;
-    }
     default: return fail(RBF_EINVAL, "unknown option %d", option);
     }
 }
@@ -648,15 +599,17 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     uint32_t base = units / group;
     if (base < 1) base = 1;
     if (base > 32) base = 32;
-    // A batch of several GOPs (rbf_encode_runs: up to 128 coded frames) whose filters are single tiles goes through ONE insert launch
-    // -- the CUs take the next (frame, slice) workgroup as they come free, no drain between groups of 32 frames -- with
-    // `insert_slices` slices per frame (RBF_OPT_INSERT_SLICES; 0 = auto).
-    if (p.insert_tiles == 1 && !p.insert_two_phase && active > group && !ctx->insert_grouped) {
+    // Single-tile filters (every frame size up to 1080p): ONE insert launch for the whole batch -- up to 128 coded frames when several
+    // GOPs ride in one block (rbf_encode_runs) -- of about one workgroup per CU: the largest power of two of slices per frame that fits.
+    // An insert workgroup costs its filter tile twice over (zeroed, then written out as a partial the reduce kernel reads back), so fewer,
+    // longer workgroups win: measured on 4 x 29 frames of 1080p (profiles/r05_sweep1.txt, r05_sweep2.txt) 8 slices in groups of 32 frames
+    // (round 4) 155 us, 8 slices in one launch 135, 4 slices 117, 2 slices 115, 1 slice 212 (116 of 256 CUs), 3 slices 170 (a slice no
+    // longer stays on one XCD); 2 x 29 frames: 4 slices 58, 2 slices 102; 29 frames: 8 slices 33, 4 slices 54, 16 slices 42.
+    if (p.insert_tiles == 1 && !p.insert_two_phase && active) {
         group = active;
-        base = ctx->insert_slices ? ctx->insert_slices : INSERT_SLICES;
-        if (base > 32) base = 32;
-    } else if (ctx->insert_slices && p.insert_tiles == 1 && !p.insert_two_phase) {
-        base = ctx->insert_slices > 32 ? 32 : ctx->insert_slices;
+        base = 1;
+        while (base * 2 * active <= units && base < 32) base *= 2;
+        if (ctx->insert_slices) base = ctx->insert_slices > 32 ? 32 : ctx->insert_slices;      // RBF_OPT_INSERT_SLICES (tuning)
     }
     p.insert_group = group;
     p.S = base;
@@ -804,10 +757,9 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
                               uint32_t sample_bytes, int32_t thr_floor, const int32_t *thr_floors,
                               void *masks_dev, uint64_t mask_stride_bytes, uint64_t *ones_dev, bool finish,
                               const MaskFinish *gop_tail = nullptr /* rbf_encode_gop: publish + clears; fused into the mask kernel when it covers the frame */,
-                              const uint8_t *skip = nullptr /* rbf_encode_runs: skip[p] != 0 = pair p is not coded (zero row, zero count) */,
-                              bool join = true /* false: rbf_encode_runs_begin has decided whether an outstanding side-stream compaction must be waited for */)
+                              const uint8_t *skip = nullptr /* rbf_encode_runs: skip[p] != 0 = pair p is not coded (zero row, zero count) */)
 {
-    if (int r = set_device(ctx, join)) return r;
+    if (int r = set_device(ctx)) return r;
     if (int r = check_mask_args(frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
                                 thr_floors, masks_dev, mask_stride_bytes, ones_dev)) return r;
     const uint64_t n = (uint64_t)width * height;
@@ -1001,9 +953,13 @@ static int launch_query(rbf_ctx *ctx, const Plan &pl, uint64_t n, uint32_t nfram
         uint32_t nactive; uint64_t empty[2];
         const FrameTable stab = query_table_s64(tab, nframes, &nactive, empty);
         if (quiet_passthrough) empty[0] = empty[1] = 0;
-        bool general = false;                                       // a coded frame whose floor(k*) is not 1 or 2: the kernel with every case compiled in
-        for (uint32_t f = 0; f < nframes; ++f) general = general || (tab.f[f].m && (tab.f[f].floor_k < 1 || tab.f[f].floor_k > 2));
-        auto qkern = general ? k_query_s64t<true> : k_query_s64t<false>;
+        int mode = 0;                                               // 0: every coded frame has floor(k*) 1 or 2; 1: 0, 1 or 2; 2: anything (all frames walk their probes per tile)
+        for (uint32_t f = 0; f < nframes; ++f) {
+            if (!tab.f[f].m) continue;
+            if (tab.f[f].floor_k > 2) mode = 2;
+            else if (tab.f[f].floor_k == 0 && mode < 1) mode = 1;
+        }
+        auto qkern = mode == 2 ? k_query_s64t<2> : mode == 1 ? k_query_s64t<1> : k_query_s64t<0>;
         if (int r = allow_big_lds((const void *)qkern)) return r;
         hipLaunchKernelGGL(qkern, dim3((uint32_t)bx), dim3(QL_THREADS), s64t_lds_bytes(pl.query_tile_words), ctx->stream,
                            n, nactive, stab, sd, (const uint32_t *)filters_dev, filter_stride_bytes / 4, pl.query_tile_words,
@@ -1165,7 +1121,6 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
             f0 = f;
             if (!per_tile) continue;
             LaunchTimer t(ctx, RBF_K_INSERT);
-            if (ctx->debug_skip & (1u << RBF_K_INSERT)) continue;
             if (two_phase) {
                 FrameTable rtab = tab;
                 uint64_t first = 0;
@@ -1185,14 +1140,12 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         {
             LaunchTimer t(ctx, RBF_K_REDUCE);
             const uint64_t words = filter_stride_bytes / 4;
-            if (!(ctx->debug_skip & (1u << RBF_K_REDUCE))) {
             const uint32_t vec_ok = (words % 4 == 0 && ((uintptr_t)filters_dev % 16) == 0) ? 1u : 0u;
             uint32_t bx = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx < 1) bx = 1;
             hipLaunchKernelGGL(k_filter_reduce, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                                (const uint32_t *)ctx->partials, part_stride, pl.S, pl.slices, tab, (uint32_t *)filters_dev, words, stats_dev, vec_ok,
                                image, (uint64_t)pl.image_stride_words);
-            }
         }
     } else {
         HIP_TRY(hipMemsetAsync(filters_dev, 0, (size_t)nframes * filter_stride_bytes, ctx->stream));
@@ -1218,33 +1171,16 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         }
     }
     // ---- query: pass word of every 64 positions + per-segment pass counts
-    if (int r = join_side(ctx)) return r;         // (an outstanding compaction still reads the pass bytes and segment counts the query is about to overwrite)
-    if (!(ctx->debug_skip & (1u << RBF_K_QUERY)))
     if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, want_image, pl.insert_tab, quiet_passthrough)) return r;
     // ---- witness: pext(mask, pass) of every word lands at its bit offset (scan fused in)
-    if (compact && !(ctx->debug_skip & (1u << RBF_K_STITCH))) {
+    if (compact) {
         const uint64_t words = pl.nseg * pl.words_per_seg;
         uint64_t bx = (words + WG_THREADS - 1) / WG_THREADS;
         if (bx < 1) bx = 1;
-        hipStream_t cs = ctx->stream;
-        if (ctx->side_ok && ctx->side_compact) {                       // behind the query, on the side stream
-            HIP_TRY(hipEventRecord(ctx->ev_query, ctx->stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->side_stream, ctx->ev_query, 0));
-            cs = ctx->side_stream;
-        }
-        {
-            LaunchTimer t(ctx, RBF_K_STITCH, cs);
-            hipLaunchKernelGGL(k_compact_witness, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, cs,
-                               ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
-                               (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4, stats_dev);
-        }
-        if (cs != ctx->stream) {
-            HIP_TRY(hipEventRecord(ctx->ev_compact, cs));
-            ctx->side_pending = true;
-            ctx->side_masks = masks_dev; ctx->side_masks_bytes = (size_t)nframes * mask_stride_bytes;
-            ctx->side_wit = witnesses_dev; ctx->side_wit_bytes = (size_t)nframes * witness_stride_bytes;
-            ctx->side_stats = stats_dev; ctx->side_stats_bytes = (size_t)nframes * RBF_STATS_PER_FRAME * 8;
-        }
+        LaunchTimer t(ctx, RBF_K_STITCH);
+        hipLaunchKernelGGL(k_compact_witness, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+                           ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
+                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4, stats_dev);
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;
@@ -1294,7 +1230,7 @@ static int encode_batch_impl(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
                              void *witnesses_dev, uint64_t witness_stride_bytes,
                              uint64_t *stats_dev, bool outputs_zeroed, const uint64_t *ones_host = nullptr)
 {
-    if (int r = set_device(ctx, !ctx->side_ok)) return r;
+    if (int r = set_device(ctx)) return r;
     if (!masks_dev || !params || !seeds || !filters_dev || !witnesses_dev || !stats_dev) return fail(RBF_EINVAL, "null pointer");
     if (int r = check_frame_geometry(n, nframes, mask_stride_bytes)) return r;
     if (int r = check_filter_strides(params, nframes, filter_stride_bytes)) return r;
@@ -1429,7 +1365,7 @@ int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
     if (!ctx) return fail(RBF_EINVAL, "null context");
     if (ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_begin: the previous GOP of this context has not been finished");
     if (!filters_dev || !witnesses_dev || !stats_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
-    if (int r = set_device(ctx, false)) return r;
+    if (int r = set_device(ctx)) return r;
     // nothing below this block has run, and nothing of the caller's has been touched, when an argument is bad
     if (int r = check_mask_args(frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes, pixel_stride_bytes, sample_bytes,
                                 thr_floors, masks_dev, mask_stride_bytes, ones_dev)) return r;
@@ -1465,15 +1401,6 @@ int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
     // The GPU publishes the counts straight into host memory and clears the output buffers in the same pass -- inside the mask
     // kernel when it covers the whole frame, else through k_finish_ones -- so the only thing between the mask kernel and the
     // Bloom kernels is the host's float64 parameter math.
-    // An outstanding side-stream compaction (RBF_OPT_SIDE_COMPACT) reads the PREVIOUS GOP's masks and writes its witness rows and stats:
-    // this GOP's mask stage may start beside it only when it touches none of those (a caller that alternates two output sets), else
-    // it waits -- correct either way.
-    if (ctx->side_pending &&
-        (ranges_overlap(masks_dev, (size_t)pairs * mask_stride_bytes, ctx->side_masks, ctx->side_masks_bytes) ||
-         ranges_overlap(witnesses_dev, (size_t)pairs * witness_stride_bytes, ctx->side_wit, ctx->side_wit_bytes) ||
-         ranges_overlap(stats_dev, (size_t)pairs * RBF_STATS_PER_FRAME * 8, ctx->side_stats, ctx->side_stats_bytes) ||
-         ranges_overlap(witnesses_dev, (size_t)pairs * witness_stride_bytes, ctx->side_masks, ctx->side_masks_bytes)))
-        if (int r = join_side(ctx)) return r;
     const uint64_t token = ++ctx->publish_token;
     MaskFinish tail{};
     tail.host_block = ctx->ones_mapped_dev; tail.token = token;
@@ -1485,7 +1412,7 @@ int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
     }
     if (int r = residual_mask_impl(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
                                    pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, false, &tail,
-                                   has_skip ? ctx->run_skip.data() : nullptr, false))
+                                   has_skip ? ctx->run_skip.data() : nullptr))
         return r;
     rbf_ctx::PendingGop &g = ctx->gop;
     g.active = true; g.token = token; g.n = n; g.pairs = pairs; g.seeds = *seeds; g.has_skip = has_skip;
@@ -1507,7 +1434,7 @@ int rbf_encode_gop_finish(rbf_ctx *ctx, rbf_filter_params *params_out, double *k
 {
     if (!ctx) return fail(RBF_EINVAL, "null context");
     if (!ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_finish: no GOP has been begun on this context");
-    if (int r = set_device(ctx, false)) return r;
+    if (int r = set_device(ctx)) return r;
     const rbf_ctx::PendingGop g = ctx->gop;
     ctx->gop.active = false;                                      // whatever happens below, the context is free for the next begin
     volatile uint64_t *flag = ctx->ones_pinned;
@@ -1528,10 +1455,8 @@ int rbf_encode_gop_finish(rbf_ctx *ctx, rbf_filter_params *params_out, double *k
         if (g.has_skip) for (uint32_t p = 0; p < g.pairs; ++p) if (ctx->run_skip[p]) params_out[p].floor_k = RBF_PAIR_SKIPPED;
     }
     if (k_out) memcpy(k_out, ctx->plan_k.data(), (size_t)g.pairs * sizeof(double));
-    ctx->side_ok = true;
     const int rc = encode_batch_impl(ctx, g.masks_dev, g.mask_stride_bytes, g.n, g.pairs, ctx->plan.data(), &g.seeds,
                                      g.filters_dev, g.filter_stride_bytes, g.witnesses_dev, g.witness_stride_bytes, g.stats_dev, true, ctx->ones_pinned + 1);
-    ctx->side_ok = false;
     return rc;
 }
 

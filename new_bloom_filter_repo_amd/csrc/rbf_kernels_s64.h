@@ -340,12 +340,16 @@ __device__ __forceinline__ uint32_t tiled_frame(const double (&hd1)[QL_P], const
 }
 
 // (120 registers: one wave of the mask / compaction kernels per SIMD runs underneath it, as under k_query_u64)
-// GENERAL = false: every coded frame of the launch has floor(k*) 1 or 2 (the host checks) -- the kernel of BASELINE config 4 and of
-// every other batch at k* ~ 2.3.  GENERAL = true: any floor(k*) (0..S64T_MAX_FK with their own instantiation of the frame, above that
-// the positions are walked per tile).  Two kernels because the register allocator sizes a kernel for its hungriest path: with the
-// cases for 0, 3, 4 probes and the walk compiled in, the floor(k*) = 2 frames spilled (146 bytes of scratch, 111 MB of scratch writes
-// per 2160p launch, 227 -> 342 us: profiles/r04_config4_2160p_lds_tile_sweep.txt of the first collection against r03's).
-template <bool GENERAL>
+// THREE kernels, because the register allocator sizes a kernel for its hungriest path and the paths do not fit one budget of 128:
+//   MODE 0  every coded frame of the launch has floor(k*) 1 or 2 (the host checks): BASELINE config 4 and every other batch at k* ~ 2.3;
+//   MODE 1  floor(k*) 0, 1 or 2, each with its own instantiation of the frame (kept positions);
+//   MODE 2  any floor(k*): (first position, step) kept, the probes walked again in every tile -- EVERY frame of such a launch takes the
+//           walk (7 instead of 5 VALU per probe and tile for the frames that could have kept their positions).
+// Round 4 had MODE 1 and 2 (and kept-position instantiations for floor(k*) 3 and 4) in one kernel: 146 dwords spilled, 111 MB of
+// scratch writes per 2160p launch.  Measured with -Rpass-analysis=kernel-resource-usage (profiles/r05_kernel_resources.txt): the
+// instantiation for 3 kept positions spills by itself next to any other path (42 dwords next to floor(k*) = 0 alone), the walk spills
+// next to any kept-position path (70 dwords) and not alone; {0, 1, 2} and {walk} are both spill-free.
+template <int MODE>
 __attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) void k_query_s64t(
     uint64_t n, uint32_t nactive, const FrameTable tab /* host: query_table_s64 */, Seeds seeds,
     const uint32_t *__restrict__ image, uint64_t image_stride_words32, uint32_t tile_words /* multiple of 4 */,
@@ -453,15 +457,10 @@ __attribute__((amdgpu_num_vgpr(60))) __global__ __launch_bounds__(QL_THREADS) vo
         // meet in phi nodes between them and the register allocator spills the hashes.
         uint32_t pbf;
 #define RBF_S64T_FRAME(FKV) tiled_frame<FKV>(hd1, hl1, hd2, hl2, rank_lo, rank_hi, c_v, m_v, ninv, fk, row, fwords, tile_words, lds_base, fbase, wave, lane, flush)
-        if constexpr (GENERAL) {
-            switch (fk) {
-            case 0: pbf = RBF_S64T_FRAME(0); break;
-            case 1: pbf = RBF_S64T_FRAME(1); break;
-            case 2: pbf = RBF_S64T_FRAME(2); break;
-            case 3: pbf = RBF_S64T_FRAME(3); break;
-            case 4: pbf = RBF_S64T_FRAME(4); break;
-            default: pbf = RBF_S64T_FRAME(-1); break;
-            }
+        if constexpr (MODE == 2) {
+            pbf = RBF_S64T_FRAME(-1);
+        } else if constexpr (MODE == 1) {
+            if (fk == 0) pbf = RBF_S64T_FRAME(0); else if (fk == 1) pbf = RBF_S64T_FRAME(1); else pbf = RBF_S64T_FRAME(2);
         } else {
             if (fk == 1) pbf = RBF_S64T_FRAME(1); else pbf = RBF_S64T_FRAME(2);
         }

@@ -24,17 +24,38 @@ from .engine import BloomEngine, adaptive_threshold, gather_values, scatter_valu
 
 
 # ----------------------------------------------------------------------------- YUV wrapper
+class _PlaneDict(dict):
+    """yuv_info of a YUVFrame: 'format' is there from the start, a plane ('y_plane', 'u_plane', 'v_plane') is copied out of the
+    interleaved frame the first time it is asked for (the reference copies all three when it wraps a frame,
+    fixed_video_compressor.py:292-296; only the keyframe record ever reads them, :64-75 -- three strided 2 MB copies per 1080p frame were
+    most of what compress_video / decompress_video cost on the host, profiles/r05_e2e.txt)."""
+    _CHANNEL = {"y_plane": 0, "u_plane": 1, "v_plane": 2}
+
+    def __init__(self, frame):
+        super().__init__(format="YUV444")
+        self._frame = frame
+
+    def __missing__(self, key):
+        if key not in self._CHANNEL:
+            raise KeyError(key)
+        plane = self[key] = self._frame[:, :, self._CHANNEL[key]].copy()
+        return plane
+
+    def __contains__(self, key):
+        return key in self._CHANNEL or super().__contains__(key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 class YUVFrame:
     """ndarray-like wrapper carrying contiguous copies of the three planes
-    (FixedVideoCompressor.add_yuv_info_to_frame, fixed_video_compressor.py:287-334)."""
+    (FixedVideoCompressor.add_yuv_info_to_frame, fixed_video_compressor.py:287-334); the copies are made on first use (_PlaneDict)."""
 
     def __init__(self, frame):
         frame = np.asarray(frame)
         self.data = frame
-        self.yuv_info = {"format": "YUV444",
-                         "y_plane": frame[:, :, 0].copy(),
-                         "u_plane": frame[:, :, 1].copy(),
-                         "v_plane": frame[:, :, 2].copy()}
+        self.yuv_info = _PlaneDict(frame)
         self.shape, self.dtype, self.nbytes = frame.shape, frame.dtype, frame.nbytes
 
     def __array__(self, dtype=None, copy=None):

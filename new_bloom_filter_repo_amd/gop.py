@@ -60,7 +60,7 @@ class GopCoder:
 
     def __init__(self, ctx, width, height, nframes, channels=3, sample_bytes=1, seeds=P.SEEDS_VIDEO,
                  allocator=None, threshold=0.0, out_allocator=None, frames_block=None, adaptive=None,
-                 planar_luma=False, keep_interleaved=True, resident_gops=1, luma_block=None, out_sets=1, run_starts=None):
+                 planar_luma=False, keep_interleaved=True, resident_gops=1, luma_block=None, run_starts=None):
         """allocator: device memory source (default: library-owned); out_allocator: separate source for
         the output record (filters, witnesses, stats); frames_block: share another coder's frame buffer.
         threshold=None with adaptive=(noise_tolerance, min_thr, max_thr): per-frame noise-adaptive
@@ -73,9 +73,7 @@ class GopCoder:
         run_starts: frame indices (within the block of `nframes` frames) that are KEYFRAMES of the caller's stream: each starts a new run,
         and the pair in front of it is not coded (rbf_encode_runs: several GOPs in ONE launch sequence; results() marks those pairs
         `skipped`).  The reference codes frame by frame (improved_video_compressor.py:198-266); batching whole GOPs is this package's.
-        out_sets: complete sets of per-GOP buffers (masks, ones, filters, witnesses, stats, params) that consecutive encodes rotate over.
-        With 2, and the context's OPT_SIDE_COMPACT on, a GOP's witness compaction runs beside the next GOP's mask / insert / reduce
-        (include/rbf.h); results(), pack() and gather_values() always refer to the GOP encoded last."""
+        """
         from .engine import threshold_floor
         self.ctx, self.W, self.H, self.F, self.C, self.sb = ctx, width, height, nframes, channels, sample_bytes
         self.n = width * height
@@ -118,23 +116,14 @@ class GopCoder:
             self.frames = None
         else:
             self.frames = alloc(self.frame_bytes * nframes * self.resident_gops)
-        self.out_sets = max(1, int(out_sets))
-        self._sets = []
-        for _ in range(self.out_sets):
-            self._sets.append(dict(masks=alloc(self.mask_stride * self.pairs), ones=alloc(8 * self.pairs),
-                                   filters=oalloc(self.filter_stride * self.pairs), witness=oalloc(self.witness_stride * self.pairs),
-                                   stats=oalloc(8 * nat.STATS_PER_FRAME * self.pairs),
-                                   params=(nat.FilterParams * self.pairs)(), k=(ctypes.c_double * self.pairs)(), record=None))
-        self._cur = self.out_sets - 1                  # the first encode uses set 0
-        self._use(self._cur)
+        self.masks, self.ones = alloc(self.mask_stride * self.pairs), alloc(8 * self.pairs)
+        self.filters, self.witness = oalloc(self.filter_stride * self.pairs), oalloc(self.witness_stride * self.pairs)
+        self.stats = oalloc(8 * nat.STATS_PER_FRAME * self.pairs)
+        self.params, self.k = (nat.FilterParams * self.pairs)(), (ctypes.c_double * self.pairs)()
+        self.record = None
         if self.adaptive is not None:
             self.moments = alloc(16 * self.pairs)
             self.noise_plane = None                       # allocated on the first exact fallback
-
-    def _use(self, i):
-        st = self._sets[i]
-        self.masks, self.ones, self.filters, self.witness, self.stats = st["masks"], st["ones"], st["filters"], st["witness"], st["stats"]
-        self.params, self.k = st["params"], st["k"]
 
     @staticmethod
     def strides(n):
@@ -143,11 +132,11 @@ class GopCoder:
         return nat.packed_stride(n), fstride, nat.packed_stride(n)
 
     @staticmethod
-    def record_bytes(n, pairs, out_sets=1):
-        """Bytes a TorchArena needs for the output records (filters | witnesses | stats) of `pairs` frames, `out_sets` of them."""
+    def record_bytes(n, pairs):
+        """Bytes a TorchArena needs for the output records (filters | witnesses | stats) of `pairs` frames."""
         _, fs, ws = GopCoder.strides(n)
         r = lambda x: (x + 255) // 256 * 256
-        return out_sets * (r(fs * pairs) + r(ws * pairs) + r(8 * nat.STATS_PER_FRAME * pairs))
+        return r(fs * pairs) + r(ws * pairs) + r(8 * nat.STATS_PER_FRAME * pairs)
 
     def close(self):
         """Free the library-owned blocks this coder allocated (torch-backed blocks die with their tensors)."""
@@ -222,8 +211,6 @@ class GopCoder:
             self.thresholds = self.adaptive_floors()
             self.thr_tab = (ctypes.c_int32 * self.pairs)(*self.thresholds)
         self.gop = gop
-        self._cur = (self._cur + 1) % self.out_sets
-        self._use(self._cur)
         if self.planar_luma:                          # dense Y planes: pixel stride = one sample
             src, fstride, pitch, pstride = self.luma.ptr + gop * self.luma_bytes * self.F, self.luma_bytes, self.W * self.sb, self.sb
         else:
@@ -248,10 +235,9 @@ class GopCoder:
         """Compact this GOP's output rows into one exact-size record on the device (rbf_pack_records);
         returns the block holding it.  `block`: where to put it (default: a block of the worst-case size)."""
         if block is None:
-            st = self._sets[self._cur]
-            if st["record"] is None:
-                st["record"] = self._out_alloc(int(nat.lib().rbf_record_max_bytes(self.pairs, self.n)))
-            block = self.record = st["record"]
+            if self.record is None:
+                self.record = self._out_alloc(int(nat.lib().rbf_record_max_bytes(self.pairs, self.n)))
+            block = self.record
         nat.check(nat.lib().rbf_pack_records(
             self.ctx.handle, self.pairs, self.n, self.params, self.k, self.masks.ptr, self.mask_stride,
             self.filters.ptr, self.filter_stride, self.witness.ptr, self.witness_stride, self.stats.ptr,

@@ -292,10 +292,14 @@ class ImprovedVideoCompressor:
             raise ValueError("No compressed frames provided")
         frames = []
         i = 0
+        # the keyframes are independent of everything else: inflate them on the host threads while the inter-frame runs go through the GPU
+        key_pool = ThreadPoolExecutor(self.num_threads)
+        keys = {j: key_pool.submit(self.compressor.decompress_frame, rec) for j, (ty, rec) in enumerate(records) if ty == KEY}
+        key_pool.shutdown(wait=False)
         while i < len(records):
             ty, rec = records[i]
             if ty == KEY:
-                frames.append(self.compressor.decompress_frame(rec))
+                frames.append(keys[i].result())
                 i += 1
             elif ty == INTER:
                 if not frames:

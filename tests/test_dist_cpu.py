@@ -304,6 +304,27 @@ def test_clip_pieces_cover_every_inter_frame():
             assert coded == [t for t in range(T) if t % I], (T, I, world)
 
 
+def test_clip_blocks_cover_every_inter_frame_once_in_order():
+    """bench.py's clip mode hands every rank's shard to the GPU in multi-GOP blocks (rbf_encode_runs): whatever the block size, every
+    inter-frame of the clip is coded exactly once, in clip order over the ranks, a block never reads outside its rank's shard + halo, and
+    every run start inside a block is a keyframe of the clip."""
+    bench = _load_bench()
+    for T, I, world, BG in [(300, 30, 1, 0), (300, 30, 2, 0), (300, 30, 4, 0), (300, 30, 8, 0), (300, 30, 8, 2), (300, 30, 2, 4), (40, 10, 1, 0), (21, 10, 1, 0),
+                            (300, 30, 8, 1), (61, 30, 3, 0), (300, 30, 7, 3), (36, 30, 1, 0), (1000, 30, 1, 0), (7, 3, 5, 0), (2, 30, 1, 0)]:
+        coded = []
+        for r in range(world):
+            a, b = D.shard_range(T, world, r)
+            first = D.halo_start(a, I)
+            blocks = bench.clip_blocks(a, b, I, BG, 4)
+            if BG == 0:
+                assert len(blocks) <= max(4, (b - first + 119) // 120)          # auto: one block per pipeline unless blocks would exceed 4 intervals
+            for f0, cnt, rs in blocks:
+                assert f0 >= first and f0 + cnt <= b and cnt >= 2, (T, I, world, BG, r, f0, cnt)
+                assert all((f0 + x) % I == 0 and 0 < x < cnt for x in rs)
+                coded += [f0 + 1 + j for j in range(cnt - 1) if (j + 1) not in rs]
+        assert coded == [t for t in range(T) if t % I], (T, I, world, BG)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # bench.py's own launcher (`python bench.py --gpus N` without torch.distributed.run): the rank processes it starts
 # must find each other.  The workers here are gloo stand-ins for bench.py's ranks (no GPU in this tier).

@@ -165,13 +165,11 @@ def test_two_phase_gop_interleaved_over_two_contexts_vs_oracle(oracle):
         c.close()
 
 
-@pytest.mark.parametrize("out_sets", [2, 1], ids=["two_output_sets", "one_output_set_waits"])
-def test_side_stream_compaction_vs_oracle(oracle, out_sets):
-    """RBF_OPT_SIDE_COMPACT: a GOP's witness compaction runs on the library's side stream while the context's stream goes on with the next
-    GOP (bench.py's default).  Two contexts, each rotating over THREE different resident GOPs, four rounds back to back without a
-    sync in between; with two output sets the next mask stage runs beside the outstanding compaction, with one it must wait for it
-    (same buffers) -- either way every GOP's records, read right after its encode, equal the CPU oracle's; pack() (a library call on
-    the context) sees finished witness rows; the decode direction gives the masks back."""
+def test_back_to_back_gops_without_sync_vs_oracle(oracle):
+    """Two contexts, each rotating over THREE different resident GOPs, four rounds back to back without a sync in between (a GOP's mask
+    stage is enqueued right behind the previous GOP's compaction on the same stream and reuses its output rows): every GOP's records, read
+    right after its encode, equal the CPU oracle's; pack() right behind the encode sees finished witness rows; the decode direction gives
+    the masks back."""
     import torch
     from new_bloom_filter_repo_amd.dist import unpack_device_record
     W, H, F = 1920, 1080, 10
@@ -181,9 +179,7 @@ def test_side_stream_compaction_vs_oracle(oracle, out_sets):
     device = torch.device("cuda", 0)
     streams = [torch.cuda.Stream(device) for _ in range(2)]
     ctxs = [nat.Context(0, s.cuda_stream) for s in streams]
-    for c in ctxs:
-        c.option(nat.OPT_SIDE_COMPACT, 1)
-    coders = [GopCoder(c, W, H, F, channels=3, sample_bytes=1, planar_luma=True, keep_interleaved=False, resident_gops=3, out_sets=out_sets) for c in ctxs]
+    coders = [GopCoder(c, W, H, F, channels=3, sample_bytes=1, planar_luma=True, keep_interleaved=False, resident_gops=3) for c in ctxs]
     for c, gk in zip(coders, gops):
         for g in range(3):
             c.load_frames(gk[g], g)
@@ -198,7 +194,7 @@ def test_side_stream_compaction_vs_oracle(oracle, out_sets):
             res = c.results()
             check_records(res, want[k][g], n, "context %d gop %d" % (k, g))
             if k == 0:
-                rows = unpack_device_record(c.pack().numpy(c.ctx), n)     # pack right behind the encode: the library joins the side stream by itself
+                rows = unpack_device_record(c.pack().numpy(c.ctx), n)     # pack right behind the encode, on the same stream
                 for r, w in zip(rows, res):
                     assert r["witness_bits"] == w["witness_bits"] and np.array_equal(r["witness"], w["witness"]), (g, "packed witness")
                 decode_back(ctxs[0], res, n, "gop %d" % g)

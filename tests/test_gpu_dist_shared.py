@@ -1,0 +1,109 @@
+"""The sharded path with the REAL kernels at world > 1 on a 1-GPU box: N rank processes share device 0 (each with its own library
+contexts and streams) and talk over gloo -- the shard + halo addressing, the per-rank multi-GOP blocks, the exact-size record gather and
+rank 0's reassembly in frame order are the code an 8-GPU node runs; only the transport (RCCL over xGMI there, host memory here) differs.
+
+* BASELINE config 3 at its stated size (1920x1080, 300 frames, keyframe every 30) and config 5's 16-bit samples through bench.py's clip
+  mode (`--backend gloo --one-device`, bench.py's own launcher): every rank checks its frames against the CPU oracle, rank 0 parses the
+  290 records that arrived and checks that they are the clip's inter-frames in order.
+* dist.encode_video_sharded (the plugin surface sharded: ImprovedVideoCompressor.encode_range per rank, container records gathered to
+  rank 0): the container equals the single-process container byte for byte and decodes bit-exactly (verify_true_lossless.py:338-492
+  semantics, verify.verify_bit_exact).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def run_json(cmd, timeout):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=REPO)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, p.stdout[-2000:] + p.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("world,bits,frames", [(2, 8, 300), (8, 8, 300), (8, 16, 300)], ids=["config3_world2", "config3_world8", "config5_uint16_world8"])
+def test_clip_sharded_over_ranks_on_one_device(world, bits, frames):
+    res = run_json([sys.executable, "bench.py", "--gpus", str(world), "--backend", "gloo", "--one-device", "--clip-frames", str(frames),
+                    "--keyframe-interval", "30", "--steps", "2", "--warmup", "1", "--bits", str(bits)], timeout=1500)
+    v = res["verified_vs_oracle"]
+    coded = frames - frames // 30
+    assert res["n_gpus"] == world and res["scaling"] == "strong" and res["config"]["gather_to_rank0"]
+    assert v["frames"] == coded == v["of"] == v["records_parsed_on_rank0"], v
+    assert v["bytes_gathered_on_rank0"] > 0 and res["value"] > 0
+
+
+WORKER = r'''
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, %(repo)r)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+T, I, W, H, bits = %(frames)d, 30, 1920, 1080, %(bits)d
+import datetime
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+torch.cuda.init()
+dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+from new_bloom_filter_repo_amd import _native as nat, dist as D
+from new_bloom_filter_repo_amd.synthetic import make_clip_shard
+from new_bloom_filter_repo_amd.video_compressor import ImprovedVideoCompressor
+from new_bloom_filter_repo_amd.verify import verify_bit_exact
+dtype = np.uint8 if bits == 8 else np.uint16
+start, stop = D.shard_range(T, world, rank)
+first = D.halo_start(start, I)
+shard = make_clip_shard(3200, W, H, first, stop, I, dtype=dtype)            # frames first..stop-1 of the SAME clip on every rank
+ctx = nat.Context(0)
+blob = D.encode_video_sharded([shard[i] for i in range(len(shard))], first, T, keyframe_interval=I, ctx=ctx)
+out = None
+if rank == 0:
+    clip = make_clip_shard(3200, W, H, 0, T, I, dtype=dtype)
+    frames = [clip[t] for t in range(T)]
+    comp = ImprovedVideoCompressor(keyframe_interval=I, ctx=ctx, inter_frames=True)
+    single = ImprovedVideoCompressor._container(comp.encode_range(frames, 0, 0, T))
+    assert blob == single, "sharded container (%%d bytes) differs from the single-process container (%%d bytes)" %% (len(blob), len(single))
+    recs = ImprovedVideoCompressor._parse_container(blob)
+    kinds = [ty for ty, _ in recs]
+    assert kinds == [1 if t %% I == 0 else 2 for t in range(T)], "records are not in frame order"
+    dec = comp.decompress_video(compressed_frames=recs)
+    v = verify_bit_exact(frames, dec, color_space="YUV")
+    assert v["success"] and v["exact_matches"] == T, v["different_frame_indices"][:8]
+    out = {"container_bytes": len(blob), "frames": T, "inter_frames": kinds.count(2), "exact_matches": v["exact_matches"], "world": world}
+    comp.close()
+dist.barrier()
+dist.destroy_process_group()
+if out is not None:
+    print(json.dumps(out), flush=True)
+'''
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_shared_tests", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("world,bits,frames", [(2, 8, 120), (8, 8, 300), (8, 16, 120)], ids=["world2", "config3_world8", "uint16_world8"])
+def test_sharded_container_equals_single_process_and_decodes_bit_exact(tmp_path, world, bits, frames):
+    bench = _load_bench()
+    worker = tmp_path / "worker.py"
+    worker.write_text(WORKER % {"repo": REPO, "frames": frames, "bits": bits})
+    out_path = tmp_path / "rank0.out"
+    os.environ.pop("RANK", None)
+    with open(out_path, "w") as f:
+        rc = bench.launch_ranks(world, [sys.executable, str(worker)], stdout0=f)
+    text = out_path.read_text()
+    assert rc == 0, text[-3000:]
+    res = json.loads([ln for ln in text.splitlines() if ln.startswith("{")][-1])
+    assert res["frames"] == frames == res["exact_matches"] and res["inter_frames"] == frames - frames // 30 and res["world"] == world

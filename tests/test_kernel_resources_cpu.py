@@ -7,7 +7,7 @@ import subprocess
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 HOT = (                                   # demangled name prefixes (tools/kernel_resources.py prints them)
-    "k_query_u64", "k_query_u64w", "k_query_s64t<false>", "k_insert_tab<false, true>", "k_insert_tab<false, false>", "k_insert_positions<true>",
+    "k_query_u64", "k_query_u64w", "k_query_s64t<0>", "k_query_s64t<1>", "k_query_s64t<2>", "k_insert_tab<false, true>", "k_insert_tab<false, false>", "k_insert_positions<true>",
     "k_insert_records", "k_filter_reduce", "k_compact_witness", "k_residual_mask_gop<unsigned char, 1, false, true>", "k_expand_mask", "k_hash_table",
 )
 
@@ -27,6 +27,6 @@ def test_hot_kernels_do_not_spill_and_keep_their_occupancy():
             vgprs, _, scratch, spills, waves = rows[n][:5]
             assert scratch == "0" and spills == "0", (n, rows[n])
     # the 1024-thread kernels need four waves per SIMD: at most 128 registers
-    for k in ("k_query_u64", "k_query_u64w", "k_query_s64t<false>", "k_query_s64t<true>", "k_insert_tab<false, true>"):
+    for k in ("k_query_u64", "k_query_u64w", "k_query_s64t<0>", "k_query_s64t<1>", "k_query_s64t<2>", "k_insert_tab<false, true>"):
         for n in (n for n in rows if n.startswith(k)):
             assert int(rows[n][0]) <= 128, (n, rows[n])
