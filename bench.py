@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--spawn", action="store_true", help="start the rank processes through bench.py's own launcher even for --gpus 1 (smoke-tests the N>1 launch path)")
     ap.add_argument("--no-clips", action="store_true", help="skip the clip300 / clip300_uint16 legs (BASELINE configs 3 and 5) behind the weak-scaling headline")
     ap.add_argument("--clip-leg-frames", type=int, default=300, help="frames of the clip legs of the default run")
-    ap.add_argument("--clip-steps", type=int, default=10, help="timed passes over the clip in the clip legs")
+    ap.add_argument("--clip-steps", type=int, default=40, help="timed passes over the clip in the clip legs")
     ap.add_argument("--begin-ahead", type=int, default=0, help="GOPs whose mask stage (rbf_encode_gop_begin) is enqueued before the oldest one is finished (rbf_encode_gop_finish); 0 = the one-call form (default: the fastest feed measured, profiles/r04_feed_sweep.txt), -1 = pipelines - 1")
     ap.add_argument("--host-threads", type=int, default=0, help="1 = one host thread per pipeline (each calls rbf_encode_gop for its own context; ctypes drops the GIL) instead of one thread issuing begin / finish in turn")
     ap.add_argument("--no-legs", action="store_true", help="skip the interleaved / config4_2160p / decode_1080p / batched_gops legs behind the headline")
@@ -940,33 +940,36 @@ def clip_pieces(start, stop, interval):
 
 def clip_blocks(start, stop, interval, block_gops, pipelines=4):
     """The blocks a rank hands to the GPU, one rbf_encode_runs launch sequence each: list of (first_read_frame, nframes_read, run_starts)
-    covering the inter-frames of [start, stop).  A block spans whole keyframe intervals (the shard's first and last may be partial) and
-    begins at a keyframe or at the shard's halo frame; run_starts are the keyframes inside it, relative to its first frame -- the pairs in
-    front of them are not coded.  block_gops = 1: clip_pieces' runs (one call per run, round 4); N > 1: N intervals per block;
-    0 (auto): the shard's intervals in min(pipelines, about one block per 72 inter-frames) contiguous groups of nearly equal size, at most 4
-    intervals each -- every pipeline of the rank gets ONE block per pass, as few launch sequences as keep the pipelines busy."""
+    covering the inter-frames of [start, stop).  A block's first frame is only read (a keyframe, or the frame in front of the block's
+    first inter-frame: a halo inside the rank's own shard costs one frame of extra reads); run_starts are the keyframes inside the block,
+    relative to its first frame -- the pairs in front of them are not coded.
+    block_gops = 1: clip_pieces' runs (one call per run, round 4); N > 1: blocks of N keyframe intervals, cut at keyframes;
+    0 (auto): the rank's frames in min(pipelines, about one block per 72 inter-frames) contiguous ranges of EQUAL length (cut anywhere, not
+    only at keyframes), at most 128 frames each -- every pipeline of the rank gets one block of the same size per pass."""
     if block_gops == 1:
         return [(f0, cnt, []) for f0, cnt in clip_pieces(start, stop, interval)]
     first = start if start == 0 or start % interval == 0 else start - 1          # dist.halo_start
-    cuts = [first] + [t for t in range(first + 1, stop) if t % interval == 0] + [stop]      # the shard cut at its keyframes
-    parts = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b - a >= 2]                     # (a lone keyframe at the shard's end codes nothing)
-    if not parts:
-        return []
     if block_gops > 1:
-        sizes = [block_gops] * ((len(parts) + block_gops - 1) // block_gops)
+        cuts = [first] + [t for t in range(first + 1, stop) if t % interval == 0][block_gops - 1::block_gops] + [stop]
+        if first % interval:                                                     # a shard that starts inside an interval: its partial interval counts as one
+            cuts = [first] + [t for t in range(first + 1, stop) if t % interval == 0][max(0, block_gops - 2)::block_gops] + [stop]
+        ranges = list(zip(cuts[:-1], cuts[1:]))
     else:
-        coded = sum(b - a - 1 for a, b in parts)
-        groups = max(1, min(pipelines, len(parts), (coded + 36) // 72))
-        groups = max(groups, (len(parts) + 3) // 4)
-        sizes = [len(parts) // groups + (1 if g < len(parts) % groups else 0) for g in range(groups)]
-    blocks, i = [], 0
-    for sz in sizes:
-        grp = parts[i:i + sz]
-        i += sz
-        if not grp:
+        coded = sum(1 for t in range(start, stop) if t % interval)
+        groups = max(1, min(pipelines, (coded + 36) // 72), (stop - start + 126) // 127)
+        base, extra = divmod(stop - start, groups)
+        ranges, a = [], start
+        for g in range(groups):
+            b = a + base + (1 if g < extra else 0)
+            ranges.append((a, b))
+            a = b
+    blocks = []
+    for a, b in ranges:                                                          # the range's inter-frames, read from their predecessor on
+        lo = a if (a % interval == 0 or a == first) else a - 1
+        lo = max(lo, first)
+        if b - lo < 2 or not any(t % interval for t in range(max(lo + 1, a), b)):
             continue
-        lo, hi = grp[0][0], grp[-1][1]
-        blocks.append((lo, hi - lo, [t - lo for t in range(lo + 1, hi) if t % interval == 0]))
+        blocks.append((lo, b - lo, [t - lo for t in range(lo + 1, b) if t % interval == 0]))
     return blocks
 
 
@@ -1039,9 +1042,25 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
         torch.cuda.synchronize(device)
 
     def timed(gather):
-        got = None
+        # warm-up: the passes asked for, then more until 30 ms have gone by (a pass is ~1 ms; the first ones after start-up run
+        # 8-10 % slower than the steady state, like the headline's steps); every rank runs the same number
+        got, spent, extra = None, 0.0, 0
         for _ in range(max(1, warmup)):
             got = step(gather)
+        barrier()
+        while extra < 200:
+            t0 = time.perf_counter()
+            got = step(gather)
+            torch.cuda.synchronize(device)
+            spent += time.perf_counter() - t0
+            extra += 1
+            done = spent >= 0.030
+            if use_dist:
+                flag = torch.tensor([1 if done else 0], dtype=torch.int64, device=COMM_DEVICE)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                done = bool(flag.item())
+            if done:
+                break
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):

@@ -556,7 +556,10 @@ static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint3
     p.fast_insert = !ctx->force_generic && mmax > 0 && !(auto_tiles && p.insert_tiles > MAX_INSERT_TILES);
     // query
     // k_query_u64 (FP64 reductions, probe image) is double-buffered only; its buffers end with the SAFE dwords
-    if (2 * (fbytes + 16) + u64_geo_bytes(nframes) > LDS_LIMIT || ctx->single_buffer) p.f64_mod = false;      // (filters that fit twice but leave no room for the frame records go to the tiled kernel: one buffer)
+    // ... and it addresses its outputs with 32-bit offsets (pass bytes: frame * nseg * 64 + ...): a chunk of frames x pixels >= 2^35 goes to
+    // the tiled kernel, which keeps 64-bit row bases
+    const bool u64_offsets_fit = (uint64_t)nframes * ((n + QL_SEG_PIXELS - 1) / QL_SEG_PIXELS) * (QL_SEG_PIXELS / 8) < (1ull << 32);
+    if (2 * (fbytes + 16) + u64_geo_bytes(nframes) > LDS_LIMIT || ctx->single_buffer || !u64_offsets_fit) p.f64_mod = false;      // (filters that fit twice but leave no room for the frame records go to the tiled kernel: one buffer)
     const size_t qbytes = fbytes + (p.f64_mod ? 16 : 0);
     p.double_buffer = 2 * qbytes <= LDS_LIMIT && !ctx->single_buffer;
     p.query_kind = 0;

@@ -117,7 +117,8 @@ __device__ __forceinline__ void insert_tab_steps(const uint8_t *__restrict__ mas
             ha_kept = h.ha;
         } else {
             slot_kept = hash_table_slot(idx);
-            e0 = tv.pos[slot_kept];                                // (a non-temporal gather was measured in round 5: insert 33 -> 55 us alone, profiles/r05_sweep1.txt)
+            e0 = tv.pos[slot_kept];                                // (round 5 measured a non-temporal gather: insert 33 -> 55 us alone, profiles/r05_sweep1.txt; and batches of 128 / 256 keys,
+                                                                   //  two / four gathers per lane in flight: 35.3 / 36.1 us, the step unchanged, profiles/r05_insert_batch_keys.txt)
             tag = tv.tag[idx];
         }
         pending = count;

@@ -1,7 +1,7 @@
 // rbf_kernels_q64.h -- what the FP64 kernels share (k_query_u64, k_query_s64t, k_insert_tab, k_insert_positions; filters of
 // 2^15 <= m < 2^23 bits): the exact h mod m through one v_fma_f64, the probe image, activation ranks, the pixel-index hash table's
 // layout and the LDS-DMA of an image row.  (Rounds 2 and 3 kept their query kernels k_query_f64 / f64t / p4 / r64 here and in
-// rbf_kernels_r64.h; they are history now -- frozen copies for the old harnesses live in tools/legacy/.)
+// rbf_kernels_r64.h; they are history now: git keeps them, tools/legacy/ up to round 4.)
 #pragma once
 #include "rbf_kernels_lds.h"
 

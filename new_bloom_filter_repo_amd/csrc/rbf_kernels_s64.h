@@ -2,7 +2,7 @@
 //
 //   frame_pass_rows / frame_pass_plain   one frame's probes of a lane's 8 pixels against a probe image in LDS (used by k_query_u64,
 //                                        rbf_kernels_u64.h; round 3's k_query_s64 / k_query_s64w, the first kernels built on them,
-//                                        are in tools/legacy/)
+//                                        are in the git history, tools/legacy/ up to round 4)
 //   k_query_s64t                         filters that do not fit LDS twice (1440p ... 5K, m < 2^23: BASELINE config 4), walked in
 //                                        tiles of one maximal LDS buffer
 //

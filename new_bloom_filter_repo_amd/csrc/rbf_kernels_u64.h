@@ -138,7 +138,7 @@ struct RowDmaC {
 // `cls.n[k]`: frames of class k.  `empty_lo / empty_hi`: bit f set = frame f of the batch is not coded and this launch writes its
 // (empty) outputs.  Dynamic LDS: two image buffers of ((fwords_max + 3) & ~3) + 4 dwords, then u64_geo_bytes(nactive).
 // `image_stride_words32` is also what is staged per frame: rows must be readable over their whole pitch (the library's are).
-// (The measurement variants of this body -- no staging, no barrier, no outputs, no priorities -- live in tools/legacy/rbf_kernels_u64_ab.h.)
+// (The measurement variants of this body -- no staging, no barrier, no outputs, no priorities -- were tools/legacy/rbf_kernels_u64_ab.h up to round 4: git history.)
 template <bool WIDE>
 __device__ __forceinline__ void query_u64_body(
     uint64_t n, uint32_t nactive, const FrameTable &tab, const U64Classes &cls, Seeds seeds,

@@ -27,6 +27,19 @@ KEY, INTER = 1, 2
 _POPCOUNT8 = np.unpackbits(np.arange(256, dtype=np.uint8)[:, None], axis=1).sum(axis=1).astype(np.uint8)   # numpy 1.x has no bitwise_count
 
 
+def _as_block(data):
+    """The frames of a block as ONE contiguous (F, H, W[, C]) array for the upload: a zero-copy view when the caller's frames already lie
+    back to back in memory (slices of one decoded clip), a stacked copy otherwise."""
+    a = data[0]
+    if all(d.flags.c_contiguous for d in data):
+        base, nb = a.ctypes.data, a.nbytes
+        if nb and all(d.ctypes.data == base + i * nb for i, d in enumerate(data)):
+            import ctypes
+            raw = np.ctypeslib.as_array((ctypes.c_uint8 * (nb * len(data))).from_address(base))      # (the frames in `data` keep the memory alive)
+            return raw.view(a.dtype).reshape((len(data),) + a.shape)
+    return np.stack(data)
+
+
 class ImprovedVideoCompressor:
     def __init__(self, noise_tolerance=10.0, keyframe_interval=30, min_diff_threshold=3.0,
                  max_diff_threshold=30.0, bloom_threshold_modifier=1.0, batch_size=30,
@@ -127,7 +140,7 @@ class ImprovedVideoCompressor:
                 self._gop_coder.close()
             self._gop_coder, self._gop_key = GopCoder(ctx, W, H, len(seg), channels=C, sample_bytes=a.dtype.itemsize, run_starts=list(run_starts)), key
         coder = self._gop_coder
-        block = np.stack(data)
+        block = _as_block(data)
         t1 = time.perf_counter()
         coder.load_frames(block)
         ctx.sync()

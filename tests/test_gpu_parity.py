@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
                                         "lds_tiled_8KiB_insert_tab", "generic"])
 def eng(request):
     """Every LIVE kernel family must be bit-exact (round 4 pruned the superseded FP64 query kernels: k_query_f64 / f64t / p4 / r64 / r64t /
-    s64 / s64w are in tools/legacy/, outside the library): the LDS-resident fast path -- k_query_u64 (FP64 reductions, frame records
+    s64 / s64w left the library in round 4; git keeps them): the LDS-resident fast path -- k_query_u64 (FP64 reductions, frame records
     and LDS-DMA staging; default whenever every filter of the batch has 2^15 <= m < 2^23 and fits LDS twice) with k_insert_tab
     gathering from the pixel-index hash table; "lds_single_buffer" / "lds_barrett_only": the integer Barrett kernels (k_query_lds,
     k_insert_lds), so both forms of h mod m are pinned to the same fixtures; "hash_in_insert": the insert kernel hashes its set

@@ -32,7 +32,8 @@ while time.time() < t_end:
     W, H = (int(rng.integers(200, 900)), int(rng.integers(100, 500))) if big else (int(rng.integers(1, 200)), int(rng.integers(1, 100)))
     C = int(rng.choice([1, 3]))
     dtype = [np.uint8, np.uint16][int(rng.integers(0, 2))]
-    F = int(rng.integers(2, 5))
+    F = int(rng.integers(2, 8))
+    starts = [t for t in range(1, F) if rng.random() < 0.3] if rng.random() < 0.5 else []      # keyframes inside the block: rbf_encode_runs
     seeds = [P.SEEDS_VIDEO, P.SEEDS_BLOOM_COMPRESS, tuple(int(x) for x in rng.integers(0, 2 ** 63, 3))][int(rng.integers(0, 3))]
     thr = float(rng.choice([0.0, 0.0, 0.0, 1.0, 7.5]))
     top = np.iinfo(dtype).max
@@ -44,7 +45,7 @@ while time.time() < t_end:
     if C == 1:
         frames = np.ascontiguousarray(frames[..., 0])
     n = W * H
-    desc = dict(seed=seed, case=cases, knob=knob, W=W, H=H, C=C, dtype=np.dtype(dtype).name, F=F, seeds=seeds, thr=thr)
+    desc = dict(seed=seed, case=cases, knob=knob, W=W, H=H, C=C, dtype=np.dtype(dtype).name, F=F, seeds=seeds, thr=thr, run_starts=starts)
     # planar luma block (device de-interleave at upload), a resident-GOP slot other than 0, the separate finish launch instead of the mask
     # kernel's fused tail, the two-phase form of rbf_encode_gop
     planar = bool(rng.random() < 0.5)
@@ -56,7 +57,7 @@ while time.time() < t_end:
     ctx.force_generic(knob)
     ctx.option(nat.OPT_SEPARATE_FINISH, opts[1])
     eng = BloomEngine(ctx)
-    coder = GopCoder(ctx, W, H, F, channels=C, sample_bytes=np.dtype(dtype).itemsize, seeds=seeds, threshold=thr, planar_luma=planar, resident_gops=slots)
+    coder = GopCoder(ctx, W, H, F, channels=C, sample_bytes=np.dtype(dtype).itemsize, seeds=seeds, threshold=thr, planar_luma=planar, resident_gops=slots, run_starts=starts)
     coder.load_frames(frames, gop=slot) if planar else coder.load_frames(frames)
     if opts[0]:
         coder.encode_begin(slot if planar else 0)
@@ -75,6 +76,11 @@ while time.time() < t_end:
             ch = (a != b) if C == 1 else (a != b).any(axis=2)
             assert int(uncovered[f]) == int((ch & ~m).sum()), "uncovered"
         for f, r in enumerate(res):
+            if (f + 1) in starts:                                # the pair in front of a keyframe: not coded, a header row without payload
+                assert r.get("skipped") and not r["mask"].any() and r["ones"] == 0 and r["witness_bits"] == 0, "skipped pair"
+                assert recs[f].get("skipped") and "filter" not in recs[f] and "mask" not in recs[f], "skipped record"
+                continue
+            assert not r.get("skipped") and not recs[f].get("skipped"), "coded pair marked skipped"
             y0, y1 = (frames[f], frames[f + 1]) if C == 1 else (frames[f][..., 0], frames[f + 1][..., 0])
             want = oracle.residual_mask(np.ascontiguousarray(y0), np.ascontiguousarray(y1), thr).reshape(-1)
             assert np.array_equal(unpack(r["mask"], n), want), "mask"

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-5 evidence run on the GPU box (gpurun): everything DESIGN.md cites beyond tools/r05_profile.sh, written under gpurun_out/r05final/
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05final; mkdir -p $O
+( time python bench.py --steps 20 --warmup 5 ) > $O/bench_default.json 2> $O/bench_default.err
+bash tools/density_sweep.sh > $O/density_sweep.txt 2>&1
+bash tools/large_frames.sh > $O/large_frames.txt 2>&1
+for st in 1 2 3 4 6; do python bench.py --no-cpu-baseline --no-clips --no-legs --no-verify --streams $st 2>/dev/null | grep '^{' | tail -1 | python -c "
+import json,sys;d=json.loads(sys.stdin.readline());print('streams %d: %.0f Mpixel/s median 20-step region, %.0f steady, alone %s' % ($st, d['value'], d['steady_state']['value'], d['kernels_ms_per_step_alone']))"; done > $O/streams_sweep.txt
+bash tools/tile_sweep.sh > $O/config4_2160p_lds_tile_sweep.txt 2>&1
+python tools/decode_bench.py > $O/decode_bench.txt 2>&1; python tools/decode_bench.py 3840 2160 9 >> $O/decode_bench.txt 2>&1
+( time python -m pytest tests -m gpu -q ) > $O/gpu_tests.txt 2>&1
+timeout 300 python tools/fuzz_soak.py 180 > $O/fuzz_soak.txt 2>&1
+timeout 200 python tools/fuzz_surface.py 120 > $O/fuzz_surface.txt 2>&1
+tail -3 $O/gpu_tests.txt $O/fuzz_soak.txt $O/fuzz_surface.txt $O/density_sweep.txt
