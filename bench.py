@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the rational-Bloom insert+query path on MI355X.
 
-A step = one pass of the hot path over one GOP resident in HBM: residual masks of the 29
-inter-frames of a 1920x1080 YUV444 30-frame GOP -> ones counts to the host -> filter geometry
-(float64, host) -> Bloom insert -> query + witness compaction (BASELINE.json configs[1], k* = 2.3).
-`--streams` GOP pipelines are in flight per GPU, EACH WITH ITS OWN GOP (distinct synthetic frames, so the
-resident inputs total ~750 MB, well past the 256 MiB Infinity Cache: the mask kernel reads HBM, not L3).
-With N > 1 every rank encodes its own GOPs (independent frames shard; weak scaling) and the step compacts
-its per-frame (filter, witness, stats) rows into one exact-size record on the device and gathers it to
-rank 0 over RCCL inside the step (asynchronously, overlapping the next step's kernels).
-`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks ITSELF (one process per GPU, RCCL over
-127.0.0.1); under `python -m torch.distributed.run --nproc-per-node N` it joins the launcher's ranks instead.
-After the weak-scaling headline the same process group runs BASELINE configs[2] and [4] as written -- ONE clip of 300 frames
-(keyframe every 30; 8-bit, then 16-bit) sharded by frame over the ranks (strong scaling, run_clip()) -- and adds them to the
-line as `clip300` / `clip300_uint16` (with and without the gather to rank 0); `--clip-frames F` runs only that mode.
+A step = one pass of the hot path over one GOP resident in HBM: residual masks of the 29 inter-frames of a 1920x1080 YUV444 30-frame
+GOP -> ones counts to the host -> filter geometry (float64, host) -> Bloom insert -> query + witness compaction (BASELINE.json
+configs[1], k* = 2.3).  `--streams` GOP pipelines are in flight per GPU, EACH WITH ITS OWN GOPs (distinct synthetic frames, ~750 MB of
+resident input: the mask kernel reads HBM, not the Infinity Cache).  `--gops-per-call G` makes a step ONE rbf_encode_runs call over G GOPs
+(one launch sequence per G x 29 inter-frames); the default stays 1 and the default run adds a `batched_gops` leg with 4.
 
-Prints ONE JSON line on rank 0.  After the timed region every pipeline's 29 frames are compared with the
-CPU oracle (`verified_vs_oracle`).  `roofline` prices the dominant kernel (query) at its ALGORITHMIC bytes
-(packed mask in + filter in + witness out) against the 8 TB/s HBM peak, from its UNCONTENDED launch time
-(HIP events on the launching stream, >= 50 launches, one pipeline alone); the event time measured inside
-the timed region, where four pipelines queue behind each other, is reported as `latency_under_overlap_ms`.
-`cpu_baseline` is the CPU oracle (scalar C port of the reference algorithm) timed on the host.
+Timing protocol: --warmup steps, then untimed settling (windows of --steps steps until two agree within 2 % and 30 ms have gone by),
+then NINE regions of EXACTLY --steps steps, each between barrier + synchronize, max over ranks; the MEDIAN region is the headline
+(`steps` = --steps, `regions_ms` lists all nine).  One long region follows as `steady_state`.
+
+With N > 1 every rank encodes its own GOPs (weak scaling), compacts each step's rows into one exact-size record on the device and
+gathers it to rank 0 over RCCL inside the step.  `python bench.py --gpus N` without a launcher environment starts the N ranks ITSELF (one
+process per GPU, RCCL over 127.0.0.1); under `python -m torch.distributed.run --nproc-per-node N` it joins the launcher's ranks.
+`--backend gloo --one-device` lets the N ranks share GPU 0 (records staged through host memory): the sharded path with the real kernels
+on a 1-GPU box.  After the headline the same process group runs BASELINE configs[2] and [4] as written -- ONE clip of 300 frames (keyframe
+every 30; 8-bit, then 16-bit) sharded by frame over the ranks, every rank's frames in equal multi-GOP blocks (strong scaling, run_clip())
+-- as `clip300` / `clip300_uint16`; `--clip-frames F` runs only that mode.  A single-GPU default run also carries the legs
+`decode_1080p`, `interleaved_yuv444`, `batched_gops`, `config4_2160p` (+ `_gop9`) and `e2e_surface` (the plugin surface end to end).
+
+Prints ONE JSON line on rank 0.  After the timed regions every GOP of every pipeline is compared with the CPU oracle
+(`verified_vs_oracle`); so is every leg.  `roofline` prices the dominant kernel (query) at its ALGORITHMIC bytes (packed mask in + filter
+in + witness out) against the 8 TB/s HBM peak, from its UNCONTENDED launch time (HIP events on the launching stream, 50 launches, one
+pipeline alone); `traffic` and `issue` are constants replayed from profiles/ and tagged as such.  `cpu_baseline` is the CPU oracle
+(scalar C port of the reference algorithm) timed on the host.
 """
 import argparse
 import json

@@ -43,6 +43,17 @@ def test_clip_sharded_over_ranks_on_one_device(world, bits, frames):
     assert v["bytes_gathered_on_rank0"] > 0 and res["value"] > 0
 
 
+def test_weak_mode_two_ranks_on_one_device():
+    """The driver's `--gpus N` line (weak scaling: every rank codes its own GOPs) at N = 2 on one device over gloo: both ranks run the
+    pipelines through the settle / region protocol in step with each other, rank 0 verifies its GOPs against the oracle and prints the aggregate.  (The record gather of the weak mode posts device
+    tensors and needs RCCL: `tests/test_gpu_dist_nccl.py` runs it at world 1.)"""
+    res = run_json([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "8", "--warmup", "2", "--width", "640", "--height", "360",
+                    "--frames", "8", "--no-cpu-baseline", "--no-clips", "--no-legs", "--gops-per-call", "2", "--gops-per-pipeline", "1"], timeout=900)
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 8 and res["value"] > 0
+    assert res["config"]["backend"] == "gloo" and res["config"]["ranks_share_one_device"] and not res["config"]["gather_to_rank0"]
+    assert res["config"]["pixels_per_step"] == 2 * 2 * 7 * 640 * 360 and res["verified_vs_oracle"]["frames"] == 4 * 14
+
+
 WORKER = r'''
 import json, os, sys, time
 import numpy as np
