@@ -86,6 +86,7 @@ int rbf_free(rbf_ctx *ctx, void *ptr_dev);
 int rbf_memset(rbf_ctx *ctx, void *dst_dev, int value, size_t bytes);            /* async */
 int rbf_memcpy_h2d(rbf_ctx *ctx, void *dst_dev, const void *src, size_t bytes);  /* blocks */
 int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes);  /* blocks */
+int rbf_memcpy_d2d(rbf_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);   /* async, on the context's stream */
 
 /* Per-kernel HIP-event timing (bench.py): launches of the selected kernels are bracketed by
  * events on the context's stream.  `on`: 0 = off, 1 = every kernel, otherwise a bit mask with

@@ -50,6 +50,7 @@ _PROTOS = {
     "rbf_memset": (_int, [_vp, _vp, _int, ctypes.c_size_t]),
     "rbf_memcpy_h2d": (_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     "rbf_memcpy_d2h": (_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "rbf_memcpy_d2d": (_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     "rbf_timing_enable": (_int, [_vp, _int]),
     "rbf_timing_reset": (_int, [_vp]),
     "rbf_ctx_force_generic": (_int, [_vp, _int]),

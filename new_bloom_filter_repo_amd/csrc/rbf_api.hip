@@ -352,6 +352,15 @@ int rbf_memcpy_d2h(rbf_ctx *ctx, void *dst, const void *src_dev, size_t bytes)
     return RBF_OK;
 }
 
+int rbf_memcpy_d2d(rbf_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
+{
+    if (int r = set_device(ctx)) return r;
+    if (bytes == 0) return RBF_OK;
+    if (!dst_dev || !src_dev) return fail(RBF_EINVAL, "null pointer");
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return RBF_OK;
+}
+
 int rbf_timing_enable(rbf_ctx *ctx, int on)
 {
     if (int r = set_device(ctx)) return r;

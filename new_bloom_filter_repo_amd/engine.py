@@ -348,31 +348,53 @@ def gather_values(ctx, frame, mask_packed):
     return vals
 
 
-def apply_chain(ctx, base, masks_packed, values_list):
+def apply_chain(ctx, base, masks_packed, values_list, chunk_frames=64):
     """A8 for a run of inter-frames: frame t = frame t-1 with `values_list[t]` written at mask t's '1' pixels
-    (improved_video_compressor.py:849-909).  The frame stays on the device between steps; every
-    reconstructed frame is downloaded once.  Returns the list of frames (copies)."""
+    (improved_video_compressor.py:849-909).  The run is rebuilt ON THE DEVICE in chunks of `chunk_frames`: one upload of the chunk's masks,
+    one of its values, then per frame a device-to-device copy of its predecessor and one scatter, no host round trip in between; the
+    chunk's frames come back in ONE download.  Returns the list of frames (views of the downloaded blocks)."""
     base = np.ascontiguousarray(base)
     H, W = base.shape[:2]
     C = base.shape[2] if base.ndim == 3 else 1
     sb = base.dtype.itemsize
     n = H * W
     stride = nat.packed_stride(n)
-    fb = ctx.alloc(base.nbytes).upload(base)
-    mb = ctx.alloc(stride)
-    vcap = max([8] + [np.asarray(v).nbytes for v in values_list])
-    vb = ctx.alloc(vcap)
+    fbytes = base.nbytes
+    total = len(masks_packed)
     out = []
-    row = np.zeros(stride, dtype=np.uint8)
-    for mask_packed, values in zip(masks_packed, values_list):
-        row[:] = 0
-        row[:(n + 7) // 8] = np.asarray(mask_packed, dtype=np.uint8)[:(n + 7) // 8]
-        mb.upload(row)
-        values = np.ascontiguousarray(values, dtype=base.dtype).reshape(-1)
-        if values.nbytes:
-            vb.upload(values)
-        nat.check(nat.lib().rbf_scatter_values(ctx.handle, fb.ptr, W, H, W * C * sb, C * sb, sb, C, mb.ptr, vb.ptr))
-        out.append(fb.download(base.nbytes).view(base.dtype).reshape(base.shape).copy())
+    if total == 0:
+        return out
+    L = nat.lib()
+    per = max(1, min(int(chunk_frames), total))
+    fb = ctx.alloc((per + 1) * fbytes)                            # slot 0: the predecessor of the chunk's first frame
+    mb = ctx.alloc(per * stride)
+    vcap = 8
+    for c0 in range(0, total, per):
+        vcap = max(vcap, sum(np.asarray(v).nbytes for v in values_list[c0:c0 + per]))
+    vb = ctx.alloc(vcap)
+    prev = base
+    for c0 in range(0, total, per):
+        cnt = min(per, total - c0)
+        rows = np.zeros((cnt, stride), dtype=np.uint8)
+        vals, offs = [], []
+        off = 0
+        for j in range(cnt):
+            rows[j, :(n + 7) // 8] = np.asarray(masks_packed[c0 + j], dtype=np.uint8)[:(n + 7) // 8]
+            v = np.ascontiguousarray(values_list[c0 + j], dtype=base.dtype).reshape(-1)
+            offs.append(off)
+            off += v.nbytes
+            vals.append(v)
+        fb.upload(prev, 0)
+        mb.upload(rows)
+        if off:
+            vb.upload(np.concatenate(vals))
+        for j in range(cnt):
+            dst = fb.ptr + (j + 1) * fbytes
+            nat.check(L.rbf_memcpy_d2d(ctx.handle, dst, fb.ptr + j * fbytes, fbytes))
+            nat.check(L.rbf_scatter_values(ctx.handle, dst, W, H, W * C * sb, C * sb, sb, C, mb.ptr + j * stride, vb.ptr + offs[j]))
+        block = fb.download(cnt * fbytes, offset=fbytes).view(base.dtype).reshape((cnt,) + base.shape)
+        out += [block[j] for j in range(cnt)]
+        prev = block[cnt - 1]
     for b in (fb, mb, vb):
         b.free()
     return out

@@ -60,7 +60,7 @@ class ImprovedVideoCompressor:
         self.max_diff_threshold = max_diff_threshold
         self.bloom_threshold_modifier = bloom_threshold_modifier
         self.batch_size = batch_size
-        self.num_threads = max(1, num_threads or min(32, os.cpu_count() or 1))     # zlib of keyframes / changed values
+        self.num_threads = max(1, num_threads or min(64, os.cpu_count() or 1))     # zlib of keyframes / changed values
         self.gop_batching = bool(gop_batching)
         self.block_frames = max(2, int(block_frames)) if block_frames else min(128, max(2, 4 * self.keyframe_interval))
         self.use_direct_yuv = use_direct_yuv
@@ -191,11 +191,16 @@ class ImprovedVideoCompressor:
             pending = {}
 
             def key(t):
-                pending[t] = (KEY, pool.submit(self.compressor.compress_frame, frames[t - first_index]))
+                if t not in pending:
+                    pending[t] = (KEY, pool.submit(self.compressor.compress_frame, frames[t - first_index]))
+            # the keyframes the rule fixes in advance go to the host threads FIRST: their zlib-9 (the longest single jobs, ~0.3 s for a 1080p
+            # frame and its three planes) then runs under the GPU's blocks instead of behind the last one
+            for t in range(start, stop):
+                if not inter_frames or t % I == 0 or t - 1 < first_index:
+                    key(t)
             t = start
             while t < stop:
                 if not inter_frames or t % I == 0 or t - 1 < first_index:
-                    key(t)
                     t += 1
                     continue
                 end = min(stop, t - 1 + self.block_frames)                   # the block reads frames t-1 .. end-1
