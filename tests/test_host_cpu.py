@@ -300,3 +300,29 @@ def test_graft_entry_build_check_follows_the_header():
     """__graft_entry__.build() compares the library's ABI version with include/rbf.h (round 4: a literal 2 survived the bump to 3)."""
     src = open(os.path.join(REPO, "__graft_entry__.py"), encoding="utf-8").read()
     assert "RBF_ABI_VERSION" in src and "rbf_version() ==" not in src
+
+
+def test_yuv_frame_planes_are_lazy_copies_and_blocks_are_zero_copy_views():
+    """Host-side helpers of the plugin surface (no GPU): YUVFrame.yuv_info behaves like the reference's dict of plane copies
+    (fixed_video_compressor.py:292-296) but copies a plane on first use; _as_block hands contiguous frames to the upload without a copy."""
+    from new_bloom_filter_repo_amd.frame_codec import FixedVideoCompressor, YUVFrame
+    from new_bloom_filter_repo_amd.video_compressor import _as_block
+    clip = np.random.default_rng(5).integers(0, 256, (4, 6, 8, 3), dtype=np.uint8)
+    f = YUVFrame(clip[1])
+    info = f.yuv_info
+    assert hasattr(f, "yuv_info") and info.get("format", "x") == "YUV444" and "u_plane" in info and info.get("nope") is None
+    assert not any(k in dict.keys(info) for k in ("y_plane", "u_plane", "v_plane"))            # nothing copied yet
+    u = info["u_plane"]
+    assert u.flags.c_contiguous and np.array_equal(u, clip[1][:, :, 1]) and not np.shares_memory(u, clip) and info["u_plane"] is u
+    with pytest.raises(KeyError):
+        info["w_plane"]
+    fx = FixedVideoCompressor()
+    back = fx.decompress_frame(fx.compress_frame(f))                                        # the keyframe record carries the three planes
+    assert np.array_equal(back.data, clip[1]) and np.array_equal(back.yuv_info["v_plane"], clip[1][:, :, 2])
+    blk = _as_block([clip[i] for i in range(4)])
+    assert np.shares_memory(blk, clip) and np.array_equal(blk, clip)
+    blk = _as_block([clip[i] for i in (0, 2)])
+    assert not np.shares_memory(blk, clip) and np.array_equal(blk, clip[[0, 2]])
+    c16 = clip.astype(np.uint16) * 257
+    blk = _as_block([c16[i] for i in range(1, 4)])
+    assert blk.dtype == np.uint16 and np.shares_memory(blk, c16) and np.array_equal(blk, c16[1:])
