@@ -881,6 +881,17 @@ def verify_all(host_gops, res_all, n, npipes):
     return {"frames": frames_checked, "pipelines": npipes, "fields": "mask, k, l, filter, witness", "seconds": round(time.perf_counter() - t0, 2)}
 
 
+def _cgroup_cpu_max():
+    """The container's CPU quota as the kernel states it ("max 100000" = unlimited), or None: says why 256 threads may not mean 256 cores."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            pass
+    return None
+
+
 def cpu_baseline(res, n, nframes):
     """CPU oracle (scalar C port of the reference loops, oracle/rbf_oracle.c) on the step's own masks:
     residual mask is not included (numpy-trivial); insert + query/witness, one core, >= ~10 s of work."""
@@ -900,27 +911,43 @@ def cpu_baseline(res, n, nframes):
             t_total += time.perf_counter() - t0
             px += n
         passes += 1
-    # the same port with the frames spread over the host's cores (frames are independent; ctypes drops the GIL)
-    from concurrent.futures import ThreadPoolExecutor
+    # the same port with the frames spread over the host's cores (frames are independent; ctypes drops the GIL).  Every thread owns its
+    # output buffers for the whole run and touches them beforehand: allocating 2.6 MB per call (round 4) had 256 threads fight over the
+    # process's address-space lock (mmap / page faults / munmap) and capped the figure at ~10x one core.
+    import threading
     threads = max(1, os.cpu_count() or 1)
-    jobs = max(len(frames), 2 * threads)          # two frames per host core (the step's masks, cyclically): every core it reports is busy
+    per_thread = 2                                # frames per thread (the step's masks, cyclically): ~0.2 s of work each
+    jobs = threads * per_thread
+    lmax = max(r["l"] for r in frames)
+    start_evt = threading.Event()
+    ready = threading.Barrier(threads + 1)
+    done = [0.0] * threads
 
-    def one(j):
-        i = j % len(frames)
-        r, mask = frames[i], masks[i]
-        bit_array = np.zeros(r["l"], dtype=np.uint8)
-        witness = np.zeros(n, dtype=np.uint8)
-        L.orc_compress(mask.ctypes.data, n, r["l"], ctypes.c_double(r["k"]), seeds, bit_array.ctypes.data, witness.ctypes.data)
-    with ThreadPoolExecutor(threads) as pool:
-        list(pool.map(one, range(threads)))       # (threads started, pages touched)
-        t0 = time.perf_counter()
-        list(pool.map(one, range(jobs)))
-        t_all = time.perf_counter() - t0
+    def worker(t):
+        bit_array = np.ones(lmax, dtype=np.uint8)
+        witness = np.ones(n, dtype=np.uint8)      # (pages touched)
+        ready.wait()
+        start_evt.wait()
+        for j in range(per_thread):
+            r, mask = frames[(t * per_thread + j) % len(frames)], masks[(t * per_thread + j) % len(frames)]
+            L.orc_compress(mask.ctypes.data, n, r["l"], ctypes.c_double(r["k"]), seeds, bit_array.ctypes.data, witness.ctypes.data)
+        done[t] = time.perf_counter()
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for th in ths:
+        th.start()
+    ready.wait()
+    t0 = time.perf_counter()
+    start_evt.set()
+    for th in ths:
+        th.join()
+    t_all = max(done) - t0
     return {"value": round(px / t_total / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
             "sample": "%d passes over the step's %d masks (%d pixels each), insert+query/witness in the scalar C oracle, %.1f s"
                       % (passes, len(frames), n, t_total),
             "all_cores": {"value": round(jobs * n / t_all / 1e6, 1), "unit": "Mpixel/s", "cores": threads, "host_cpus": os.cpu_count(),
-                          "sample": "%d frames (the step's %d masks, cyclically) over %d threads, one frame per call, %.2f s" % (jobs, len(frames), threads, t_all)},
+                          "usable_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": _cgroup_cpu_max(),
+                          "speedup_over_one_core": round(jobs * n / t_all / (px / t_total), 1),
+                          "sample": "%d frames (the step's %d masks, cyclically) over %d threads with their own pre-touched buffers, %d frames each, one frame per call, %.2f s" % (jobs, len(frames), threads, per_thread, t_all)},
             "reference_python_mpixels_per_s": {"value": 0.38, "source": "BASELINE.md (recorded constant: the reference's own Python loops, build container, 1 core)"}}
 
 
