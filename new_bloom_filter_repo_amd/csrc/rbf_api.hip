@@ -529,6 +529,7 @@ struct Plan {
 
 constexpr size_t HASH_TABLE_CACHE_BYTES = (size_t)96 << 20;    // k_insert_positions: a pixel-index table larger than this is not worth gathering from (1440p, 118 MB: step 454 -> 425 us hashed; 2160p, 265 MB: insert 124 -> 97; re-measured with the 26-byte table of round 4: 1440p equal, 2160p 207 -> 192 Gpixel/s gathered, profiles/r04_bigtable.txt)
 constexpr uint32_t MAX_INSERT_TILES = 7, MAX_QUERY_TILES = 3;     // measured crossovers, see make_plan
+constexpr uint32_t STREAM_MIN_FRAMES = 64;                        // coded frames of a launch from which its one-shot data is moved with non-temporal accesses (rbf_kernels_lds.h, cache-policy note)
 
 static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n, bool have_ones = false)
 {
@@ -877,10 +878,11 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
             }
             fin = *gop_tail;
             fin.enabled = 1; fin.count = pairs; fin.ticket = ctx->mask_ticket; fin.ones_out = ones_dev;
+            fin.stream_clears = pairs >= STREAM_MIN_FRAMES ? 1u : 0u;
             fused = true;
         }
         LaunchTimer t(ctx, RBF_K_MASK);
-#define RBF_MASK_GOP(S, PB, Z) hipLaunchKernelGGL((k_residual_mask_gop<S, PB, false, Z>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
+#define RBF_MASK_GOP(S, PB, Z) hipLaunchKernelGGL((k_residual_mask_gop<S, PB, true, Z>), dim3(bx, chunks), dim3(WG_THREADS), lds, ctx->stream,   \
                                (const uint8_t *)frames_dev, frame_stride_bytes, nframes, fast_segs, thr_floor, thr_tab_fast, (uint16_t *)masks_dev, \
                                mask_stride_bytes / 2, acc, mc, fin)
 #define RBF_MASK_GOP2(S, PB) do { if (thr0) RBF_MASK_GOP(S, PB, true); else RBF_MASK_GOP(S, PB, false); } while (0)
@@ -1052,6 +1054,9 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
     }
     FrameTable tab;
     if (int r = fill_table(params, nframes, &tab)) return r;
+    uint32_t coded = 0;
+    for (uint32_t f = 0; f < nframes; ++f) coded += params[f].m ? 1u : 0u;
+    const bool stream_once = coded >= STREAM_MIN_FRAMES;            // a block of several GOPs: its one-shot data must not evict the hash table and the probe images
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * pl.words_per_seg * 8)) return r;
     if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4 + 16)) return r;     // + 16: k_compact_witness reads the counts four to a load
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
@@ -1155,7 +1160,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
             const uint32_t vec_ok = (words % 4 == 0 && ((uintptr_t)filters_dev % 16) == 0) ? 1u : 0u;
             uint32_t bx = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx < 1) bx = 1;
-            hipLaunchKernelGGL(k_filter_reduce, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+            hipLaunchKernelGGL(stream_once ? k_filter_reduce<true> : k_filter_reduce<false>, dim3(bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                                (const uint32_t *)ctx->partials, part_stride, pl.S, pl.slices, tab, (uint32_t *)filters_dev, words, stats_dev, vec_ok,
                                image, (uint64_t)pl.image_stride_words);
         }
@@ -1177,7 +1182,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
             const uint64_t words = filter_stride_bytes / 4;
             uint32_t bx2 = (uint32_t)((words + WG_THREADS * 4 - 1) / (WG_THREADS * 4));
             if (bx2 < 1) bx2 = 1;
-            hipLaunchKernelGGL(k_filter_reduce, dim3(bx2, nframes), dim3(WG_THREADS), 0, ctx->stream,
+            hipLaunchKernelGGL(k_filter_reduce<false>, dim3(bx2, nframes), dim3(WG_THREADS), 0, ctx->stream,
                                (const uint32_t *)filters_dev, words, 1u, ones, tab, (uint32_t *)filters_dev, words, stats_dev, 0u,
                                image, (uint64_t)pl.image_stride_words);
         }
@@ -1190,7 +1195,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         uint64_t bx = (words + WG_THREADS - 1) / WG_THREADS;
         if (bx < 1) bx = 1;
         LaunchTimer t(ctx, RBF_K_STITCH);
-        hipLaunchKernelGGL(k_compact_witness, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL(stream_once ? k_compact_witness<true> : k_compact_witness<false>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                            ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
                            (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4, stats_dev);
     }

@@ -19,6 +19,17 @@
 
 namespace rbf {
 
+// Cache policy for data that is read or written ONCE.  A step of several GOPs moves ~750 MB through 32 MB of L2 and the 256 MB Infinity
+// Cache, next to two things that must stay cached: the pixel-index hash table the insert gathers from (54 MB) and the probe images every
+// query workgroup restages.  Non-temporal loads / stores keep the one-shot streams from evicting them.  Measured (profiles/r05_cache_policy.txt,
+// four pipelines): the mask kernel's frame loads alone +2.6 % at one GOP per call and +1.6 % at four; with the witness-row clears, the
+// reduce kernel's partial loads and filter stores and the compaction's pass-word and mask loads +5.4 % at four GOPs per call, +3.8 % at
+// three, nothing at two, -1 % at one (so those follow the batch size: STREAM).  The query kernel's pass-byte stores and the compaction's
+// witness stores must NOT stream (-2 ... -3 %: their consumers follow at once), nor the table gathers (insert 33 -> 55 us).
+typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(uint4 *p, uint4 v) { const nt_u32x4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<nt_u32x4 *>(p)); }
+__device__ __forceinline__ uint4 load_stream(const uint4 *p) { const nt_u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(p)); return make_uint4(x.x, x.y, x.z, x.w); }
+
 constexpr int QL_THREADS = 1024;                   // 16 waves, one workgroup per CU, filter double-buffered in LDS
 constexpr int QL_WAVES = QL_THREADS / WAVE;
 constexpr int QL_P = 8;                            // pixels per lane
@@ -158,6 +169,7 @@ __global__ __launch_bounds__(IL_THREADS) void k_insert_lds(
 // OR the S partial filters of every frame into the final packed filter; count its set bits.
 // 16-byte accesses (rows are 8-byte padded and 16-byte aligned bases are not guaranteed, so the
 // vector path is taken only when both strides are multiples of 4 words and the bases are aligned).
+template <bool STREAM>
 __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
     const uint32_t *partials, uint64_t part_stride_words32, uint32_t Smax /* row pitch of the partials, in slices */,
     const SliceTable slices /* partial filters per frame */,
@@ -187,7 +199,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const uint32_t sj = s0 + j < S ? s0 + j : S - 1;
-                        x[j] = *reinterpret_cast<const uint4 *>(part + (uint64_t)sj * part_stride_words32 + w);
+                        const uint4 *src = reinterpret_cast<const uint4 *>(part + (uint64_t)sj * part_stride_words32 + w);
+                        x[j] = STREAM ? load_stream(src) : *src;
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { v.x |= x[j].x; v.y |= x[j].y; v.z |= x[j].z; v.w |= x[j].w; }
@@ -196,7 +209,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_filter_reduce(
                 if (w + 2 >= fwords) v.z = 0;
                 if (w + 3 >= fwords) v.w = 0;
             }
-            if (m) *reinterpret_cast<uint4 *>(filt + w) = v;     // passthrough frames: filter untouched
+            if (m) {                                             // passthrough frames: filter untouched
+                if (STREAM) store_stream(reinterpret_cast<uint4 *>(filt + w), v); else *reinterpret_cast<uint4 *>(filt + w) = v;
+            }
             if (image && w < image_stride_words32)
                 *reinterpret_cast<uint4 *>(image + (uint64_t)f * image_stride_words32 + w) =
                     make_uint4(~__builtin_bswap32(v.x), ~__builtin_bswap32(v.y), ~__builtin_bswap32(v.z), ~__builtin_bswap32(v.w));
@@ -625,6 +640,7 @@ __device__ __forceinline__ uint32_t pdep32_lut(const uint8_t *lut, uint32_t w, u
     return out;
 }
 
+template <bool STREAM>
 __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
     const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n,
@@ -652,8 +668,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     const uint32_t w = wbeg + threadIdx.x;
     // my word (packed -> bit b = position 64w + b) and its mask word: requested before anything waits
     const bool have = w < total && w < nwords;
-    const uint64_t pw_raw = have ? pwf[w] : 0ull;
-    const uint64_t mk_raw = have ? masks[(uint64_t)f * mask_stride_words64 + w] : 0ull;
+    const uint64_t *mkp = masks + (uint64_t)f * mask_stride_words64 + w;
+    const uint64_t pw_raw = have ? (STREAM ? __builtin_nontemporal_load(pwf + w) : pwf[w]) : 0ull;        // read once: see the cache-policy note at the top
+    const uint64_t mk_raw = have ? (STREAM ? __builtin_nontemporal_load(mkp) : *mkp) : 0ull;
     const uint32_t part = counts_before_share(cnt, wbeg / words_per_seg);
     lut[threadIdx.x] = (uint8_t)pext4_entry(threadIdx.x);
     buf[threadIdx.x] = 0;
@@ -851,6 +868,7 @@ struct MaskFinish {
     uint64_t token;
     uint4 *clear_a; uint64_t quads_a;
     uint4 *clear_b; uint64_t quads_b;
+    uint32_t stream_clears;        // 1: region a (the witness rows) is cleared with non-temporal stores (blocks of several GOPs)
 };
 
 // The temporal chunks of one launch (blockIdx.y).  count == 0: uniform chunks of `ppc` pairs over the whole block (one run).  Otherwise
@@ -939,7 +957,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         __syncthreads();
     }
     if (wave != 0) {                               // waves 1..3: their share of the clears, and out
-        for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
+        if (fin.stream_clears) for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) store_stream(fin.clear_a + i, z);
+        else for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
         for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_b; i += nwg * WG_THREADS) fin.clear_b[i] = z;
         return;
     }
@@ -961,7 +980,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         }
     }
     is_last = __builtin_amdgcn_readfirstlane(is_last);
-    for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
+    if (fin.stream_clears) for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) store_stream(fin.clear_a + i, z);
+    else for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
     for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_b; i += nwg * WG_THREADS) fin.clear_b[i] = z;
     if (!is_last) return;
     // the last workgroup: counts out (to the caller's array and the host), accumulator and ticket back to zero
