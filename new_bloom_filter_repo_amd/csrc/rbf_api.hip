@@ -529,7 +529,7 @@ struct Plan {
 
 constexpr size_t HASH_TABLE_CACHE_BYTES = (size_t)96 << 20;    // k_insert_positions: a pixel-index table larger than this is not worth gathering from (1440p, 118 MB: step 454 -> 425 us hashed; 2160p, 265 MB: insert 124 -> 97; re-measured with the 26-byte table of round 4: 1440p equal, 2160p 207 -> 192 Gpixel/s gathered, profiles/r04_bigtable.txt)
 constexpr uint32_t MAX_INSERT_TILES = 7, MAX_QUERY_TILES = 3;     // measured crossovers, see make_plan
-constexpr uint32_t STREAM_MIN_FRAMES = 64;                        // coded frames of a launch from which its one-shot data is moved with non-temporal accesses (rbf_kernels_lds.h, cache-policy note)
+constexpr uint64_t STREAM_MIN_PIXEL_FRAMES = 64ull * 1920 * 1080;  // pixels x coded frames of a launch from which its one-shot data is moved with non-temporal accesses (rbf_kernels_lds.h, cache-policy note): 1080p from 64 frames, 2160p from 16
 
 static Plan make_plan(const rbf_ctx *ctx, const rbf_filter_params *params, uint32_t nframes, uint64_t n, bool have_ones = false)
 {
@@ -878,7 +878,7 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
             }
             fin = *gop_tail;
             fin.enabled = 1; fin.count = pairs; fin.ticket = ctx->mask_ticket; fin.ones_out = ones_dev;
-            fin.stream_clears = pairs >= STREAM_MIN_FRAMES ? 1u : 0u;
+            fin.stream_clears = (uint64_t)pairs * n >= STREAM_MIN_PIXEL_FRAMES ? 1u : 0u;
             fused = true;
         }
         LaunchTimer t(ctx, RBF_K_MASK);
@@ -1056,7 +1056,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
     if (int r = fill_table(params, nframes, &tab)) return r;
     uint32_t coded = 0;
     for (uint32_t f = 0; f < nframes; ++f) coded += params[f].m ? 1u : 0u;
-    const bool stream_once = coded >= STREAM_MIN_FRAMES;            // a block of several GOPs: its one-shot data must not evict the hash table and the probe images
+    const bool stream_once = (uint64_t)coded * n >= STREAM_MIN_PIXEL_FRAMES;      // a block of several GOPs (or of large frames): its one-shot data must not evict the hash table and the probe images
     if (int r = grow((void **)&ctx->pass_words, &ctx->pass_words_cap, (size_t)nframes * pl.nseg * pl.words_per_seg * 8)) return r;
     if (int r = grow((void **)&ctx->seg_cnt, &ctx->seg_cnt_cap, (size_t)nframes * pl.nseg * 4 + 16)) return r;     // + 16: k_compact_witness reads the counts four to a load
     if (int r = grow((void **)&ctx->seg_off, &ctx->seg_off_cap, (size_t)nframes * pl.nseg * 8)) return r;
