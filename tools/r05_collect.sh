@@ -10,6 +10,6 @@ import json,sys;d=json.loads(sys.stdin.readline());print('streams %d: %.0f Mpixe
 bash tools/tile_sweep.sh > $O/config4_2160p_lds_tile_sweep.txt 2>&1
 python tools/decode_bench.py > $O/decode_bench.txt 2>&1; python tools/decode_bench.py 3840 2160 9 >> $O/decode_bench.txt 2>&1
 ( time python -m pytest tests -m gpu -q ) > $O/gpu_tests.txt 2>&1
-timeout 300 python tools/fuzz_soak.py 180 > $O/fuzz_soak.txt 2>&1
-timeout 200 python tools/fuzz_surface.py 120 > $O/fuzz_surface.txt 2>&1
-tail -3 $O/gpu_tests.txt $O/fuzz_soak.txt $O/fuzz_surface.txt $O/density_sweep.txt
+timeout 200 python tools/fuzz_soak.py 120 > $O/fuzz_soak.txt 2>&1
+timeout 150 python tools/fuzz_surface.py 90 > $O/fuzz_surface.txt 2>&1
+tail -qn 3 $O/gpu_tests.txt $O/fuzz_soak.txt $O/fuzz_surface.txt $O/density_sweep.txt

@@ -13,8 +13,9 @@ NL="--no-cpu-baseline --no-verify --no-clips --no-legs"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_default" -o stats -- python $ROOT/bench.py $NL --steps 20 --warmup 5 > "$OUT/stats_default.log" 2>&1
 ALONE="--streams 1 --steps 10 --warmup 2 --exact-steps --no-kernel-timing --force-bits 32768 $NL"
 declare -A SHAPE=( [g1]="" [g4]="--gops-per-call 4 --gops-per-pipeline 1" [c4]="--width 3840 --height 2160 --frames 30 --gops-per-pipeline 1" )
+declare -A STEPS=( [g1]=160 [g4]=48 [c4]=16 )      # (time stats over many launches: the first ones after start-up run at lower clocks)
 for s in g1 g4 c4; do
-  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_$s" -o stats -- python $ROOT/bench.py $ALONE ${SHAPE[$s]} > "$OUT/stats_$s.log" 2>&1
+  rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_$s" -o stats -- python $ROOT/bench.py $ALONE ${SHAPE[$s]} --steps ${STEPS[$s]} --warmup 8 > "$OUT/stats_$s.log" 2>&1
   rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch_$s" -o pmc -- python $ROOT/bench.py $ALONE ${SHAPE[$s]} > "$OUT/pmc_fetch_$s.log" 2>&1
   rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write_$s" -o pmc -- python $ROOT/bench.py $ALONE ${SHAPE[$s]} > "$OUT/pmc_write_$s.log" 2>&1
 done
