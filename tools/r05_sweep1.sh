@@ -1,4 +1,5 @@
 #!/bin/bash
+# (ran at commit 30a3087: --side-compact, --skip-kernels and --insert-grouped were removed from bench.py and the library afterwards; results in profiles/r05_sweep1.txt)
 # round 5, sweep 1: the multi-GOP block (rbf_encode_runs, 4 x 30 frames per call) -- insert launch shape, gather cache policy, mask chunks
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r05_sweep1; mkdir -p $O

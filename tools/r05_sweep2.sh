@@ -1,4 +1,5 @@
 #!/bin/bash
+# (ran at commit 30a3087: --skip-kernels was removed from bench.py and the library afterwards; results in profiles/r05_sweep2.txt)
 # round 5, sweep 2: insert slices x pipelines on the 4-GOP block; what every kernel costs the overlapped step (results wrong with --skip-kernels)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r05_sweep2; mkdir -p $O
