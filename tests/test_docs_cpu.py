@@ -51,3 +51,12 @@ def test_bench_replays_the_constants_it_names():
     assert m["frame_loop_issue_bound_valu_only_ms"] < m["frame_loop_issue_bound_ms"]
     assert m["kernel"].startswith("k_query_u64") and "k_query_u64" in src
 
+
+
+def test_integration_names_every_entry_point():
+    """INTEGRATION.md is the map from the C ABI to the reference: every function include/rbf.h declares appears in it."""
+    hdr = open(os.path.join(REPO, "include", "rbf.h"), encoding="utf-8").read()
+    doc = open(os.path.join(REPO, "INTEGRATION.md"), encoding="utf-8").read()
+    declared = set(re.findall(r"\b(rbf_[a-z0-9_]+)\s*\(", hdr))
+    missing = sorted(n for n in declared if n not in doc)
+    assert not missing, missing
