@@ -175,3 +175,38 @@ def test_begin_rejects_a_filter_stride_the_planner_could_outgrow():
         c.encode()                                 # the context is still usable
         ctx.sync()
         c.close()
+
+
+@pytest.mark.parametrize("W,H", [(640, 360), (322, 181)], ids=["whole_segments", "ragged"])
+def test_runs_with_per_pair_thresholds(oracle, W, H):
+    """Per-pair thresholds (the adaptive rule's thr_floors, improved_video_compressor.py:804-805) together with run starts: the fast mask
+    kernel then takes the chunk table AND the threshold table, the generic kernel the thresholds with INT32_MAX for the skipped pairs."""
+    frames, starts = make_runs(57, W, H, [[0.0889, 0.0889, 0.2], [0.05, 0.0889], [0.0889]])
+    F, n = len(frames), W * H
+    thr = [0, 3, 0, 9, 1, 0, 5, 2][:F - 1]
+    with nat.Context(0) as ctx:
+        coder = GopCoder(ctx, W, H, F, planar_luma=True, keep_interleaved=False, run_starts=starts)
+        coder.thr_tab = (ctypes.c_int32 * (F - 1))(*thr)
+        coder.load_frames(frames)
+        coder.encode()
+        res = coder.results()
+        skipped = {t - 1 for t in starts}
+        L = oracle.lib()
+        sd = (ctypes.c_uint64 * 3)(*P.SEEDS_VIDEO)
+        U8P = ctypes.POINTER(ctypes.c_uint8)
+        for f in range(F - 1):
+            r = res[f]
+            if f in skipped:
+                assert r.get("skipped") and not r["mask"].any() and r["ones"] == 0
+                continue
+            mask = np.ascontiguousarray(oracle.residual_mask(np.ascontiguousarray(frames[f][..., 0]), np.ascontiguousarray(frames[f + 1][..., 0]), float(thr[f])).reshape(-1), dtype=np.uint8)
+            assert np.array_equal(np.unpackbits(r["mask"])[:n], mask), (f, "mask")
+            k, l = oracle.optimal_params(n, np.uint64(int(mask.sum())) / n)
+            if l == 0 or l >= n:
+                assert r["l"] == 0
+                continue
+            bit_array, witness = np.zeros(l, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+            w = L.orc_compress(mask.ctypes.data_as(U8P), n, l, ctypes.c_double(k), sd, bit_array.ctypes.data_as(U8P), witness.ctypes.data_as(U8P))
+            assert (r["k"], r["l"]) == (k, l) and np.array_equal(np.unpackbits(r["filter"])[:l], bit_array), (f, "filter")
+            assert r["witness_bits"] == w and np.array_equal(np.unpackbits(r["witness"])[:w], witness[:w]), (f, "witness")
+        coder.close()
