@@ -469,7 +469,7 @@ def main():
                    "launcher": os.environ.get("RBF_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process"),
                    "rccl_ranks": world if (use_dist and args.backend == "nccl") else 0, "backend": args.backend if use_dist else None,
                    "ranks_share_one_device": bool(args.one_device),
-                   "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by gloo world-2 tests (incl. the self-spawn launcher) and nccl world-1 tests"},
+                   "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by world-2 / world-8 runs of the real kernels on ONE device over gloo (tests/test_gpu_dist_shared.py), gloo world-2/3 CPU tests (incl. the self-spawn launcher) and RCCL world-1 tests"},
     }
     if rank == 0 and gather:
         out["config"]["gathered_records_parsed_on_rank0"] = check_gathered(og, world, G, pairs, n, res_all)
@@ -723,8 +723,8 @@ def pipelines_leg(torch, nat, device, local_rank, W, H, F, bits, planar, G_res, 
         ach = alg_bytes / (alone["query"] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_query_s64t" if n > 1920 * 1080 else "k_query_u64", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBPS, 5), "avg_launch_ms": alone["query"], "launches_averaged": 20,
-                           "algorithmic_bytes_per_launch": int(alg_bytes), "frames_per_launch": coded_pairs,
-                           "traffic": replayed_traffic(W, H, F, bits, GPC)}
+                           "algorithmic_bytes_per_launch": int(alg_bytes), "frames_per_launch": coded_pairs}
+        out["roofline"].update(measured_traffic(W, H, F, bits, False, GPC))
     if verify:
         out["verified_vs_oracle"] = verify_all([h for h, _ in checked], [r for _, r in checked], n, len(checked))
     for c in coders:
