@@ -52,6 +52,7 @@ struct rbf_ctx {
     // scratch (grown on demand, never shrunk)
     uint32_t *seg_cnt = nullptr;     size_t seg_cnt_cap = 0;
     uint64_t *seg_off = nullptr;     size_t seg_off_cap = 0;
+    uint32_t *chunk_off = nullptr;   size_t chunk_off_cap = 0;   // k_chunk_offsets: where every compaction / expansion workgroup's witness bits start
     uint64_t *pass_words = nullptr;  size_t pass_words_cap = 0;
     uint32_t *partials = nullptr;    size_t partials_cap = 0;
     uint2 *ins_records = nullptr;    size_t ins_records_cap = 0;  // two-kernel insert: 8 bytes per set mask bit of the batch
@@ -281,6 +282,7 @@ int rbf_ctx_destroy(rbf_ctx *ctx)
     if (ctx->ones_pinned) (void)hipHostFree(ctx->ones_pinned);
     if (ctx->seg_cnt) (void)hipFree(ctx->seg_cnt);
     if (ctx->seg_off) (void)hipFree(ctx->seg_off);
+    if (ctx->chunk_off) (void)hipFree(ctx->chunk_off);
     if (ctx->pass_words) (void)hipFree(ctx->pass_words);
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ins_records) (void)hipFree(ctx->ins_records);
@@ -940,6 +942,18 @@ static int check_filter_strides(const rbf_filter_params *params, uint32_t nframe
     return RBF_OK;
 }
 
+// The scan in front of the compaction (encode) / expansion (decode): the start of every workgroup's range of witness bits, from the
+// segment pass counts the query kernel left (k_chunk_offsets, one workgroup per frame).
+static int launch_chunk_offsets(rbf_ctx *ctx, const Plan &pl, uint32_t nframes, uint32_t nchunks)
+{
+    if (WG_THREADS % pl.words_per_seg) return fail(RBF_EINVAL, "segments of %u words do not tile a workgroup's chunk", pl.words_per_seg);
+    if (int r = grow((void **)&ctx->chunk_off, &ctx->chunk_off_cap, (size_t)nframes * nchunks * 4)) return r;
+    LaunchTimer t(ctx, RBF_K_SCAN);
+    hipLaunchKernelGGL(k_chunk_offsets, dim3(nframes), dim3(CO_THREADS), 0, ctx->stream, (const uint32_t *)ctx->seg_cnt, pl.nseg,
+                       (uint32_t)WG_THREADS / pl.words_per_seg, nchunks, ctx->chunk_off);
+    return RBF_OK;
+}
+
 // query launch shared by encode and decode
 static int ensure_image(rbf_ctx *ctx, const Plan &pl, uint32_t nframes)
 {
@@ -1194,10 +1208,11 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         const uint64_t words = pl.nseg * pl.words_per_seg;
         uint64_t bx = (words + WG_THREADS - 1) / WG_THREADS;
         if (bx < 1) bx = 1;
+        if (int r = launch_chunk_offsets(ctx, pl, nframes, (uint32_t)bx)) return r;
         LaunchTimer t(ctx, RBF_K_STITCH);
         hipLaunchKernelGGL(stream_once ? k_compact_witness<true> : k_compact_witness<false>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                            ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
-                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4, stats_dev);
+                           (const uint64_t *)masks_dev, mask_stride_bytes / 8, n, (uint32_t *)witnesses_dev, witness_stride_bytes / 4, stats_dev, ctx->chunk_off);
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;
@@ -1613,10 +1628,11 @@ static int decode_chunk(rbf_ctx *ctx, const void *filters_dev, uint64_t filter_s
     if (!split) if (int r = launch_query(ctx, pl, n, nframes, tab, sd, filters_dev, filter_stride_bytes, false)) return r;
     {   // one lane per 64-position word; the kernel sums the earlier segment counts itself (until round 4: k_scan_segments + k_expand_mask_p)
         const uint64_t bx = (pl.nseg * wps + WG_THREADS - 1) / WG_THREADS;
+        if (int r = launch_chunk_offsets(ctx, pl, nframes, (uint32_t)bx)) return r;
         LaunchTimer t(ctx, RBF_K_EXPAND);
         hipLaunchKernelGGL(k_expand_mask, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                            ctx->pass_words, ctx->seg_cnt, pl.nseg, wps, (const uint32_t *)witnesses_dev, witness_stride_bytes / 4,
-                           (uint64_t *)masks_dev, mask_stride_bytes / 8, n);
+                           (uint64_t *)masks_dev, mask_stride_bytes / 8, n, ctx->chunk_off);
     }
     HIP_TRY(hipGetLastError());
     return RBF_OK;

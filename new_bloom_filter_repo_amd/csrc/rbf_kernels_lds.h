@@ -561,34 +561,40 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_tiled(
 // One lane per 64-pixel word: its bits are pext(mask word, pass word) placed at
 // seg_off[segment] + (passes of the segment's earlier words) in the pre-zeroed packed witness.
 // ------------------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) SegCounts4 { uint32_t x, y, z, w; };      // four segment counts: rows of seg_cnt are only dword-aligned
-
-// This thread's share of cnt[0] + ... + cnt[seg0 - 1] (sum the shares over the workgroup): four counts per load, four loads in flight
-// per thread.  (A thread of the last workgroup of a 1080p frame used to issue sixteen single-count loads behind 64-bit index
-// arithmetic: a third of k_compact_witness's instructions.)  The loads may run up to 12 bytes past seg0: the allocation is padded.
-__device__ __forceinline__ uint32_t counts_before_share(const uint32_t *__restrict__ cnt, uint32_t seg0)
+// Where the witness bits of every chunk of WG_THREADS words (= chunk_segs whole segments: the compaction's and the expansion's
+// workgroups) start: off[f][c] = passes of all earlier segments of frame f.  One workgroup per frame scans the frame's segment counts once
+// -- until round 5 every compaction workgroup summed all the counts in front of it by itself (a third of its instructions, and 1 MB of L2
+// reads per 1080p frame).  total < 2^32 (n < 2^32).
+constexpr int CO_THREADS = 1024;
+__global__ __launch_bounds__(CO_THREADS) void k_chunk_offsets(const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t chunk_segs, uint32_t nchunks,
+                                                              uint32_t *__restrict__ off)
 {
-    uint32_t part = 0;
-    if ((seg0 & 3u) == 0) {                                                   // (workgroup-uniform) whole quads only: segments of <= 64 words
-        for (uint32_t q0 = threadIdx.x; 4u * q0 < seg0; q0 += WG_THREADS * 4) {
-            SegCounts4 v[4];
-            bool in[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = 4u * (q0 + (uint32_t)k * WG_THREADS);
-                in[k] = i < seg0;
-                v[k] = *reinterpret_cast<const SegCounts4 *>(cnt + (in[k] ? i : 0u));
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t q = (v[k].x + v[k].y) + (v[k].z + v[k].w);
-                part += in[k] ? q : 0u;
-            }
-        }
-    } else {
-        for (uint32_t s0 = threadIdx.x; s0 < seg0; s0 += WG_THREADS) part += cnt[s0];
+    // a thread sums `per` consecutive counts (4 when a chunk has that many segments), the workgroup scans the sums, and the thread that
+    // holds a chunk's first segments writes the chunk's offset; frames of more than 1024 * per segments take several rounds with a carry
+    __shared__ uint32_t wtot[CO_THREADS / WAVE];
+    __shared__ uint32_t carry_s;
+    const uint32_t f = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
+    uint32_t *out = off + (uint64_t)f * nchunks;
+    const uint32_t per = (chunk_segs & 3u) == 0 ? 4u : (chunk_segs & 1u) == 0 ? 2u : 1u;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < nseg; base += (uint64_t)CO_THREADS * per) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * per;
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < per; ++k) sum += i0 + k < nseg ? cnt[i0 + k] : 0u;
+        const uint32_t incl = wave_inclusive_scan(sum);
+        if (lane == WAVE - 1) wtot[wave] = incl;
+        const uint32_t carry = carry_s;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t k = 0; k < wave; ++k) before += wtot[k];
+        if (i0 < nseg && i0 % chunk_segs == 0) out[i0 / chunk_segs] = before + incl - sum;
+        __syncthreads();
+        if (threadIdx.x == CO_THREADS - 1) carry_s = before + incl;
+        __syncthreads();
     }
-    return part;
 }
 
 // Software pext / pdep through a 256-byte LDS table of their 4-bit forms, entry [p4 << 4 | x4] (thread t of a 256-thread workgroup
@@ -597,7 +603,7 @@ __device__ __forceinline__ uint32_t counts_before_share(const uint32_t *__restri
 // by one broadcast and the table covers each of the 64 banks once, so there are no bank conflicts -- against a loop that ran as long as
 // the busiest lane of the wave (~9 rounds of 19 instructions for the compaction, ~22 of 14 for the expansion).
 static_assert(WG_THREADS == 256, "one table entry per thread");
-__device__ __forceinline__ uint32_t pext4_entry(uint32_t t)
+__host__ __device__ constexpr uint32_t pext4_entry(uint32_t t)
 {
     const uint32_t p4 = t >> 4, x4 = t & 15u;
     uint32_t r = 0, k = 0;
@@ -606,7 +612,7 @@ __device__ __forceinline__ uint32_t pext4_entry(uint32_t t)
         if ((p4 >> b) & 1u) { r |= ((x4 >> b) & 1u) << k; ++k; }
     return r;
 }
-__device__ __forceinline__ uint32_t pdep4_entry(uint32_t t)
+__host__ __device__ constexpr uint32_t pdep4_entry(uint32_t t)
 {
     const uint32_t p4 = t >> 4, x4 = t & 15u;
     uint32_t r = 0, k = 0;
@@ -615,6 +621,23 @@ __device__ __forceinline__ uint32_t pdep4_entry(uint32_t t)
         if ((p4 >> b) & 1u) { r |= ((x4 >> k) & 1u) << b; ++k; }
     return r;
 }
+// The two tables, built at compile time (until round 5 every workgroup computed its own: ~25 instructions per thread), 64 dwords each in
+// constant memory; wave 0 of a workgroup copies one into LDS.
+struct Lut256 { uint32_t w[64]; };
+template <bool PDEP>
+constexpr Lut256 make_lut4()
+{
+    Lut256 t{};
+    for (uint32_t i = 0; i < 256; ++i) t.w[i >> 2] |= (PDEP ? pdep4_entry(i) : pext4_entry(i)) << (8u * (i & 3u));
+    return t;
+}
+static __constant__ Lut256 LUT_PEXT4 = make_lut4<false>();
+static __constant__ Lut256 LUT_PDEP4 = make_lut4<true>();
+__device__ __forceinline__ void lut_to_lds(uint8_t *lut, const Lut256 &src)
+{
+    if (threadIdx.x < 64u) reinterpret_cast<uint32_t *>(lut)[threadIdx.x] = src.w[threadIdx.x];
+}
+
 // pext(x, p) of a 32-bit half: <= popc(p) <= 32 bits, LSB = the first set position of p
 __device__ __forceinline__ uint32_t pext32_lut(const uint8_t *lut, uint32_t x, uint32_t p)
 {
@@ -644,25 +667,26 @@ template <bool STREAM>
 __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
     const uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n,
-    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32, uint64_t *__restrict__ stats)
+    uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32, uint64_t *__restrict__ stats,
+    const uint32_t *__restrict__ chunk_off /* k_chunk_offsets: [frame][workgroup] */)
 {
     // A workgroup owns WG_THREADS consecutive words (= whole segments).  Their witness bits form one contiguous bit range starting at
-    // (passes of all earlier segments): the range is assembled in LDS with LDS atomics and written with plain coalesced stores; only
-    // its first and last dword are shared with the neighbouring workgroups (atomicOr).  No separate scan kernel: the start is a block
-    // reduction over the earlier segment counts, the offsets inside the chunk a block scan.
+    // (passes of all earlier segments, from k_chunk_offsets): the range is assembled in LDS with LDS atomics and written with plain
+    // coalesced stores; only its first and last dword are shared with the neighbouring workgroups (atomicOr).  The offsets inside the
+    // chunk are a block scan.
     //
     // The step is bound by instruction issue, so this kernel is written for a short instruction stream (round 3: ~415
     // VALU wave-instructions per 64 words, now ~230): the earlier counts are read four to a load, all loads of a thread are in flight
     // before the first wait, both block-wide sums cross ONE barrier, the wave scans are DPP adds, and the pext is sixteen look-ups.
     __shared__ uint32_t buf[WG_THREADS * 2 + 2];
-    __shared__ uint32_t red[WG_WAVES], wsum[WG_WAVES];
+    __shared__ uint32_t wsum[WG_WAVES];
     __shared__ __attribute__((aligned(4))) uint8_t lut[256];
     const uint32_t f = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwords = (uint32_t)((n + 63) >> 6);                        // n < 2^32 (rbf_plan_batch)
     const uint32_t total = (uint32_t)nseg * words_per_seg;
     const uint64_t *pwf = pass_words + (uint64_t)f * total;
-    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
+    const uint32_t start32 = chunk_off[(uint64_t)f * gridDim.x + blockIdx.x];      // (uniform: a scalar load)
     uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
     const uint32_t wbeg = blockIdx.x * WG_THREADS;
     const uint32_t w = wbeg + threadIdx.x;
@@ -671,8 +695,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     const uint64_t *mkp = masks + (uint64_t)f * mask_stride_words64 + w;
     const uint64_t pw_raw = have ? (STREAM ? __builtin_nontemporal_load(pwf + w) : pwf[w]) : 0ull;        // read once: see the cache-policy note at the top
     const uint64_t mk_raw = have ? (STREAM ? __builtin_nontemporal_load(mkp) : *mkp) : 0ull;
-    const uint32_t part = counts_before_share(cnt, wbeg / words_per_seg);
-    lut[threadIdx.x] = (uint8_t)pext4_entry(threadIdx.x);
+    lut_to_lds(lut, LUT_PEXT4);
     buf[threadIdx.x] = 0;
     buf[threadIdx.x + WG_THREADS] = 0;
     if (threadIdx.x < 2) buf[threadIdx.x + 2 * WG_THREADS] = 0;
@@ -680,13 +703,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     const uint32_t pw_lo = (uint32_t)pw, pw_hi = (uint32_t)(pw >> 32);
     const uint32_t c_lo = __popc(pw_lo), c = c_lo + __popc(pw_hi);
     const uint32_t incl = wave_inclusive_scan(c);
-    const uint32_t psum = wave_sum_to_lane63(part);
-    if (lane == WAVE - 1) { wsum[wave] = incl; red[wave] = psum; }
+    if (lane == WAVE - 1) wsum[wave] = incl;
     __syncthreads();
-    uint32_t start32 = 0, before = 0, chunk_total = 0;
+    uint32_t before = 0, chunk_total = 0;
 #pragma unroll
     for (int k = 0; k < WG_WAVES; ++k) {
-        start32 += red[k];
         if ((uint32_t)k < wave) before += wsum[k];
         chunk_total += wsum[k];
     }
@@ -720,42 +741,37 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
 }
 
 // A6 expand: out[i] = witness[rank(i)] where position i passes, else 0 (:299-304).  One lane per 64-position word, a workgroup per
-// WG_THREADS consecutive words (= whole segments), offsets as in k_compact_witness: the start is a block reduction over the earlier
-// segment counts, the offsets inside the chunk a block scan (until round 4 a separate scan kernel wrote segment offsets and every lane
-// summed the pass words in front of it in its segment with up to seven dependent loads).  The lane's popc(pass) stream bits are fetched
+// WG_THREADS consecutive words (= whole segments), offsets as in k_compact_witness: the start comes from k_chunk_offsets, the offsets
+// inside the chunk are a block scan.  The lane's popc(pass) stream bits are fetched
 // as one 64-bit window and dealt out to the set bits of the pass word through the pdep table.  Reads never leave the row.
 __global__ __launch_bounds__(WG_THREADS) void k_expand_mask(
     const uint64_t *__restrict__ pass_words, const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t words_per_seg,
     const uint32_t *__restrict__ witnesses, uint64_t witness_stride_words32,
-    uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n)
+    uint64_t *__restrict__ masks, uint64_t mask_stride_words64, uint64_t n, const uint32_t *__restrict__ chunk_off /* k_chunk_offsets */)
 {
-    __shared__ uint32_t red[WG_WAVES], wsum[WG_WAVES];
+    __shared__ uint32_t wsum[WG_WAVES];
     __shared__ __attribute__((aligned(4))) uint8_t lut[256];
     const uint32_t f = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwords = (uint32_t)((n + 63) >> 6);
     const uint32_t total = (uint32_t)nseg * words_per_seg;
-    const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
+    const uint32_t start32 = chunk_off[(uint64_t)f * gridDim.x + blockIdx.x];
     const uint32_t *wit = witnesses + (uint64_t)f * witness_stride_words32;
     const uint32_t wbeg = blockIdx.x * WG_THREADS;
     const uint32_t w = wbeg + threadIdx.x;
     const bool have = w < total && w < nwords;
     const uint64_t pw_raw = have ? pass_words[(uint64_t)f * total + w] : 0ull;
-    const uint32_t part = counts_before_share(cnt, wbeg / words_per_seg);
-    lut[threadIdx.x] = (uint8_t)pdep4_entry(threadIdx.x);
+    lut_to_lds(lut, LUT_PDEP4);
     const uint64_t p = flip_bytes64(pw_raw);                      // packed -> bit b = position 64w + b
     const uint32_t p_lo = (uint32_t)p, p_hi = (uint32_t)(p >> 32);
     const uint32_t c_lo = __popc(p_lo), c = c_lo + __popc(p_hi);
     const uint32_t incl = wave_inclusive_scan(c);
-    const uint32_t psum = wave_sum_to_lane63(part);
-    if (lane == WAVE - 1) { wsum[wave] = incl; red[wave] = psum; }
+    if (lane == WAVE - 1) wsum[wave] = incl;
     __syncthreads();
-    uint32_t o = incl - c;
+    uint32_t o = start32 + incl - c;
 #pragma unroll
-    for (int k = 0; k < WG_WAVES; ++k) {
-        o += red[k];
+    for (int k = 0; k < WG_WAVES; ++k)
         if ((uint32_t)k < wave) o += wsum[k];
-    }
     if (w >= nwords) return;
     uint64_t out = 0;
     if (c) {

@@ -8,7 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 HOT = (                                   # demangled name prefixes (tools/kernel_resources.py prints them)
     "k_query_u64", "k_query_u64w", "k_query_s64t<0>", "k_query_s64t<1>", "k_query_s64t<2>", "k_insert_tab<false, true>", "k_insert_tab<false, false>", "k_insert_positions<true>",
-    "k_insert_records", "k_filter_reduce", "k_compact_witness", "k_residual_mask_gop<unsigned char, 1, true, true>", "k_expand_mask", "k_hash_table",
+    "k_insert_records", "k_filter_reduce", "k_chunk_offsets", "k_compact_witness", "k_residual_mask_gop<unsigned char, 1, true, true>", "k_expand_mask", "k_hash_table",
 )
 
 
