@@ -211,7 +211,8 @@ int rbf_noise_moments_batch(rbf_ctx *ctx, const void *frames_dev, uint64_t frame
  *   masks_dev     nframes packed masks, stride mask_stride_bytes
  *   params        nframes host structs
  *   filters_dev   out: nframes packed filters, stride filter_stride_bytes >= ceil(m/64)*8
- *   witnesses_dev out: nframes packed witnesses, stride witness_stride_bytes >= ceil(n/64)*8
+ *   witnesses_dev out: nframes packed witnesses, stride witness_stride_bytes >= ceil(n/64)*8; the first stats[f][RBF_STAT_WITNESS_BITS]
+ *                 bits of row f are the witness, zero-padded to whole 64-bit words -- what lies behind them in the row is unspecified
  *   stats_dev     out: nframes x RBF_STATS_PER_FRAME uint64 */
 int rbf_bloom_encode_batch(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_stride_bytes,
                            uint64_t n, uint32_t nframes, const rbf_filter_params *params,
@@ -239,7 +240,7 @@ int rbf_encode_gop(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_b
 /* The same in two phases (`..._masks()` -> host parameter math -> `..._blooms()`; the reference does these steps one
  * after the other per frame, improved_video_compressor.py:198-266 -- mask, :211-215 parameters, :235-237 insert, :245-253 query).
  *   rbf_encode_gop_begin   checks EVERY argument first (a bad call touches neither the stream nor the caller's buffers), enqueues the
- *                          mask stage (its last workgroup publishes the set-bit counts into pinned host memory and the witness /
+ *                          mask stage (its last workgroup publishes the set-bit counts into pinned host memory and the
  *                          stats rows are cleared on the way) and returns without waiting.
  *   rbf_encode_gop_poll    *ready = 1 once the counts have arrived (never blocks).
  *   rbf_encode_gop_finish  waits for the counts, runs rbf_plan_batch, enqueues insert / reduce / query / compaction; params_out /
@@ -264,7 +265,7 @@ int rbf_encode_gop_poll(rbf_ctx *ctx, int *ready);
  * instead of once per GOP.
  *   run_starts   HOST array of nframes bytes, nullable (= one run, rbf_encode_gop_begin).  run_starts[t] != 0 for t >= 1: frame t is a
  *                keyframe of the caller's stream, it starts a new run, and PAIR t-1 (frame t against frame t-1) IS NOT CODED: its mask
- *                row is written as zeros, ones_dev[t-1] = 0, its witness row and stats are cleared, its filter row is not touched,
+ *                row is written as zeros, ones_dev[t-1] = 0, its stats are zero (an empty witness), its filter row is not touched,
  *                params_out[t-1] = {m = 0, floor_k = RBF_PAIR_SKIPPED, 0}, k_out[t-1] = 0, and rbf_pack_records gives it a header row
  *                with no payload.  run_starts[0] is ignored.  No frame of a run is read by the mask stage of another run.
  * Everything else as rbf_encode_gop_begin / rbf_encode_gop; rbf_encode_gop_poll / rbf_encode_gop_finish complete either kind of begin.

@@ -880,7 +880,6 @@ static int residual_mask_impl(rbf_ctx *ctx, const void *frames_dev, uint64_t fra
             }
             fin = *gop_tail;
             fin.enabled = 1; fin.count = pairs; fin.ticket = ctx->mask_ticket; fin.ones_out = ones_dev;
-            fin.stream_clears = (uint64_t)pairs * n >= STREAM_MIN_PIXEL_FRAMES ? 1u : 0u;
             fused = true;
         }
         LaunchTimer t(ctx, RBF_K_MASK);
@@ -944,13 +943,14 @@ static int check_filter_strides(const rbf_filter_params *params, uint32_t nframe
 
 // The scan in front of the compaction (encode) / expansion (decode): the start of every workgroup's range of witness bits, from the
 // segment pass counts the query kernel left (k_chunk_offsets, one workgroup per frame).
-static int launch_chunk_offsets(rbf_ctx *ctx, const Plan &pl, uint32_t nframes, uint32_t nchunks)
+static int launch_chunk_offsets(rbf_ctx *ctx, const Plan &pl, uint32_t nframes, uint32_t nchunks, void *witnesses_dev = nullptr /* encode: zero the shared dwords */,
+                                uint64_t witness_stride_bytes = 0)
 {
     if (WG_THREADS % pl.words_per_seg) return fail(RBF_EINVAL, "segments of %u words do not tile a workgroup's chunk", pl.words_per_seg);
     if (int r = grow((void **)&ctx->chunk_off, &ctx->chunk_off_cap, (size_t)nframes * nchunks * 4)) return r;
     LaunchTimer t(ctx, RBF_K_SCAN);
     hipLaunchKernelGGL(k_chunk_offsets, dim3(nframes), dim3(CO_THREADS), 0, ctx->stream, (const uint32_t *)ctx->seg_cnt, pl.nseg,
-                       (uint32_t)WG_THREADS / pl.words_per_seg, nchunks, ctx->chunk_off);
+                       (uint32_t)WG_THREADS / pl.words_per_seg, nchunks, ctx->chunk_off, (uint32_t *)witnesses_dev, witness_stride_bytes / 4);
     return RBF_OK;
 }
 
@@ -1079,10 +1079,8 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
     if (want_image) if (int r = ensure_image(ctx, pl, nframes)) return r;
     uint32_t *image = want_image ? ctx->qimage : nullptr;
 
-    if (!outputs_zeroed) {
-        HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)nframes * witness_stride_bytes, ctx->stream));
+    if (!outputs_zeroed)                                           // (the witness rows need no clearing: k_chunk_offsets zeroes what the compaction shares)
         HIP_TRY(hipMemsetAsync(stats_dev, 0, (size_t)nframes * RBF_STATS_PER_FRAME * 8, ctx->stream));
-    }
     // ---- insert
     if (pl.fast_insert) {
         const uint64_t part_stride = (pl.fwords_max + 3u) & ~3ull;      // 16-byte rows for the reduce kernel
@@ -1208,7 +1206,7 @@ static int encode_chunk_pass(rbf_ctx *ctx, const void *masks_dev, uint64_t mask_
         const uint64_t words = pl.nseg * pl.words_per_seg;
         uint64_t bx = (words + WG_THREADS - 1) / WG_THREADS;
         if (bx < 1) bx = 1;
-        if (int r = launch_chunk_offsets(ctx, pl, nframes, (uint32_t)bx)) return r;
+        if (int r = launch_chunk_offsets(ctx, pl, nframes, (uint32_t)bx, witnesses_dev, witness_stride_bytes)) return r;
         LaunchTimer t(ctx, RBF_K_STITCH);
         hipLaunchKernelGGL(stream_once ? k_compact_witness<true> : k_compact_witness<false>, dim3((uint32_t)bx, nframes), dim3(WG_THREADS), 0, ctx->stream,
                            ctx->pass_words, ctx->seg_cnt, pl.nseg, pl.words_per_seg,
@@ -1430,18 +1428,15 @@ int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
         }
         ctx->host_cap = pairs + 16;
     }
-    // The GPU publishes the counts straight into host memory and clears the output buffers in the same pass -- inside the mask
+    // The GPU publishes the counts straight into host memory and clears the stats rows in the same pass -- inside the mask
     // kernel when it covers the whole frame, else through k_finish_ones -- so the only thing between the mask kernel and the
-    // Bloom kernels is the host's float64 parameter math.
+    // Bloom kernels is the host's float64 parameter math.  (The witness rows are not cleared any more: k_chunk_offsets zeroes the dwords
+    // the compaction's workgroups share, the compaction writes everything else.)
     const uint64_t token = ++ctx->publish_token;
     MaskFinish tail{};
     tail.host_block = ctx->ones_mapped_dev; tail.token = token;
-    tail.clear_a = (uint4 *)witnesses_dev; tail.quads_a = (uint64_t)pairs * witness_stride_bytes / 16;
+    tail.clear_a = nullptr; tail.quads_a = 0;
     tail.clear_b = (uint4 *)stats_dev;     tail.quads_b = (uint64_t)pairs * RBF_STATS_PER_FRAME * 8 / 16;
-    if (((uint64_t)pairs * witness_stride_bytes) % 16) {          // (never the case for the library's own buffers) plain memset, nothing for the kernel
-        HIP_TRY(hipMemsetAsync(witnesses_dev, 0, (size_t)pairs * witness_stride_bytes, ctx->stream));
-        tail.clear_a = nullptr; tail.quads_a = 0;
-    }
     if (int r = residual_mask_impl(ctx, frames_dev, frame_stride_bytes, nframes, width, height, row_pitch_bytes,
                                    pixel_stride_bytes, sample_bytes, thr_floor, thr_floors, masks_dev, mask_stride_bytes, ones_dev, false, &tail,
                                    has_skip ? ctx->run_skip.data() : nullptr))

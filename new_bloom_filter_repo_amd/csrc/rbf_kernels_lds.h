@@ -22,9 +22,9 @@ namespace rbf {
 // Cache policy for data that is read or written ONCE.  A step of several GOPs moves ~750 MB through 32 MB of L2 and the 256 MB Infinity
 // Cache, next to two things that must stay cached: the pixel-index hash table the insert gathers from (54 MB) and the probe images every
 // query workgroup restages.  Non-temporal loads / stores keep the one-shot streams from evicting them.  Measured (profiles/r05_cache_policy.txt,
-// four pipelines): the mask kernel's frame loads alone +2.6 % at one GOP per call and +1.6 % at four; with the witness-row clears, the
-// reduce kernel's partial loads and filter stores and the compaction's pass-word and mask loads +5.4 % at four GOPs per call, +3.8 % at
-// three, nothing at two, -1 % at one (so those follow the batch size: STREAM).  The query kernel's pass-byte stores and the compaction's
+// four pipelines): the mask kernel's frame loads alone +2.6 % at one GOP per call and +1.6 % at four; with the witness-row clears (since
+// removed altogether), the reduce kernel's partial loads and filter stores and the compaction's pass-word and mask loads +5.4 % at four GOPs
+// per call, +3.8 % at three, nothing at two, -1 % at one (so those follow the batch size: STREAM).  The query kernel's pass-byte stores and the compaction's
 // witness stores must NOT stream (-2 ... -3 %: their consumers follow at once), nor the table gathers (insert 33 -> 55 us).
 typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_stream(uint4 *p, uint4 v) { const nt_u32x4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<nt_u32x4 *>(p)); }
@@ -567,8 +567,11 @@ __global__ __launch_bounds__(QL_THREADS) void k_query_tiled(
 // reads per 1080p frame).  total < 2^32 (n < 2^32).
 constexpr int CO_THREADS = 1024;
 __global__ __launch_bounds__(CO_THREADS) void k_chunk_offsets(const uint32_t *__restrict__ seg_cnt, uint64_t nseg, uint32_t chunk_segs, uint32_t nchunks,
-                                                              uint32_t *__restrict__ off)
+                                                              uint32_t *__restrict__ off, uint32_t *__restrict__ witnesses /* nullable (decode) */, uint64_t witness_stride_words32)
 {
+    // Encode: this kernel also ZEROES the few witness dwords the compaction's workgroups share -- the 64-bit word around every chunk's
+    // first bit and around the witness's end (whose pad bits must read 0) -- so that nobody has to clear whole witness rows (until round 5
+    // the mask kernel cleared 259 KB per 1080p frame for them: a tenth of its HBM traffic).  Everything else the compaction overwrites.
     // a thread sums `per` consecutive counts (4 when a chunk has that many segments), the workgroup scans the sums, and the thread that
     // holds a chunk's first segments writes the chunk's offset; frames of more than 1024 * per segments take several rounds with a carry
     __shared__ uint32_t wtot[CO_THREADS / WAVE];
@@ -577,6 +580,12 @@ __global__ __launch_bounds__(CO_THREADS) void k_chunk_offsets(const uint32_t *__
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t *cnt = seg_cnt + (uint64_t)f * nseg;
     uint32_t *out = off + (uint64_t)f * nchunks;
+    uint32_t *wit = witnesses ? witnesses + (uint64_t)f * witness_stride_words32 : nullptr;
+    auto zero_word_at = [&](uint32_t bit) {
+        const uint64_t d = (bit >> 5) & ~1u;
+        if (d < witness_stride_words32) wit[d] = 0;
+        if (d + 1 < witness_stride_words32) wit[d + 1] = 0;
+    };
     const uint32_t per = (chunk_segs & 3u) == 0 ? 4u : (chunk_segs & 1u) == 0 ? 2u : 1u;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -590,11 +599,15 @@ __global__ __launch_bounds__(CO_THREADS) void k_chunk_offsets(const uint32_t *__
         __syncthreads();
         uint32_t before = carry;
         for (uint32_t k = 0; k < wave; ++k) before += wtot[k];
-        if (i0 < nseg && i0 % chunk_segs == 0) out[i0 / chunk_segs] = before + incl - sum;
+        if (i0 < nseg && i0 % chunk_segs == 0) {
+            out[i0 / chunk_segs] = before + incl - sum;
+            if (wit) zero_word_at(before + incl - sum);
+        }
         __syncthreads();
         if (threadIdx.x == CO_THREADS - 1) carry_s = before + incl;
         __syncthreads();
     }
+    if (wit && threadIdx.x == 0) zero_word_at(carry_s);          // the end of the witness
 }
 
 // Software pext / pdep through a 256-byte LDS table of their 4-bit forms, entry [p4 << 4 | x4] (thread t of a 256-thread workgroup
@@ -672,7 +685,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
 {
     // A workgroup owns WG_THREADS consecutive words (= whole segments).  Their witness bits form one contiguous bit range starting at
     // (passes of all earlier segments, from k_chunk_offsets): the range is assembled in LDS with LDS atomics and written with plain
-    // coalesced stores; only its first and last dword are shared with the neighbouring workgroups (atomicOr).  The offsets inside the
+    // coalesced stores; only its first and last dword may be shared with the neighbouring workgroups (atomicOr onto zeroed dwords).  The offsets inside the
     // chunk are a block scan.
     //
     // The step is bound by instruction issue, so this kernel is written for a short instruction stream (round 3: ~415
@@ -731,10 +744,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_compact_witness(
     __syncthreads();
     const uint32_t oend = start32 + chunk_total;
     const uint32_t ndw = ((oend - obase) + 31u) >> 5;
+    // a dword this workgroup shares with a neighbour (its first one when it does not start on a dword, its last one when it does not end on
+    // one) was zeroed by k_chunk_offsets and is OR-ed into; every other dword of the range is written whole, zero or not
     for (uint32_t i = threadIdx.x; i < ndw; i += WG_THREADS) {
         const uint32_t v = buf[i];
-        if (!v) continue;
-        if (i == 0 || i + 1 == ndw) atomicOr(&wit[(obase >> 5) + i], flip_bytes32(v));
+        const bool shared = (i == 0 && (start32 & 31u)) || (i + 1 == ndw && (oend & 31u));
+        if (shared) { if (v) atomicOr(&wit[(obase >> 5) + i], flip_bytes32(v)); }
         else wit[(obase >> 5) + i] = flip_bytes32(v);
     }
     if (threadIdx.x == 0 && wbeg + WG_THREADS >= total) stats[(uint64_t)f * 4 + 0] = oend;   // len(witness)
@@ -884,7 +899,6 @@ struct MaskFinish {
     uint64_t token;
     uint4 *clear_a; uint64_t quads_a;
     uint4 *clear_b; uint64_t quads_b;
-    uint32_t stream_clears;        // 1: region a (the witness rows) is cleared with non-temporal stores (blocks of several GOPs)
 };
 
 // The temporal chunks of one launch (blockIdx.y).  count == 0: uniform chunks of `ppc` pairs over the whole block (one run).  Otherwise
@@ -973,8 +987,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         __syncthreads();
     }
     if (wave != 0) {                               // waves 1..3: their share of the clears, and out
-        if (fin.stream_clears) for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) store_stream(fin.clear_a + i, z);
-        else for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
+        for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
         for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_b; i += nwg * WG_THREADS) fin.clear_b[i] = z;
         return;
     }
@@ -996,8 +1009,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         }
     }
     is_last = __builtin_amdgcn_readfirstlane(is_last);
-    if (fin.stream_clears) for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) store_stream(fin.clear_a + i, z);
-    else for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
+    for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_a; i += nwg * WG_THREADS) fin.clear_a[i] = z;
     for (uint64_t i = wg * WG_THREADS + threadIdx.x; i < fin.quads_b; i += nwg * WG_THREADS) fin.clear_b[i] = z;
     if (!is_last) return;
     // the last workgroup: counts out (to the caller's array and the host), accumulator and ticket back to zero
