@@ -326,3 +326,22 @@ def test_yuv_frame_planes_are_lazy_copies_and_blocks_are_zero_copy_views():
     c16 = clip.astype(np.uint16) * 257
     blk = _as_block([c16[i] for i in range(1, 4)])
     assert blk.dtype == np.uint16 and np.shares_memory(blk, c16) and np.array_equal(blk, c16[1:])
+
+
+def test_filter_stride_min_covers_every_plan():
+    """rbf_encode_gop_begin / rbf_encode_runs_begin refuse a filter stride below rbf_filter_stride_min(n) BEFORE the filters are planned:
+    the bound has to cover whatever rbf_plan_batch (improved_video_compressor.py:161-196, :211-225) can produce for n pixels."""
+    import ctypes
+    L = nat.lib()
+    for n in (1, 63, 64, 1000, 57600, 230400, 2073600, 8294400, 33177600, 2 ** 32 - 1):
+        smin = int(L.rbf_filter_stride_min(n))
+        assert smin % 8 == 0 and smin >= 8
+        cnt = 4001 if n > 4001 else n + 1
+        ones = (ctypes.c_uint64 * cnt)(*sorted({min(n, int(round(i * n / (cnt - 1)))) for i in range(cnt)} | {min(n, int(0.13183 * n)), min(n, int(0.13183 * n) + 1)})[:cnt])
+        cnt = len(ones)
+        params = (nat.FilterParams * cnt)()
+        nat.check(L.rbf_plan_batch(n, ones, cnt, 1, params, None))
+        worst = max(int(p.m) for p in params)
+        assert (worst + 63) // 64 * 8 <= smin, (n, worst, smin)
+        if n >= 57600:
+            assert smin * 8 <= 0.32 * n + 128            # ... without asking for more than GopCoder.strides gives
