@@ -1,5 +1,6 @@
 """GOP-level driver: frames resident in HBM -> residual masks -> (host: filter geometry) ->
-Bloom insert + query/witness, one C-ABI call per GOP (rbf_encode_gop).
+Bloom insert + query/witness, one C-ABI call per block of frames: one GOP (rbf_encode_gop) or several GOPs whose keyframes
+are marked (rbf_encode_runs: ONE launch sequence for all of them).
 
 Device memory comes from an allocator callback so the same code runs on library-owned buffers
 (default) or on torch tensors (bench.py / dist.py pass `torch_allocator`, which lets RCCL move the
