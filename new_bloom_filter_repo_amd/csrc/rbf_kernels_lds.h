@@ -884,7 +884,8 @@ __device__ __forceinline__ uint32_t lane_bits_thr0(const LanePixels<SAMPLE, PIXE
 }
 
 // What used to be k_finish_ones' job, folded into the mask kernel when it covers the whole frame (rbf_encode_gop on frames of whole
-// 1024-pixel segments): every workgroup clears its share of two output regions (the witness rows and the stats of the batch), and
+// 1024-pixel segments): every workgroup clears its share of up to two output regions (round 5: only the stats of the batch -- the
+// witness rows are no longer cleared, k_chunk_offsets zeroes the few words compaction ORs into; region a is null), and
 // the LAST workgroup to finish (a ticket) hands the counts out -- to the caller's array and into the device-visible pinned block
 // whose token the host spins on -- and re-zeroes the accumulator and the ticket.  One launch less per step, and the publish no
 // longer queues behind whatever else occupies the GPU (profiles/r02_overlap_4pipelines.txt: the 5 us k_finish_ones took 61 us
