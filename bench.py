@@ -84,6 +84,11 @@ def parse_args():
     ap.add_argument("--gops-per-call", type=int, default=1, help="GOPs of --frames frames that ONE call (rbf_encode_runs: one mask / insert / reduce / query / compact launch sequence) codes; "
                     "a step is then one such call.  1 = the contract line (one GOP per call); the default run adds a `batched_gops` leg with 4")
     ap.add_argument("--insert-slices", type=int, default=0, help="tuning: RBF_OPT_INSERT_SLICES (0 = auto)")
+    ap.add_argument("--clip-pass-slots", type=int, default=0, help="clip mode: sets of coders (own contexts, streams and records) consecutive passes rotate over, so that the mask stage, compaction and packing of "
+                    "pass p+1 run under the Bloom kernels of pass p when a rank's share is fewer blocks than it has pipelines; 0 = auto (pipelines // blocks per pass), 1 = one set (round 5)")
+    ap.add_argument("--clip-groups", type=int, default=0, help="clip mode: force the number of equal blocks a rank cuts its frames into per pass (0 = auto, see clip_blocks)")
+    ap.add_argument("--proxy", default="", help="clip mode, single process: 'N,r' = run what rank r of an N-way split would run (gather stubbed), 'N' = every rank of the split in turn")
+    ap.add_argument("--no-shard-proxy", action="store_true", help="skip the shard_proxy leg (one rank's share of configs 3 / 5 at N = 2, 4, 8, timed on this GPU)")
     ap.add_argument("--clip-block-gops", type=int, default=0, help="clip mode: keyframe intervals a rank hands to the GPU in ONE rbf_encode_runs launch sequence; 0 = auto (one block per pipeline and pass, see clip_blocks), 1 = one call per run of inter-frames (round 4)")
     return ap.parse_args()
 
@@ -542,10 +547,19 @@ def main():
         del coders, coder, arenas, ctxs, ctx, og, slots, probe
         torch.cuda.empty_cache()
         env = (world, rank, local_rank, device, use_dist)
-        c8 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 8, args.clip_steps, 2)
-        c16 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 16, args.clip_steps, 2)
+        proxy = world == 1 and not use_dist and not args.no_shard_proxy and (W, H, args.bits) == (1920, 1080, 8) and not args.density
+        cache = {} if proxy else None             # (N > 1: every rank makes its own shard)
+        c8 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 8, args.clip_steps, 2, clip_cache=cache)
+        sp = dict(SHARD_PROXY_WHAT)
+        if proxy:                                 # 8-bit proxies while the 8-bit clip is cached, then the 16-bit clip
+            sp["clip300"] = shard_proxy_leg(args, env, args.clip_leg_frames, args.keyframe_interval, args.clip_steps, cache, 8, c8)
+        c16 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 16, args.clip_steps, 2, clip_cache=cache)
+        if proxy:
+            sp["clip300_uint16"] = shard_proxy_leg(args, env, args.clip_leg_frames, args.keyframe_interval, args.clip_steps, cache, 16, c16)
         if rank == 0:
             out["clip300"], out["clip300_uint16"] = c8, c16
+            if proxy:
+                out["shard_proxy"] = sp
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -553,12 +567,14 @@ def main():
         print(json.dumps(out), flush=True)        # the last thing on stdout (RCCL prints its own lines while it is alive)
 
 
-def e2e_surface_leg(nat, local_rank, W, H, density, T=300, I=30):
+def e2e_surface_leg(nat, local_rank, W, H, density, T=300, I=30, block_frames=None, gpu_lanes=2, profile_stages=False):
     """What a caller of the plugin surface gets (improved_video_compressor.py:358-504): ImprovedVideoCompressor.compress_video +
     decompress_video on host-resident YUV444 frames -- one 30-frame GOP and the 300-frame clip of BASELINE configs[2] -- with the time
-    of every stage (stacking, upload, GPU encode, row download, changed-value gather, host zlib-9) and verify_bit_exact
-    (verify_true_lossless.py:338-492 semantics) of the decoded frames.  The reference's only published time for this surface is 12.45 s
-    for its own clip (results.md:140; other hardware, other content): not comparable, reported for orientation only."""
+    of every stage and verify_bit_exact (verify_true_lossless.py:338-492 semantics) of the decoded frames.  The blocks of a clip alternate
+    over `gpu_lanes` contexts, each block on its own host thread, so the stage times of different blocks OVERLAP (their sums can exceed the
+    wall time); `gpu_busy_frac` is the share of the call's wall time during which at least one lane had a copy or a kernel in flight.  The
+    reference's only published time for this surface is 12.45 s for its own clip (results.md:140; other hardware, other content): not
+    comparable, reported for orientation only."""
     from new_bloom_filter_repo_amd.synthetic import make_clip_shard
     from new_bloom_filter_repo_amd.video_compressor import ImprovedVideoCompressor
     from new_bloom_filter_repo_amd.verify import verify_bit_exact
@@ -568,28 +584,38 @@ def e2e_surface_leg(nat, local_rank, W, H, density, T=300, I=30):
     with nat.Context(local_rank) as ctx:
         for name, count in (("gop30", I), ("clip300", T)):
             frames = [clip[t] for t in range(count)]
-            comp = ImprovedVideoCompressor(keyframe_interval=I, ctx=ctx)
+            comp = ImprovedVideoCompressor(keyframe_interval=I, ctx=ctx, block_frames=block_frames, gpu_lanes=gpu_lanes)
+            comp.profile_stages = profile_stages
             t0 = time.perf_counter()
             res = comp.compress_video(list(frames), input_color_space="YUV")
             t1 = time.perf_counter()
             tm = dict(comp.last_timing or {})
             dec = comp.decompress_video(compressed_frames=comp.last_compressed_frames)
             t2 = time.perf_counter()
+            td = dict(comp.last_timing or {})
             v = verify_bit_exact(frames, dec, color_space="YUV")
             if not v["success"]:
                 raise SystemExit("e2e_surface: %s does not round-trip bit-exactly: %s" % (name, v["different_frame_indices"][:5]))
             inter = count - res["keyframes"]
+            rnd = lambda d: {k: (round(x, 3) if isinstance(x, float) else x) for k, x in d.items()}
             out[name] = {"frames": count, "keyframes": res["keyframes"], "inter_frames": inter,
                          "compress_s": round(t1 - t0, 3), "compress_fps": round(count / (t1 - t0), 1), "compress_mpixels_per_s": round(count * n / (t1 - t0) / 1e6, 1),
+                         "gpu_busy_frac": round(tm.get("gpu_busy", 0.0) / (t1 - t0), 3),
                          "decompress_s": round(t2 - t1, 3), "decompress_fps": round(count / (t2 - t1), 1),
+                         "decompress_gpu_busy_frac": round(td.get("gpu_busy", 0.0) / (t2 - t1), 3),
                          "compression_ratio": round(res["compression_ratio"], 4), "container": "BFV2",
-                         "stages_s": {k: round(x, 3) for k, x in tm.items()},
+                         "stages_s": rnd(tm), "decompress_stages_s": rnd(td),
                          "verify_bit_exact": {"success": v["success"], "exact_matches": v["exact_matches"], "frames_compared": v["frames_compared"]}}
             comp.close()
-    out["what"] = ("ImprovedVideoCompressor.compress_video(frames, input_color_space='YUV') + decompress_video, host-resident %dx%d YUV444 uint8 frames, keyframe every %d; "
-                   "stages_s: stack = np.stack of a block's frames, upload = pageable host -> HBM, gpu_encode = rbf_encode_runs of the block (synchronised), download_rows = masks / "
-                   "filters / witnesses to the host, value_gather = rbf_gather_values_batch + download, zlib_wait = what the host threads' zlib-9 (keyframes, changed values) still "
-                   "owed after the last block; synthetic frames are incompressible noise, so the ratio says nothing about real video" % (W, H, I))
+    out["what"] = ("ImprovedVideoCompressor.compress_video(frames, input_color_space='YUV') + decompress_video, host-resident %dx%d YUV444 uint8 frames, keyframe every %d, "
+                   "blocks of %s frames alternating over %d GPU lanes (own context, stream and host thread each); "
+                   "stages_s (summed over the blocks, which overlap): stack = np.stack of a block's frames (0 when they lie back to back), upload = pageable host -> HBM, gpu_encode = "
+                   "enqueueing rbf_encode_runs, download_rows = rbf_pack_records + ONE exact-size download of the block's record (this is where the host waits for the kernels), "
+                   "value_gather = rbf_gather_values_batch + download, gpu_phase = wall time until the last block's values were on the host, zlib_wait = what the host threads' "
+                   "zlib-9 (keyframes: four jobs each; changed values: one job per frame) still owed after that, gpu_busy = wall time with a copy or kernel in flight on some lane; "
+                   "decompress_stages_s likewise per run (mask_decode = rbf_bloom_decode_batch, apply_chain = device-side rebuild + download of the frames); "
+                   "synthetic frames are incompressible noise, so the ratio says nothing about real video and zlib-9 of ~290 MB of it on the host's cores is the floor of compress_s"
+                   % (W, H, I, block_frames or "2 x keyframe interval", gpu_lanes))
     return out
 
 
@@ -979,14 +1005,17 @@ def clip_pieces(start, stop, interval):
     return pieces
 
 
-def clip_blocks(start, stop, interval, block_gops, pipelines=4):
+def clip_blocks(start, stop, interval, block_gops, pipelines=4, force_groups=0):
     """The blocks a rank hands to the GPU, one rbf_encode_runs launch sequence each: list of (first_read_frame, nframes_read, run_starts)
     covering the inter-frames of [start, stop).  A block's first frame is only read (a keyframe, or the frame in front of the block's
     first inter-frame: a halo inside the rank's own shard costs one frame of extra reads); run_starts are the keyframes inside the block,
     relative to its first frame -- the pairs in front of them are not coded.
     block_gops = 1: clip_pieces' runs (one call per run, round 4); N > 1: blocks of N keyframe intervals, cut at keyframes;
     0 (auto): the rank's frames in min(pipelines, about one block per 72 inter-frames) contiguous ranges of EQUAL length (cut anywhere, not
-    only at keyframes), at most 128 frames each -- every pipeline of the rank gets one block of the same size per pass."""
+    only at keyframes), at most 128 frames each -- every pipeline of the rank gets one block of the same size per pass.  A share of fewer
+    blocks than pipelines (N >= 2) is NOT cut smaller -- every block pays the query kernel's hashing prologue once, and the insert and query
+    kernels own their CUs, so small blocks only add prologues (profiles/r06_shard_proxy.txt) -- the idle pipelines take the NEXT pass
+    instead (run_clip's pass slots).  force_groups > 0 overrides the number of ranges (--clip-groups: the sweep behind that statement)."""
     if block_gops == 1:
         return [(f0, cnt, []) for f0, cnt in clip_pieces(start, stop, interval)]
     first = start if start == 0 or start % interval == 0 else start - 1          # dist.halo_start
@@ -998,6 +1027,8 @@ def clip_blocks(start, stop, interval, block_gops, pipelines=4):
     else:
         coded = sum(1 for t in range(start, stop) if t % interval)
         groups = max(1, min(pipelines, (coded + 36) // 72), (stop - start + 126) // 127)
+        if force_groups > 0:
+            groups = max(min(force_groups, max(1, coded)), (stop - start + 126) // 127)
         base, extra = divmod(stop - start, groups)
         ranges, a = [], start
         for g in range(groups):
@@ -1014,13 +1045,24 @@ def clip_blocks(start, stop, interval, block_gops, pipelines=4):
     return blocks
 
 
-def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
+def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip_cache=None):
     """One clip of T frames (W x H YUV444, `bits` per sample), keyframe every I: the inter-frames shard over the ranks by
-    CONTIGUOUS FRAME RANGE with one halo frame (dist.shard_range / halo_start), every rank codes its runs with rbf_encode_gop and
-    packs each run's record on the device; with N > 1 the records travel to rank 0 in one exact-size gather per pass (sizes
-    all-gathered together with an error flag, then one point-to-point message per peer; rank 0's own records stay out of the
-    collective).  A pass = the whole clip once; timed with and (N > 1) without the gather.  Strong scaling: total work is fixed
-    as N grows.  Returns the result dict on rank 0 (None elsewhere)."""
+    CONTIGUOUS FRAME RANGE with one halo frame (dist.shard_range / halo_start), every rank codes its frames in blocks of one
+    rbf_encode_runs launch sequence each (clip_blocks) and packs each block's record on the device; with N > 1 the records travel to
+    rank 0 in one exact-size gather per pass (sizes all-gathered together with an error flag, then one point-to-point message per peer;
+    rank 0's own records stay out of the collective).  A pass = the whole clip once; timed with and (N > 1) without the gather.  Strong
+    scaling: total work is fixed as N grows.
+
+    PASS SLOTS: a rank whose share is fewer blocks than it has pipelines (N >= 2: 145 / 73 / 37 inter-frames are 2 / 1 / 1 blocks) keeps
+    `pipelines // blocks` SETS of coders -- own contexts, streams, masks, filters, witnesses -- and consecutive passes rotate over them,
+    so that the mask stage (HBM), the host's parameter round trip, the compaction and the packing of pass p+1 run under the CU-exclusive
+    insert and query kernels of pass p, exactly as the four pipelines of the N = 1 pass overlap each other.  Records are double-buffered
+    and the gather of pass p is issued after pass p+1 has been enqueued, so the GPU works while the host sits in the size exchange.
+    `pass_latency_ms` (one pass alone, synchronised before and after) is reported beside the sustained `ms_per_pass`.
+
+    proxy = (N, r): this single process runs what rank r of an N-way split would run (the shard arithmetic, blocks, pass slots and the
+    packed record of that rank; the gather is stubbed) -- bench.py's `shard_proxy` leg.  clip_cache: dict that keeps the whole synthetic
+    clip of a bit depth between calls.  Returns the result dict on rank 0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
     world, rank, local_rank, device, use_dist = env
@@ -1029,21 +1071,34 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
     from new_bloom_filter_repo_amd.gop import GopCoder, torch_allocator
     from new_bloom_filter_repo_amd.synthetic import make_clip_shard, P_KSTAR_2_3
 
+    if proxy is not None and (world != 1 or use_dist):
+        raise SystemExit("run_clip(proxy=...) is a single-process measurement")
+    s_world, s_rank = proxy if proxy is not None else (world, rank)          # the split the shard arithmetic sees
     W, H = args.width, args.height
     n = W * H
     dtype = np.uint8 if bits == 8 else np.uint16
-    start, stop = shard_range(T, world, rank)
+    start, stop = shard_range(T, s_world, s_rank)
     first = halo_start(start, I)
     density = args.density or P_KSTAR_2_3
-    shard = make_clip_shard(3000, W, H, first, stop, I, p=density, dtype=dtype)       # frames first..stop-1 of the SAME clip on every rank
+    if clip_cache is not None:                    # frames first..stop-1 of the SAME clip on every rank (here: a view of the cached whole clip)
+        key = (W, H, T, I, bits, density)
+        if key not in clip_cache:
+            clip_cache.clear()                    # one clip at a time: 300 x 1080p x 16 bit is 3.7 GB of host memory
+            clip_cache[key] = make_clip_shard(3000, W, H, 0, T, I, p=density, dtype=dtype)
+        shard = clip_cache[key][first:stop]
+    else:
+        shard = make_clip_shard(3000, W, H, first, stop, I, p=density, dtype=dtype)
     BG = max(0, args.clip_block_gops)
     NP = max(1, args.streams)
-    pieces = clip_blocks(start, stop, I, BG, NP)
+    FG = max(0, args.clip_groups)
+    pieces = clip_blocks(start, stop, I, BG, NP, FG)
     total_pairs = sum(max(0, min(T, (g + 1) * I) - g * I - 1) for g in range((T + I - 1) // I))
     my_pairs = sum(c - 1 - len(rs) for _, c, rs in pieces)
-    max_pieces = max(len(clip_blocks(*shard_range(T, world, r), I, BG, NP)) for r in range(world))     # every rank can compute every rank's count
+    max_pieces = max(len(clip_blocks(*shard_range(T, s_world, r), I, BG, NP, FG)) for r in range(s_world))     # every rank can compute every rank's count
 
-    nstreams = max(1, min(args.streams, len(pieces) or 1))
+    nblocks = len(pieces)
+    nsets = 1 if not nblocks else max(1, min(args.clip_pass_slots or NP, NP // nblocks))
+    nstreams = max(1, min(NP, nblocks * nsets))
     streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
     ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
     if args.force_bits:
@@ -1051,31 +1106,63 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
             c.force_generic(args.force_bits)
     planar = not args.interleaved
     frame_bytes = n * (1 if planar else 3) * (bits // 8)
-    resident = np.ascontiguousarray(shard[..., 0]) if planar else shard       # planar: only the Y planes of the shard (+ halo) are resident in HBM
+    resident = np.ascontiguousarray(shard[..., 0]) if planar else np.ascontiguousarray(shard)       # planar: only the Y planes of the shard (+ halo) are resident in HBM
     frames_t = torch.from_numpy(resident.reshape(-1).view(np.uint8)).to(device)
+    del resident
 
     class View:                                   # a run's frames inside the shard buffer
         def __init__(self, off, nbytes):
             self.ptr, self.nbytes = frames_t.data_ptr() + off, nbytes
-    coders, records = [], []
-    for i, (f0, cnt, rs) in enumerate(pieces):
-        view = View((f0 - first) * frame_bytes, cnt * frame_bytes)
-        c = GopCoder(ctxs[i % nstreams], W, H, cnt, channels=3, sample_bytes=bits // 8, allocator=torch_allocator(device),
-                     frames_block=None if planar else view, planar_luma=planar, keep_interleaved=False, luma_block=view if planar else None, run_starts=rs)
-        coders.append(c)
-        records.append(c._out_alloc(int(nat.lib().rbf_record_max_bytes(cnt - 1, n))))
+    NREC = max(2, nsets)                          # record buffers per block: pass p packs into buffer p % NREC (the gather of pass p runs under pass p+1)
+    sets, records = [], [[] for _ in range(NREC)]
+    for s in range(nsets):
+        coders = []
+        for i, (f0, cnt, rs) in enumerate(pieces):
+            view = View((f0 - first) * frame_bytes, cnt * frame_bytes)
+            coders.append(GopCoder(ctxs[(s * nblocks + i) % nstreams], W, H, cnt, channels=3, sample_bytes=bits // 8, allocator=torch_allocator(device),
+                                   frames_block=None if planar else view, planar_luma=planar, keep_interleaved=False, luma_block=view if planar else None, run_starts=rs))
+        sets.append(coders)
+    for b in range(NREC):
+        for i, (f0, cnt, rs) in enumerate(pieces):
+            records[b].append(sets[0][i]._out_alloc(int(nat.lib().rbf_record_max_bytes(cnt - 1, n))))
     can_gather = use_dist and not args.no_gather
+    state = {"p": 0, "pending": None, "free": [None] * NREC}
+
+    def do_gather(pend):
+        b, evs = pend
+        cur = torch.cuda.current_stream(device)
+        for ev in evs:
+            cur.wait_event(ev)
+        got = gather_device_records([r.tensor for r in records[b]], device, max_records=max_pieces)
+        ev = torch.cuda.Event()
+        ev.record(cur)                            # buffer b may be packed again once what the gather enqueued on this stream has read it
+        state["free"][b] = ev
+        return got
 
     def step(gather):
-        for i, c in enumerate(coders):
-            with torch.cuda.stream(streams[i % nstreams]):
+        p = state["p"]
+        state["p"] += 1
+        s, b = p % nsets, p % NREC
+        evs = []
+        for i, c in enumerate(sets[s]):
+            st = streams[(s * nblocks + i) % nstreams]
+            with torch.cuda.stream(st):
                 c.encode()
-                c.pack(records[i])
-        if gather:
-            for s in streams:
-                torch.cuda.current_stream(device).wait_stream(s)
-            return gather_device_records([r.tensor for r in records], device, max_records=max_pieces)
-        return None
+                if gather and state["free"][b] is not None:
+                    st.wait_event(state["free"][b])
+                c.pack(records[b][i])
+                if gather:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
+        if not gather:
+            return None
+        prev, state["pending"] = state["pending"], (b, evs)
+        return do_gather(prev) if prev is not None else None
+
+    def finish_gather():
+        prev, state["pending"] = state["pending"], None
+        return do_gather(prev) if prev is not None else None
 
     def barrier():
         if use_dist:
@@ -1087,11 +1174,14 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
         # 8-10 % slower than the steady state, like the headline's steps); every rank runs the same number
         got, spent, extra = None, 0.0, 0
         for _ in range(max(1, warmup)):
-            got = step(gather)
+            step(gather)
+        finish_gather()
         barrier()
-        while extra < 200:
+        while extra < 400:
             t0 = time.perf_counter()
-            got = step(gather)
+            for _ in range(nsets):
+                step(gather)
+            finish_gather()
             torch.cuda.synchronize(device)
             spent += time.perf_counter() - t0
             extra += 1
@@ -1105,7 +1195,8 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            got = step(gather)
+            step(gather)
+        got = finish_gather()                     # the last pass's records (every pass was gathered inside the region: `steps` exchanges)
         torch.cuda.synchronize(device)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -1116,26 +1207,65 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
         return elapsed, got
 
     elapsed_plain, _ = timed(False)
+    # one pass ALONE (nothing of a neighbouring pass under it): what a caller waits for who has only this one clip
+    lat = []
+    for _ in range(9):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        step(False)
+        torch.cuda.synchronize(device)
+        lat.append(time.perf_counter() - t0)
+    latency = sorted(lat)[len(lat) // 2]
     elapsed_gather, got = timed(True) if can_gather else (None, None)
 
     verified = None
     if verify and not args.no_verify:
-        # every rank checks ITS frames against the CPU oracle from the host frames; rank 0 also parses what it received
-        host = [[shard[f0 - first + j] for j in range(cnt)] for f0, cnt, _ in pieces]
-        res_all = [c.results() for c in coders]
-        v = verify_all([np.stack(h) for h in host], res_all, n, len(coders)) if coders else {"frames": 0}
-        cnt_t = torch.tensor([v["frames"]], dtype=torch.int64, device=COMM_DEVICE)
+        # every rank checks ITS frames -- the rows of EVERY pass slot -- against the CPU oracle from the host frames; rank 0 also parses what it received
+        for s in range(nsets):                    # (the slots' last passes may be older than the latency passes: run each once more)
+            for c in sets[s]:
+                c.encode()
+        host = [np.stack([shard[f0 - first + j] for j in range(cnt)]) for f0, cnt, _ in pieces]
+        res_sets = [[c.results() for c in coders] for coders in sets]
+        frames_ok = 0
+        for s in range(nsets):
+            v = verify_all(host, res_sets[s], n, nblocks) if nblocks else {"frames": 0}
+            if s and v["frames"] != frames_ok:
+                raise SystemExit("clip: pass slot %d verified %d frames, slot 0 %d" % (s, v["frames"], frames_ok))
+            frames_ok = v["frames"]
+        res_all = res_sets[0] if nsets else []
+        cnt_t = torch.tensor([frames_ok], dtype=torch.int64, device=COMM_DEVICE)
         if use_dist:
             dist.all_reduce(cnt_t)
-        verified = {"frames": int(cnt_t.item()), "of": total_pairs, "fields": "mask, k, l, filter, witness; frames arrive on rank 0 in clip order"}
-        if verified["frames"] != total_pairs:
-            raise SystemExit("clip: %d of %d inter-frames verified" % (verified["frames"], total_pairs))
+        want = total_pairs if proxy is None else my_pairs
+        verified = {"frames": int(cnt_t.item()), "of": want, "pass_slots_checked": nsets,
+                    "fields": "mask, k, l, filter, witness" + ("; frames arrive on rank 0 in clip order" if proxy is None else "; the packed record parses to the same rows")}
+        if verified["frames"] != want:
+            raise SystemExit("clip: %d of %d inter-frames verified" % (verified["frames"], want))
+        if proxy is not None and nblocks:
+            # the gather is stubbed: what WOULD travel is the packed record of every block -- parse it and compare it with the rows
+            b = (state["p"] - 1) % NREC
+            torch.cuda.synchronize(device)
+            parsed = 0
+            for i in range(nblocks):
+                rows = unpack_device_record(records[b][i].tensor.view(torch.uint8), n)
+                if len(rows) != len(res_all[i]):
+                    raise SystemExit("shard proxy: a packed record holds %d rows, its block %d" % (len(rows), len(res_all[i])))
+                for a, w in zip(rows, res_all[i]):
+                    if bool(a.get("skipped")) != bool(w.get("skipped")):
+                        raise SystemExit("shard proxy: skipped flags differ")
+                    if a.get("skipped"):
+                        continue
+                    if not (a["l"] == w["l"] and a["k"] == w["k"] and a["witness_bits"] == w["witness_bits"] and np.array_equal(a["witness"], w["witness"])
+                            and (not w["l"] or np.array_equal(a["filter"], w["filter"]))):
+                        raise SystemExit("shard proxy: a packed record differs from its block's rows")
+                    parsed += 1
+            verified["records_parsed"] = parsed
         if rank == 0 and got is not None:
             # every coded frame of the clip, in clip order, rebuilt from what ARRIVED: rank-major records, each a block's rows; the rows of
             # rank 0 are compared with its own results field by field, the others' frame indices with the shard arithmetic every rank can do
             parsed, expect = 0, []
             for r in range(world):
-                for f0, cnt, rs in clip_blocks(*shard_range(T, world, r), I, BG, NP):
+                for f0, cnt, rs in clip_blocks(*shard_range(T, world, r), I, BG, NP, FG):
                     expect.append([f0 + 1 + j for j in range(cnt - 1) if (j + 1) not in rs])
             if len(got) != len(expect):
                 raise SystemExit("rank 0 holds %d records, the shards make %d blocks" % (len(got), len(expect)))
@@ -1149,7 +1279,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
             if order != [t for t in range(T) if t % I]:
                 raise SystemExit("the gathered records do not cover the clip's inter-frames in order")
             mine = [x for res in res_all for x in res if not x.get("skipped")]
-            theirs = [x for b in got[:len(coders)] for x in unpack_device_record(b, n) if not x.get("skipped")]
+            theirs = [x for b in got[:nblocks] for x in unpack_device_record(b, n) if not x.get("skipped")]
             for a, w in zip(theirs, mine):
                 if not (a["l"] == w["l"] and a["witness_bits"] == w["witness_bits"] and np.array_equal(a["witness"], w["witness"]) and (not w["l"] or np.array_equal(a["filter"], w["filter"]))):
                     raise SystemExit("a record rank 0 kept from itself differs from its own rows")
@@ -1160,24 +1290,72 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True):
     out = None
     if rank == 0:
         e = elapsed_gather if elapsed_gather is not None else elapsed_plain
-        out = {"value": round(total_pairs * n * steps / e / 1e6, 2), "unit": "Mpixel/s", "ms_per_pass": round(e / steps * 1e3, 4),
+        pairs_timed = total_pairs if proxy is None else my_pairs
+        out = {"value": round(pairs_timed * n * steps / e / 1e6, 2), "unit": "Mpixel/s", "ms_per_pass": round(e / steps * 1e3, 4),
+               "pass_latency_ms": round(latency * 1e3, 4),
                "gather_to_rank0": elapsed_gather is not None,
-               "without_gather": {"value": round(total_pairs * n * steps / elapsed_plain / 1e6, 2), "ms_per_pass": round(elapsed_plain / steps * 1e3, 4)},
+               "without_gather": {"value": round(pairs_timed * n * steps / elapsed_plain / 1e6, 2), "ms_per_pass": round(elapsed_plain / steps * 1e3, 4)},
                "passes": steps, "scaling": "strong", "n_gpus": world,
                "workload": "%dx%d YUV444 %d-bit synthetic clip of %d frames, keyframe every %d (%d inter-frames/pass over %d GPU%s), k*=2.3, threshold 0"
-                           % (W, H, bits, T, I, total_pairs, world, "s" if world > 1 else ""),
+                           % (W, H, bits, T, I, total_pairs, s_world, "s" if s_world > 1 else ""),
                "sharding": "contiguous frame ranges + 1 halo frame (dist.shard_range)", "inter_frames_rank0": my_pairs,
-               "gops_per_call": BG or "auto", "blocks_rank0": [cnt - 1 - len(rs) for _, cnt, rs in pieces], "calls_per_pass_rank0": len(pieces), "backend": (args.backend if use_dist else None), "ranks_share_one_device": bool(args.one_device),
-               "batching": "one rbf_encode_gop per run of inter-frames" if BG == 1 else "every rank hands blocks of several keyframe intervals to ONE rbf_encode_runs launch sequence each (cut at the keyframes; inter-frames per block: blocks_rank0)",
+               "gops_per_call": BG or "auto", "blocks_rank0": [cnt - 1 - len(rs) for _, cnt, rs in pieces], "calls_per_pass_rank0": nblocks,
+               "pass_slots": nsets, "pipelines_used": nstreams,
+               "backend": (args.backend if use_dist else None), "ranks_share_one_device": bool(args.one_device),
+               "batching": "one rbf_encode_gop per run of inter-frames" if BG == 1 else "every rank hands blocks of several keyframe intervals to ONE rbf_encode_runs launch sequence each (cut at the keyframes; inter-frames per block: blocks_rank0); consecutive passes rotate over `pass_slots` sets of coders",
                "layout": "planar Y" if planar else "interleaved", "verified_vs_oracle": verified}
+        if proxy is not None:
+            out["proxy_of"] = {"world": s_world, "rank": s_rank, "frames": [start, stop], "first_frame_read": first, "gather": "stubbed (single process)"}
     # release the clip before the next leg
-    for c in coders:
-        c.close()
+    for coders in sets:
+        for c in coders:
+            c.close()
     for c in ctxs:
         c.close()
-    del coders, records, frames_t, ctxs
+    del sets, records, frames_t, ctxs
     torch.cuda.empty_cache()
     return out
+
+
+def shard_proxy_leg(args, env, T, I, steps, clip_cache, bits, base):
+    """What ONE rank of an N-way split of BASELINE configs[2] / [4] does, for N = 2, 4, 8 and EVERY rank of the split, on this one GPU:
+    run_clip(proxy=(N, r)) -- the rank's frame range + halo, its blocks, its pass slots, its packed record; the gather is stubbed.
+    The pass time of an N-GPU run is the slowest rank's (max over ranks, as the contract's timing takes it), so
+    predicted speed-up = (N = 1 pass) / (slowest rank's pass) and efficiency = speed-up / N.  A PREDICTION from single-GPU runs: no
+    xGMI transfer, no RCCL launch, no host of eight processes is in it.  The slowest rank's frames are verified against the oracle.
+    base: the clip leg's result at N = 1 for this bit depth.  Returns {"N1": ..., "N2": ..., "N4": ..., "N8": ...}."""
+    from new_bloom_filter_repo_amd.dist import shard_range
+    leg = {}
+    for N in (2, 4, 8):
+        coded = [sum(1 for t in range(*shard_range(T, N, r)) if t % I) for r in range(N)]
+        heavy = max(range(N), key=lambda r: (coded[r], -r))
+        per_rank, checked = [], None
+        for r in range(N):
+            res = run_clip(args, env, T, I, bits, steps, 2, verify=(r == heavy), proxy=(N, r), clip_cache=clip_cache)
+            per_rank.append(res)
+            if r == heavy:
+                checked = res["verified_vs_oracle"]
+        slow = max(range(N), key=lambda r: per_rank[r]["ms_per_pass"])
+        ms = per_rank[slow]["ms_per_pass"]
+        row = {"inter_frames_per_rank": coded, "ms_per_pass_per_rank": [x["ms_per_pass"] for x in per_rank],
+               "pass_latency_ms_per_rank": [x["pass_latency_ms"] for x in per_rank],
+               "slowest_rank": slow, "ms_per_pass": ms, "pass_latency_ms": per_rank[slow]["pass_latency_ms"],
+               "blocks_per_pass": per_rank[slow]["blocks_rank0"], "pass_slots": per_rank[slow]["pass_slots"],
+               "mpixels_per_s_of_the_rank": per_rank[slow]["value"],
+               "verified_vs_oracle": dict(checked or {}, rank=heavy)}
+        if base:
+            row["predicted_speedup"] = round(base["without_gather"]["ms_per_pass"] / ms, 2)
+            row["predicted_efficiency"] = round(base["without_gather"]["ms_per_pass"] / ms / N, 3)
+            row["predicted_clip_mpixels_per_s"] = round(base["without_gather"]["value"] * base["without_gather"]["ms_per_pass"] / ms, 1)
+        leg["N%d" % N] = row
+    if base:
+        leg["N1"] = {"ms_per_pass": base["without_gather"]["ms_per_pass"], "pass_latency_ms": base.get("pass_latency_ms"), "blocks_per_pass": base["blocks_rank0"], "pass_slots": base.get("pass_slots")}
+    return leg
+
+
+SHARD_PROXY_WHAT = {"what": "one rank's share of the clip exactly as run_clip runs it at N = 2 / 4 / 8 -- shard range + halo frame, blocks, pass slots, record packed on the device, "
+                            "gather stubbed -- timed for EVERY rank of the split on ONE GPU; predicted speed-up = N=1 pass / slowest rank's pass, efficiency = speed-up / N",
+                    "prediction_note": "a PREDICTION from single-GPU runs: the exact-size gather over xGMI (~4.4 MB per 290 frames in total), RCCL's launches and eight host processes are not in it"}
 
 
 def clip_main(args):
@@ -1185,6 +1363,15 @@ def clip_main(args):
     import torch.distributed as dist
     env = init_dist(args)
     world, rank, use_dist = env[0], env[1], env[4]
+    if args.proxy:
+        parts = [int(x) for x in args.proxy.split(",")]
+        cache = {}
+        rows = [run_clip(args, env, args.clip_frames, args.keyframe_interval, args.bits, args.steps, args.warmup, proxy=(parts[0], r), clip_cache=cache)
+                for r in (parts[1:2] or range(parts[0]))]
+        slow = max(rows, key=lambda x: x["ms_per_pass"])
+        print(json.dumps({"metric": "one rank's share of the clip (shard proxy)", "proxy_world": parts[0], "slowest": slow,
+                          "ms_per_pass_per_rank": [x["ms_per_pass"] for x in rows], "pass_latency_ms_per_rank": [x["pass_latency_ms"] for x in rows]}), flush=True)
+        return
     r = run_clip(args, env, args.clip_frames, args.keyframe_interval, args.bits, args.steps, args.warmup)
     if use_dist:
         dist.barrier()

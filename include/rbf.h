@@ -151,7 +151,8 @@ int rbf_activation_threshold(double k_star, uint32_t *floor_k, uint64_t *thresho
 /* The host step of BloomFilterCompressor.compress for a batch (:211-225): for frame f with
  * ones[f] set bits out of n, fill params[f] (and k[f] if k != NULL).  A frame the reference would
  * NOT Bloom-code (p >= P_STAR, l == 0, or l >= n when guard_l_ge_n != 0) gets params[f].m = 0,
- * which every batch entry point treats as "skip this frame" (empty witness, filter untouched). */
+ * which every batch entry point treats as "skip this frame": an empty witness, and a filter row WITHOUT DEFINED CONTENT (the LDS
+ * insert kernels leave it alone, the generic path clears every row of the batch). */
 int rbf_plan_batch(uint64_t n, const uint64_t *ones, uint32_t nframes, int guard_l_ge_n,
                    rbf_filter_params *params, double *k);
 
@@ -265,13 +266,16 @@ int rbf_encode_gop_poll(rbf_ctx *ctx, int *ready);
  * instead of once per GOP.
  *   run_starts   HOST array of nframes bytes, nullable (= one run, rbf_encode_gop_begin).  run_starts[t] != 0 for t >= 1: frame t is a
  *                keyframe of the caller's stream, it starts a new run, and PAIR t-1 (frame t against frame t-1) IS NOT CODED: its mask
- *                row is written as zeros, ones_dev[t-1] = 0, its stats are zero (an empty witness), its filter row is not touched,
+ *                row is written as zeros, ones_dev[t-1] = 0, its stats are zero (an empty witness), its filter row holds NO DEFINED CONTENT afterwards (the
+ *                LDS insert kernels never write it, the generic path clears every row of the batch: read nothing from it),
  *                params_out[t-1] = {m = 0, floor_k = RBF_PAIR_SKIPPED, 0}, k_out[t-1] = 0, and rbf_pack_records gives it a header row
  *                with no payload.  run_starts[0] is ignored.  No frame of a run is read by the mask stage of another run.
  * Everything else as rbf_encode_gop_begin / rbf_encode_gop; rbf_encode_gop_poll / rbf_encode_gop_finish complete either kind of begin.
- * Both begins check EVERY argument before they touch the stream or the caller's buffers, including
- * filter_stride_bytes >= rbf_filter_stride_min(width * height): the filters are planned in the second half, so the stride must cover
- * the largest filter the planner can produce for the frame size (l <= 0.31606 n for every density, :181-193). */
+ * Both begins check EVERY argument before they touch the stream or the caller's buffers.
+ * PRECONDITION SINCE ABI 4 (a caller written against ABI 3 that sized the filter rows from its own density bound gets RBF_EINVAL now):
+ *   filter_stride_bytes >= rbf_filter_stride_min(width * height), a multiple of 8.
+ * The filters are planned in the second half, from counts the first half has not seen yet, so the stride must cover the largest filter
+ * the planner can produce for the frame size (l <= 0.31606 n for every density, :181-193) -- ask rbf_filter_stride_min, do not guess. */
 #define RBF_PAIR_SKIPPED 0xFFFFFFFFu
 uint64_t rbf_filter_stride_min(uint64_t n);
 int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_stride_bytes,

@@ -1393,7 +1393,7 @@ int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
                           void *witnesses_dev, uint64_t witness_stride_bytes, uint64_t *stats_dev)
 {
     if (!ctx) return fail(RBF_EINVAL, "null context");
-    if (ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_gop_begin: the previous GOP of this context has not been finished");
+    if (ctx->gop.active) return fail(RBF_EINVAL, "rbf_encode_runs_begin / rbf_encode_gop_begin: the previous block of this context has not been finished (rbf_encode_gop_finish)");
     if (!filters_dev || !witnesses_dev || !stats_dev || !seeds) return fail(RBF_EINVAL, "null pointer");
     if (int r = set_device(ctx)) return r;
     // nothing below this block has run, and nothing of the caller's has been touched, when an argument is bad
@@ -1405,7 +1405,7 @@ int rbf_encode_runs_begin(rbf_ctx *ctx, const void *frames_dev, uint64_t frame_s
     if (filter_stride_bytes % 8) return fail(RBF_EINVAL, "filter stride must be a multiple of 8");
     // the filters are planned in the second half, from the counts: the stride has to cover whatever the planner can produce for n pixels
     if (filter_stride_bytes < rbf_filter_stride_min(n))
-        return fail(RBF_EINVAL, "filter stride %llu < rbf_filter_stride_min(%llu) = %llu", (unsigned long long)filter_stride_bytes,
+        return fail(RBF_EINVAL, "rbf_encode_runs_begin / rbf_encode_gop_begin: filter stride %llu < rbf_filter_stride_min(%llu) = %llu", (unsigned long long)filter_stride_bytes,
                     (unsigned long long)n, (unsigned long long)rbf_filter_stride_min(n));
     bool has_skip = false;
     if (run_starts) {

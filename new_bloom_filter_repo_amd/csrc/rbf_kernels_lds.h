@@ -841,11 +841,16 @@ struct LanePixels {
 // Threshold 0 (the lossless setting, verify_true_lossless.py:244-246): the bit is "luma changed", which needs no
 // per-pixel extraction.  8-bit: XOR whole dwords, pull the luma bytes of four pixels into one dword (v_perm), turn
 // "byte != 0" into the byte's top bit with the carry trick and squeeze the four flags into a nibble with one
-// multiply: ~3 instructions per pixel instead of ~10.  16-bit: d = a - b per 16-bit half (v_pk_sub_u16); numpy's
-// int16 arithmetic makes abs(d) > 0 false for d == 0 AND for d == 0x8000 (abs(-32768) stays negative, :801), so
-// the bit is (d & 0x7FFF) != 0.
+// multiply: ~3 instructions per pixel instead of ~10.  16-bit: numpy's int16 arithmetic makes abs(a - b) > 0 false for
+// a - b == 0 AND for a - b == 0x8000 (abs(-32768) stays negative, :801), i.e. exactly when a and b agree in their LOW 15 BITS -- so
+// the bit is ((a ^ b) & 0x7FFF) != 0 and no subtraction is needed.  Planar 16-bit luma (BASELINE config 5): per dword (two pixels) one
+// v_bitop3 ((a ^ b) & 0x7FFF7FFF), one v_pk_min_u16 against 0x00010001 (the two flags at bits 0 and 16) and one v_lshl_or into an
+// accumulator whose halves interleave at the end: 26 vector instructions per 16 pixels (round 5's v_pk_sub / carry / shift chain: 62).
+// `count_src`: a value with the same population count as the returned bits (the 16-bit path's accumulator: no masking needed).
+// `one2`: 1 in both halves, made by the caller ONCE with an asm v_mov -- the compiler turns a visible min(t, 1) into v_cmp + v_cndmask
+// through VCC (21 cycles a pair, profiles/r04_opbench2.txt), hence also the asm v_pk_min_u16.
 template <typename SAMPLE, int PIXEL_BYTES>
-__device__ __forceinline__ uint32_t lane_bits_thr0(const LanePixels<SAMPLE, PIXEL_BYTES> &a, const LanePixels<SAMPLE, PIXEL_BYTES> &b)
+__device__ __forceinline__ uint32_t lane_bits_thr0(const LanePixels<SAMPLE, PIXEL_BYTES> &a, const LanePixels<SAMPLE, PIXEL_BYTES> &b, uint32_t one2, uint32_t &count_src)
 {
     uint32_t bits = 0;
     if (sizeof(SAMPLE) == 1) {
@@ -862,23 +867,32 @@ __device__ __forceinline__ uint32_t lane_bits_thr0(const LanePixels<SAMPLE, PIXE
             const uint32_t f = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;   // top bit of every non-zero byte
             bits |= (((f >> 7) * 0x08040201u) >> 24) << shift_of_group[g];            // flags at 0,8,16,24 -> 27,26,25,24
         }
+        count_src = bits;
+    } else if (PIXEL_BYTES == 2) {
+        const uint32_t k7 = 0x7FFF7FFFu;
+        uint32_t acc = 0;                                       // (one2: 0x00010001 in a VGPR the compiler cannot see through, see the kernel)                                       // dword j's flags: pixel 2j at bit 2 (j ^ 3), pixel 2j+1 sixteen bits above
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int j = s ^ 4;                                // order 4,5,6,7,0,1,2,3: the first dword ends up highest
+            const uint32_t t = (a.d[j] ^ b.d[j]) & k7;
+            uint32_t g;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(g) : "v"(t), "v"(one2));
+            acc = (acc << 2) | g;
+        }
+        bits = (acc >> 16) | (acc << 1);                        // pixel 2j -> odd bit (2j) ^ 7, pixel 2j+1 -> the bit below; bits 16.. are never stored
+        count_src = acc;
     } else {
         typedef unsigned short h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                           // pixels 2j, 2j+1
-            uint32_t d;
-            if (PIXEL_BYTES == 2) {
-                const h2 t = __builtin_bit_cast(h2, a.d[j]) - __builtin_bit_cast(h2, b.d[j]);
-                d = __builtin_bit_cast(uint32_t, t);
-            } else {                                            // 6-byte pixels: luma = low half of dword 3j, high half of dword 3j+1
-                const h2 t0 = __builtin_bit_cast(h2, a.d[3 * j]) - __builtin_bit_cast(h2, b.d[3 * j]);
-                const h2 t1 = __builtin_bit_cast(h2, a.d[3 * j + 1]) - __builtin_bit_cast(h2, b.d[3 * j + 1]);
-                d = (__builtin_bit_cast(uint32_t, t0) & 0x0000FFFFu) | (__builtin_bit_cast(uint32_t, t1) & 0xFFFF0000u);
-            }
+        for (int j = 0; j < 8; ++j) {                           // pixels 2j, 2j+1; 6-byte pixels: luma = low half of dword 3j, high half of dword 3j+1
+            const h2 t0 = __builtin_bit_cast(h2, a.d[3 * j]) - __builtin_bit_cast(h2, b.d[3 * j]);
+            const h2 t1 = __builtin_bit_cast(h2, a.d[3 * j + 1]) - __builtin_bit_cast(h2, b.d[3 * j + 1]);
+            const uint32_t d = (__builtin_bit_cast(uint32_t, t0) & 0x0000FFFFu) | (__builtin_bit_cast(uint32_t, t1) & 0xFFFF0000u);
             const uint32_t f = ((d & 0x7FFF7FFFu) + 0x7FFF7FFFu) & 0x80008000u;          // top bit of every half with (d & 0x7FFF) != 0
             const uint32_t two = ((f >> 14) & 2u) | (f >> 31);                          // pixel 2j -> bit 1, pixel 2j+1 -> bit 0
             bits |= two << (((2 * j + 1) ^ 7));
         }
+        count_src = bits;
     }
     return bits;
 }
@@ -945,35 +959,69 @@ __global__ __launch_bounds__(WG_THREADS) void k_residual_mask_gop(
         const uint64_t lane_off = (seg * 1024 + (uint64_t)lane * 16) * PIXEL_BYTES;
         const uint8_t *p = frames + lane_off;
         uint16_t *out = masks + seg * 64 + lane;
+        uint32_t one2;
+        asm volatile("v_mov_b32 %0, 0x10001" : "=v"(one2));
         LP fa, fb, fc, fd;                                        // four frames in registers, roles rotate: TWO loads are in flight while a pair is compared
         fa.template load<NT>(p + (uint64_t)f0 * frame_stride);
         fb.template load<NT>(p + (uint64_t)(f0 + 1) * frame_stride);
         if (f0 + 2 <= f1) fc.template load<NT>(p + (uint64_t)(f0 + 2) * frame_stride);
-        // pair (prev, cur) = mask f-1; `nxt2` receives frame f+2 meanwhile (frame f+1 is already on its way)
-        auto step = [&](const LP &prev, const LP &cur, LP &nxt2, uint32_t f) {
+        // pair (prev, cur) = mask f-1; `nxt2` receives frame f+2 meanwhile (frame f+1 is already on its way).  Returns a value whose
+        // population count is this lane's number of set bits.
+        auto step = [&](const LP &prev, const LP &cur, LP &nxt2, uint32_t f) -> uint32_t {
             if (f + 2 <= f1) nxt2.template load<NT>(p + (uint64_t)(f + 2) * frame_stride);
             const int32_t thr = thr_tab ? thr_tab[f - 1] : thr_all;
-            uint32_t bits = 0;
-            if (THR0) bits = lane_bits_thr0<SAMPLE, PIXEL_BYTES>(prev, cur);      // host: no per-pair table and thr == 0
+            uint32_t bits = 0, csrc = 0;
+            if (THR0) bits = lane_bits_thr0<SAMPLE, PIXEL_BYTES>(prev, cur, one2, csrc);      // host: no per-pair table and thr == 0
             else {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const bool b = residual_bit<SAMPLE>((SAMPLE)prev.luma(k), (SAMPLE)cur.luma(k), thr);
                     bits |= (b ? 1u : 0u) << (k ^ 7);         // MSB-first within each byte
                 }
+                csrc = bits;
             }
             out[(uint64_t)(f - 1) * mask_stride_u16] = (uint16_t)bits;
-            // the wave's count of the pair: six DPP adds, total in lane 63 (six __shfl_down were six ds_bpermute round trips per step)
-            const uint32_t c = wave_sum_to_lane63(__popc(bits));
-            if (lane == 63u && c) atomicAdd(&cnt[f - 1], c);
+            return csrc;
+        };
+        // The wave's counts stay in ONE register until the chunk ends: lane s of `tally` holds the ones of pairs base + 2s (low half) and
+        // base + 2s + 1 (high half).  Two pairs share a DPP tree (their lane counts ride as packed 16-bit halves, each total <= 1024),
+        // v_readlane hands the packed totals to the scalar unit and ONE v_writelane files them.  Round 5 did a six-step tree, a compare, two exec
+        // masks and the compiler's uniform-address atomic loop (~8 vector + ~15 scalar instructions and an LDS atomic) PER PAIR -- in a
+        // kernel that runs underneath the issue-bound insert / query kernels of the neighbouring pipelines, where every instruction it
+        // issues is one of theirs that waits.
+        uint32_t tally = 0, base = f0;
+        auto flush = [&]() {
+            const uint32_t i = base + 2u * lane;
+            if (i < f1 && (tally & 0xFFFFu)) atomicAdd(&cnt[i], tally & 0xFFFFu);     // (per-lane addresses: one ds_add_u32 for the wave)
+            if (i + 1u < f1 && (tally >> 16)) atomicAdd(&cnt[i + 1u], tally >> 16);
+            tally = 0;
+        };
+        auto file2 = [&](uint32_t c_even, uint32_t c_odd, uint32_t f) {               // counts of pairs f-1 and f
+            const uint32_t tot = wave_sum_to_lane63(__popc(c_even) | (__popc(c_odd) << 16));
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tot, 63);
+            const uint32_t slot = (f - 1u - base) >> 1;                               // < 64 (scalar: f and base are uniform)
+            uint32_t keep;
+            // v_writelane takes ONE SGPR over the constant bus, so the lane select rides in M0 (reserved: saved and restored, as RowDmaC does)
+            asm volatile("s_mov_b32 %1, m0\n\t"
+                         "s_mov_b32 m0, %3\n\t"
+                         "s_nop 0\n\t"
+                         "v_writelane_b32 %0, %2, m0\n\t"
+                         "s_mov_b32 m0, %1"
+                         : "+v"(tally), "=&s"(keep) : "s"(t), "s"(slot));
         };
         // unrolled by four so that the rotation prev <- cur <- nxt <- nxt2 costs no register moves
         for (uint32_t f = f0 + 1; f <= f1; f += 4) {
-            step(fa, fb, fd, f);
-            if (f + 1 <= f1) step(fb, fc, fa, f + 1);
-            if (f + 2 <= f1) step(fc, fd, fb, f + 2);
-            if (f + 3 <= f1) step(fd, fa, fc, f + 3);
+            if (f - 1u - base == 2u * WAVE) { flush(); base += 2u * WAVE; }
+            const uint32_t c0 = step(fa, fb, fd, f);
+            const uint32_t c1 = f + 1 <= f1 ? step(fb, fc, fa, f + 1) : 0u;
+            file2(c0, c1, f);
+            if (f + 2 <= f1) {
+                const uint32_t c2 = step(fc, fd, fb, f + 2);
+                const uint32_t c3 = f + 3 <= f1 ? step(fd, fa, fc, f + 3) : 0u;
+                file2(c2, c3, f + 2);
+            }
         }
+        flush();
     }
     __syncthreads();
     for (uint32_t i = f0 + threadIdx.x; i < f1; i += WG_THREADS)

@@ -57,13 +57,15 @@ def record_used_bytes(buf):
     return int(head[2])
 
 
-def unpack_device_record(buf, n):
+def unpack_device_record(buf, n, copy=True):
     """Parse the block rbf_pack_records wrote (GopCoder.pack): list of per-frame dicts with the
     packed filter / witness bytes (numpy.packbits order), or the packed mask for frames the
-    reference does not Bloom-code (l == 0).  buf: bytes-like, numpy array or (device) tensor."""
+    reference does not Bloom-code (l == 0).  buf: bytes-like, numpy array or (device) tensor.
+    copy=False: the rows' arrays are views of `buf` (a numpy uint8 array the caller keeps alive)."""
     if hasattr(buf, "cpu"):
         buf = buf.cpu().numpy()
-    raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+    raw = np.frombuffer(bytes(buf), dtype=np.uint8) if copy or not isinstance(buf, np.ndarray) else buf.view(np.uint8).reshape(-1)
+    take = (lambda a: a.copy()) if copy else (lambda a: a)
     head = raw[:32].view("<u8")
     if int(head[0]) != RECORD_MAGIC:
         raise ValueError("not a packed record")
@@ -80,10 +82,10 @@ def unpack_device_record(buf, n):
             out.append(rec)
             continue
         if m:
-            rec["filter"] = raw[foff:foff + (m + 7) // 8].copy()
+            rec["filter"] = take(raw[foff:foff + (m + 7) // 8])
         else:
-            rec["mask"] = raw[foff:foff + (n + 7) // 8].copy()
-        rec["witness"] = raw[woff:woff + (wbits + 7) // 8].copy()
+            rec["mask"] = take(raw[foff:foff + (n + 7) // 8])
+        rec["witness"] = take(raw[woff:woff + (wbits + 7) // 8])
         out.append(rec)
     return out
 

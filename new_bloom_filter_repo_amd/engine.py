@@ -348,11 +348,13 @@ def gather_values(ctx, frame, mask_packed):
     return vals
 
 
-def apply_chain(ctx, base, masks_packed, values_list, chunk_frames=64):
+def apply_chain(ctx, base, masks_packed, values_list, chunk_frames=64, chunk_bytes=256 << 20):
     """A8 for a run of inter-frames: frame t = frame t-1 with `values_list[t]` written at mask t's '1' pixels
-    (improved_video_compressor.py:849-909).  The run is rebuilt ON THE DEVICE in chunks of `chunk_frames`: one upload of the chunk's masks,
-    one of its values, then per frame a device-to-device copy of its predecessor and one scatter, no host round trip in between; the
-    chunk's frames come back in ONE download.  Returns the list of frames (views of the downloaded blocks)."""
+    (improved_video_compressor.py:849-909).  The run is rebuilt ON THE DEVICE in chunks of at most `chunk_frames` frames and `chunk_bytes`
+    bytes (1080p YUV444: 41 frames; an 8K 16-bit frame: one at a time -- device block and host block stay bounded whatever the frame
+    size): one upload of the chunk's masks, one of its values, then per frame a device-to-device copy of its predecessor and one
+    scatter, no host round trip in between; the chunk's frames come back in ONE download.
+    Returns the list of frames.  They are VIEWS of the downloaded chunk blocks: keeping one of them alive keeps its whole chunk alive."""
     base = np.ascontiguousarray(base)
     H, W = base.shape[:2]
     C = base.shape[2] if base.ndim == 3 else 1
@@ -365,7 +367,7 @@ def apply_chain(ctx, base, masks_packed, values_list, chunk_frames=64):
     if total == 0:
         return out
     L = nat.lib()
-    per = max(1, min(int(chunk_frames), total))
+    per = max(1, min(int(chunk_frames), total, int(chunk_bytes) // max(1, fbytes)))
     fb = ctx.alloc((per + 1) * fbytes)                            # slot 0: the predecessor of the chunk's first frame
     mb = ctx.alloc(per * stride)
     vcap = 8

@@ -105,20 +105,44 @@ class FixedVideoCompressor:
         self.verbose = verbose
 
     def compress_frame(self, frame):
+        return self.compress_frame_jobs(frame)()
+
+    def compress_frame_jobs(self, frame, submit=None):
+        """The keyframe record as up to four independent zlib-9 jobs -- the interleaved frame and its three planes -- handed to
+        `submit(fn) -> future` (default: run inline); returns a callable that waits for them and joins the record.  One code path for the
+        byte layout (fixed_video_compressor.py:38-106), whether the jobs run one after the other (compress_frame) or on a pool's threads
+        (ImprovedVideoCompressor: a 1080p keyframe is ~0.4 s of zlib-9 in ONE job, the longest thing a 300-frame clip waits for)."""
+        if submit is None:
+            class _Now:
+                def __init__(self, fn):
+                    self.value = fn()
+
+                def result(self):
+                    return self.value
+            submit = _Now
         arr = frame_data(frame)
-        body = zlib.compress(arr.tobytes(), level=9)
-        out = [struct.pack("<III", arr.shape[0], arr.shape[1], arr.dtype.itemsize),
-               struct.pack("<I", len(body)), body]
+        head = struct.pack("<III", arr.shape[0], arr.shape[1], arr.dtype.itemsize)
+        body = submit(lambda: zlib.compress(arr.tobytes(), level=9))
         has_info = hasattr(frame, "yuv_info")
-        out.append(struct.pack("<B", 1 if has_info else 0))
+        planes = []
         if has_info:
             fmt = frame.yuv_info.get("format", "YUV444").encode("utf-8")
-            out += [struct.pack("<H", len(fmt)), fmt]
-            for key in ("y_plane", "u_plane", "v_plane"):
-                plane = frame.yuv_info[key]
-                z = zlib.compress(plane.tobytes(), level=9)
-                out += [struct.pack("<I", len(z)), z, struct.pack("<II", *plane.shape)]
-        return b"".join(out)
+
+            def plane_job(key):
+                plane = frame.yuv_info[key]          # (copied out of the interleaved frame on first use, on the job's thread)
+                return zlib.compress(plane.tobytes(), level=9), plane.shape
+            planes = [submit(lambda key=key: plane_job(key)) for key in ("y_plane", "u_plane", "v_plane")]
+
+        def finish():
+            b = body.result()
+            out = [head, struct.pack("<I", len(b)), b, struct.pack("<B", 1 if has_info else 0)]
+            if has_info:
+                out += [struct.pack("<H", len(fmt)), fmt]
+                for job in planes:
+                    z, shape = job.result()
+                    out += [struct.pack("<I", len(z)), z, struct.pack("<II", *shape)]
+            return b"".join(out)
+        return finish
 
     def decompress_frame(self, blob):
         h, w, item = struct.unpack_from("<III", blob, 0)

@@ -85,16 +85,7 @@ class GopCoder:
         self.thr = 0 if threshold is None else threshold_floor(threshold)
         self.adaptive = adaptive if threshold is None else None
         self.thr_tab = None
-        self.run_starts = None
-        self.skipped = [False] * self.pairs
-        if run_starts:
-            self.run_starts = (ctypes.c_uint8 * nframes)()
-            for t in run_starts:
-                if not 0 <= int(t) < nframes:
-                    raise ValueError("run start %r outside the block of %d frames" % (t, nframes))
-                if int(t) > 0:
-                    self.run_starts[int(t)] = 1
-                    self.skipped[int(t) - 1] = True
+        self.set_run_starts(run_starts)
         base_alloc = allocator or owned_allocator(ctx)
         self._blocks = []
 
@@ -125,6 +116,20 @@ class GopCoder:
         if self.adaptive is not None:
             self.moments = alloc(16 * self.pairs)
             self.noise_plane = None                       # allocated on the first exact fallback
+
+    def set_run_starts(self, run_starts):
+        """Name the keyframes inside the block for the following encode() calls (see the constructor): a coder is sized by its frame
+        count, not by where its runs start, so one coder serves every block of a stream whatever the keyframe interval."""
+        self.run_starts = None
+        self.skipped = [False] * self.pairs
+        if run_starts:
+            self.run_starts = (ctypes.c_uint8 * self.F)()
+            for t in run_starts:
+                if not 0 <= int(t) < self.F:
+                    raise ValueError("run start %r outside the block of %d frames" % (t, self.F))
+                if int(t) > 0:
+                    self.run_starts[int(t)] = 1
+                    self.skipped[int(t) - 1] = True
 
     @staticmethod
     def strides(n):
@@ -272,6 +277,25 @@ class GopCoder:
         if not check_uncovered:
             return vals
         return vals, self._uncov.numpy(self.ctx)[:8 * self.pairs].view(np.uint64).copy()
+
+    def results_packed(self):
+        """What results() returns, through ONE exact-size download: the rows are compacted into a record on the device (rbf_pack_records:
+        header + the used bytes of every filter and witness, ~150 KB per 1080p frame instead of ~600 KB of padded rows), the record's
+        32-byte header says how many bytes to fetch.  Rows carry `filter` / `witness` (and `mask` only for frames the reference passes
+        through uncoded, l == 0) as views of the downloaded record; `ones` comes from the mask stage's counts."""
+        from .dist import unpack_device_record, record_used_bytes
+        block = self.pack()
+        self.ctx.sync()
+        used = record_used_bytes(block.numpy(self.ctx, 32))
+        raw = block.numpy(self.ctx, (used + 7) // 8 * 8)
+        ones = self.ones.numpy(self.ctx)[:8 * self.pairs].view(np.uint64)
+        rows = unpack_device_record(raw, self.n, copy=False)
+        assert len(rows) == self.pairs
+        for f, r in enumerate(rows):
+            r["ones"] = int(ones[f])
+            if r.get("skipped"):
+                assert self.skipped[f] and r["ones"] == 0
+        return rows
 
     def results(self):
         """Download: list of per-frame dicts (mask/filter/witness packed uint8, counts, k, l)."""

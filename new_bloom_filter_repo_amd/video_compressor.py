@@ -14,6 +14,7 @@ type-byte precedent of VideoFrameCompressor.compress_frame (:1053).
 """
 import os
 import struct
+import threading
 import time
 import zlib
 from concurrent.futures import ThreadPoolExecutor
@@ -21,7 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import params as P
-from .frame_codec import FixedVideoCompressor, VideoFrameCompressor, YUVFrame, frame_data
+from .frame_codec import FixedVideoCompressor, VideoFrameCompressor, YUVFrame, build_record, frame_data, parse_record
 
 KEY, INTER = 1, 2
 _POPCOUNT8 = np.unpackbits(np.arange(256, dtype=np.uint8)[:, None], axis=1).sum(axis=1).astype(np.uint8)   # numpy 1.x has no bitwise_count
@@ -40,16 +41,73 @@ def _as_block(data):
     return np.stack(data)
 
 
+class _Lane:
+    """One GPU lane of the plugin surface: a library context (= one HIP stream) with the GOP coders and the decode engine that live on
+    it.  Consecutive blocks of a video alternate over the lanes, each block driven by its own host thread (the C ABI's copies are
+    synchronous and ctypes drops the GIL), so block b+1 uploads while block b encodes and block b-1 downloads."""
+
+    def __init__(self, ctx, owned):
+        self.ctx, self.owned = ctx, owned
+        self.coders = {}
+        self.engine = None
+
+    def coder(self, W, H, F, C, sb):
+        from .gop import GopCoder
+        key = (W, H, F, C, sb)
+        c = self.coders.get(key)
+        if c is None:
+            if len(self.coders) >= 2:            # a stream has at most two block sizes (full blocks and its tail)
+                for old in self.coders.values():
+                    old.close()
+                self.coders = {}
+            c = self.coders[key] = GopCoder(self.ctx, W, H, F, channels=C, sample_bytes=sb)
+        return c
+
+    def decode_engine(self):
+        from .engine import BloomEngine
+        if self.engine is None:
+            self.engine = BloomEngine(self.ctx)
+        return self.engine
+
+    def release(self):
+        for c in self.coders.values():
+            c.close()
+        self.coders = {}
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+    def close(self):
+        self.release()
+        if self.owned:
+            self.ctx.close()
+
+
+def _union_seconds(intervals):
+    """Total length of the union of (t0, t1) intervals."""
+    total, end = 0.0, None
+    for t0, t1 in sorted(intervals):
+        if end is None or t0 > end:
+            total += t1 - t0
+            end = t1
+        elif t1 > end:
+            total += t1 - end
+            end = t1
+    return total
+
+
 class ImprovedVideoCompressor:
     def __init__(self, noise_tolerance=10.0, keyframe_interval=30, min_diff_threshold=3.0,
                  max_diff_threshold=30.0, bloom_threshold_modifier=1.0, batch_size=30,
                  num_threads=None, use_direct_yuv=False, verbose=False, ctx=None, inter_frames=None,
-                 gop_batching=True, block_frames=None):
-        """Reference signature (improved_video_compressor.py:318-327) plus four keyword-only extras:
+                 gop_batching=True, block_frames=None, gpu_lanes=2):
+        """Reference signature (improved_video_compressor.py:318-327) plus five keyword-only extras:
         ctx (library context), gop_batching (False: one set of C-ABI calls per inter-frame instead of one
         per block; both write the same bytes), block_frames (consecutive frames handed to the GPU in ONE
-        rbf_encode_runs launch sequence -- several GOPs, cut at the keyframes; default 4 GOPs, at most 128
-        frames) and inter_frames -- None (default): YUV input is coded with
+        rbf_encode_runs launch sequence -- several GOPs, cut at the keyframes; default 2 GOPs, at most 128
+        frames), gpu_lanes (contexts = HIP streams the blocks alternate over, each block on its own host
+        thread: upload, encode and download of neighbouring blocks overlap; 1 = one block at a time) and
+        inter_frames -- None (default): YUV input is coded with
         Bloom inter-frames ('BFV2' container, which the reference's decompress_video rejects), anything
         else as keyframes; False: always the reference's all-keyframe 'BFVC' container, readable by the
         reference; True: inter-frames for every colour space (lossless fallback to keyframes per frame)."""
@@ -62,22 +120,27 @@ class ImprovedVideoCompressor:
         self.batch_size = batch_size
         self.num_threads = max(1, num_threads or min(64, os.cpu_count() or 1))     # zlib of keyframes / changed values
         self.gop_batching = bool(gop_batching)
-        self.block_frames = max(2, int(block_frames)) if block_frames else min(128, max(2, 4 * self.keyframe_interval))
+        # default block: two keyframe intervals (a multiple of the interval: every block of a stream has the same shape), at most 128 frames.
+        # Small blocks start the host's zlib of the changed values early; the GPU's share of a block is a fraction of a millisecond either way.
+        self.block_frames = max(2, int(block_frames)) if block_frames else min(128, max(2, 2 * self.keyframe_interval if 2 * self.keyframe_interval <= 128 else self.keyframe_interval))
+        self.gpu_lanes = max(1, int(gpu_lanes))
         self.use_direct_yuv = use_direct_yuv
         self.verbose = verbose
         self.compressor = FixedVideoCompressor(verbose=verbose)
         self._ctx = ctx
         self._inter = None
         self.last_compressed_frames = None       # [(type, record bytes)] of the last compress_video call
-        self.last_timing = None                  # seconds per stage of the last encode_range (bench.py's e2e_surface leg)
-        self._gop_coder, self._gop_key = None, None
+        self.last_timing = None                  # seconds per stage of the last encode_range / decompress_video (bench.py's e2e_surface leg)
+        self.profile_stages = False              # True: synchronise between the stages of a block so that last_timing can tell them apart (bench.py)
+        self._lanes = []
+        self._tm_lock = threading.Lock()
 
     def close(self):
-        """Return the device memory this compressor holds (the cached GOP coder and the inter-frame codec's
+        """Return the device memory this compressor holds (the lanes' GOP coders and contexts, the inter-frame codec's
         scratch).  Also happens when the object is dropped; the compressor stays usable afterwards."""
-        if self._gop_coder is not None:
-            self._gop_coder.close()
-        self._gop_coder, self._gop_key = None, None
+        for lane in self._lanes:
+            lane.close()
+        self._lanes = []
         if self._inter is not None:
             self._inter.close()
 
@@ -87,12 +150,39 @@ class ImprovedVideoCompressor:
     def __exit__(self, *exc):
         self.close()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     @property
     def inter(self):
         if self._inter is None:
             self._inter = VideoFrameCompressor(keyframe_interval=self.keyframe_interval, use_direct_yuv=True,
                                                verbose=False, ctx=self._ctx)
         return self._inter
+
+    def _get_lanes(self, count):
+        """`count` lanes: lane 0 is the caller's context (or the process default), the others are contexts of their own on the same device."""
+        from . import _native as nat
+        if not self._lanes:
+            self._lanes.append(_Lane(self._ctx or nat.default_context(), False))
+        while len(self._lanes) < count:
+            self._lanes.append(_Lane(nat.Context(self._lanes[0].ctx.device), True))
+        return self._lanes[:count]
+
+    def _release_lanes(self):
+        for lane in self._lanes:
+            lane.release()
+
+    def _tm_add(self, **kw):
+        tm = self.last_timing
+        if tm is None:
+            return
+        with self._tm_lock:
+            for name, dt in kw.items():
+                tm[name] = tm.get(name, 0.0) + dt
 
     # ------------------------------------------------------------------ encode
     def _encode_inter(self, prev, curr):
@@ -111,17 +201,15 @@ class ImprovedVideoCompressor:
         record, _ = self.inter._compress_frame_differences(mask, values)
         return struct.pack("<B", b.dtype.itemsize) + record
 
-    def _encode_block(self, seg, pool, run_starts=()):
+    def _encode_block(self, seg, pool, run_starts=(), lane=None, busy=None):
         """Inter-frame records of one block of consecutive frames in one pass over the GPU: seg[0] is only read (a keyframe, or a
         shard's halo frame), every other frame is coded against its predecessor -- except the frames named in `run_starts` (indices
         into seg), which are keyframes of the stream: they start a new run and the pair in front of them is not coded.  One upload,
-        ONE rbf_encode_runs launch sequence for all the runs, one batched gather of the changed values (with the count of changes the
-        luma mask cannot carry); zlib runs in `pool`.
+        ONE rbf_encode_runs launch sequence for all the runs, ONE exact-size download of the packed record (rbf_pack_records), one
+        batched gather of the changed values (with the count of changes the luma mask cannot carry); zlib runs in `pool`.
+        lane: the context and coders to use (default: lane 0); busy: list that receives the (start, end) time of this block's GPU work.
         Returns a list of futures / None per pair (None = needs a keyframe, or is one), or None when the block cannot be batched
         (mixed shapes or dtypes)."""
-        from .gop import GopCoder
-        from . import _native as nat
-        tm = self.last_timing if self.last_timing is not None else {}
         t0 = time.perf_counter()
         data = [frame_data(f) for f in seg]
         a = data[0]
@@ -133,29 +221,27 @@ class ImprovedVideoCompressor:
         C = a.shape[2] if a.ndim == 3 else 1
         if C > 4:                                # rbf_gather_values_batch carries at most 4 samples per pixel
             return [None] * (len(seg) - 1)
-        ctx = self._ctx or nat.default_context()
-        key = (W, H, len(seg), C, a.dtype.itemsize, tuple(run_starts))
-        if self._gop_key != key:
-            if self._gop_coder is not None:
-                self._gop_coder.close()
-            self._gop_coder, self._gop_key = GopCoder(ctx, W, H, len(seg), channels=C, sample_bytes=a.dtype.itemsize, run_starts=list(run_starts)), key
-        coder = self._gop_coder
+        if lane is None:
+            lane = self._get_lanes(1)[0]
+        ctx = lane.ctx
+        coder = lane.coder(W, H, len(seg), C, a.dtype.itemsize)
+        coder.set_run_starts(list(run_starts))
         block = _as_block(data)
         t1 = time.perf_counter()
-        coder.load_frames(block)
-        ctx.sync()
+        coder.load_frames(block)                 # (synchronous: the frames are pageable host memory)
         t2 = time.perf_counter()
         coder.encode()
-        ctx.sync()
+        if self.profile_stages:
+            ctx.sync()
         t3 = time.perf_counter()
-        res = coder.results()
+        res = coder.results_packed()
         t4 = time.perf_counter()
         values, uncovered = coder.gather_values(check_uncovered=True)
         t5 = time.perf_counter()
-        for name, dt in (("stack", t1 - t0), ("upload", t2 - t1), ("gpu_encode", t3 - t2), ("download_rows", t4 - t3), ("value_gather", t5 - t4)):
-            tm[name] = tm.get(name, 0.0) + dt
+        self._tm_add(stack=t1 - t0, upload=t2 - t1, gpu_encode=t3 - t2, download_rows=t4 - t3, value_gather=t5 - t4)
+        if busy is not None:
+            busy.append((t1, t5))
         n = H * W
-        inter = self.inter
         out = []
         for f, r in enumerate(res):
             if r.get("skipped") or int(uncovered[f]):    # the pair in front of a keyframe; or chroma moved where luma did not: not representable
@@ -166,15 +252,15 @@ class ImprovedVideoCompressor:
                 # the filter and the witness were built with the k rbf_plan_batch computed in C: the record carries THAT
                 # value (the decoder derives floor_k and T from it), so a last-ulp difference to the Python twin is harmless
                 k = r["k"]
-                parts = (r["l"], r["filter"].tobytes(), r["witness_bits"], r["witness"].tobytes())
+                parts = (r["l"], r["filter"], r["witness_bits"], r["witness"])
             else:                                # the reference passes the mask itself through (:215-225)
                 k, _l = P.optimal_params(n, p)
-                parts = (n, r["mask"].tobytes(), 0, b"")
+                parts = (n, r["mask"], 0, b"")
             vals = values[f]
 
             def job(p=p, k=k, parts=parts, vals=vals):
-                vz = zlib.compress(vals.tobytes(), level=9)
-                return struct.pack("<B", vals.dtype.itemsize) + inter._build_record(p, n, k, *parts, len(vals), vz)
+                vz = zlib.compress(vals, level=9)
+                return struct.pack("<B", vals.dtype.itemsize) + build_record("f64", p, n, k, *parts, len(vals), vz)      # (VideoFrameCompressor's default wire format)
             out.append(pool.submit(job))
         return out
 
@@ -182,38 +268,64 @@ class ImprovedVideoCompressor:
         """[(type, record)] for the frames with global indices [start, stop); frames[i] is global frame
         first_index + i (a shard passes its halo frame too, dist.halo_start).  Frame t is a keyframe iff
         t % keyframe_interval == 0; the inter-frames are coded in blocks of up to `block_frames` consecutive frames --
-        several GOPs per block, ONE launch sequence on the GPU per block, cut at the keyframes."""
+        several GOPs per block, ONE launch sequence on the GPU per block, cut at the keyframes.  The blocks alternate over
+        `gpu_lanes` contexts, each block on its own host thread; the host's zlib-9 (keyframes: four jobs each; changed values:
+        one job per frame) runs on `num_threads` threads under all of it."""
         records = {}
         I = self.keyframe_interval
         self.last_timing = tm = {}
         t_all = time.perf_counter()
+        busy = []
         with ThreadPoolExecutor(self.num_threads) as pool:
             pending = {}
 
             def key(t):
                 if t not in pending:
-                    pending[t] = (KEY, pool.submit(self.compressor.compress_frame, frames[t - first_index]))
-            # the keyframes the rule fixes in advance go to the host threads FIRST: their zlib-9 (the longest single jobs, ~0.3 s for a 1080p
-            # frame and its three planes) then runs under the GPU's blocks instead of behind the last one
+                    pending[t] = (KEY, self.compressor.compress_frame_jobs(frames[t - first_index], pool.submit))
+            # the keyframes the rule fixes in advance go to the host threads FIRST: their zlib-9 (the longest single jobs, ~0.2 s for a 1080p
+            # frame, plus its three planes) then runs under the GPU's blocks instead of behind the last one
             for t in range(start, stop):
                 if not inter_frames or t % I == 0 or t - 1 < first_index:
                     key(t)
+            blocks = []                                                      # (first frame read, end, run starts)
             t = start
             while t < stop:
                 if not inter_frames or t % I == 0 or t - 1 < first_index:
                     t += 1
                     continue
                 end = min(stop, t - 1 + self.block_frames)                   # the block reads frames t-1 .. end-1
-                seg = frames[t - 1 - first_index:end - first_index]          # predecessor + the frames t..end-1
-                starts = [u - (t - 1) for u in range(t, end) if u % I == 0]  # keyframes inside the block: new runs
-                inter = self._encode_block(seg, pool, starts) if self.gop_batching else None
+                blocks.append((t - 1, end, [u - (t - 1) for u in range(t, end) if u % I == 0]))      # keyframes inside the block: new runs
+                t = end
+            results = [None] * len(blocks)
+            if self.gop_batching and blocks:
+                import queue
+                lanes = self._get_lanes(min(self.gpu_lanes, len(blocks)))
+                free = queue.Queue()
+                for lane in lanes:
+                    free.put(lane)
+
+                def run_block(b):
+                    lo, end, starts = blocks[b]
+                    lane = free.get()
+                    try:
+                        return self._encode_block(frames[lo - first_index:end - first_index], pool, starts, lane, busy)
+                    finally:
+                        free.put(lane)
+                if len(lanes) == 1:
+                    results = [run_block(b) for b in range(len(blocks))]
+                else:
+                    with ThreadPoolExecutor(len(lanes)) as gpu_pool:
+                        results = list(gpu_pool.map(run_block, range(len(blocks))))
+            tm["gpu_phase"] = time.perf_counter() - t_all                    # until the last block's values were on the host
+            for (lo, end, starts), inter in zip(blocks, results):
+                seg = frames[lo - first_index:end - first_index]             # predecessor + the frames lo+1..end-1
                 for j in range(1, len(seg)):
-                    u = t - 1 + j
+                    u = lo + j
                     if u % I == 0:
                         key(u)
                         continue
                     fut = inter[j - 1] if inter is not None else None
-                    if inter is None:
+                    if inter is None:                                        # not batchable (or gop_batching=False): frame by frame
                         rec = self._encode_inter(seg[j - 1], seg[j])
                         if rec is not None:
                             records[u] = (INTER, rec)
@@ -222,12 +334,14 @@ class ImprovedVideoCompressor:
                         pending[u] = (INTER, fut)
                     else:
                         key(u)
-                t = end
             t_wait = time.perf_counter()
             for u, (ty, fut) in pending.items():
-                records[u] = (ty, fut.result())
+                records[u] = (ty, fut() if ty == KEY else fut.result())
             tm["zlib_wait"] = time.perf_counter() - t_wait                   # what the host threads' zlib-9 still owed after the last block left the GPU
         tm["total"] = time.perf_counter() - t_all
+        tm["gpu_busy"] = _union_seconds(busy)                                # wall time during which at least one lane had a copy or a kernel in flight
+        tm["gpu_busy_frac"] = tm["gpu_busy"] / tm["total"] if tm["total"] > 0 else 0.0
+        tm["blocks"], tm["lanes"] = len(blocks), min(self.gpu_lanes, max(1, len(blocks)))
         return [records[u] for u in range(start, stop)]
 
     def compress_video(self, frames, output_path=None, input_color_space="BGR"):
@@ -248,9 +362,7 @@ class ImprovedVideoCompressor:
         try:
             records = self.encode_range(frames, 0, 0, len(frames), inter_frames=use_inter)
         finally:
-            if self._gop_coder is not None:      # a GOP of frames, masks, filters and witnesses: do not keep it between videos
-                self._gop_coder.close()
-                self._gop_coder, self._gop_key = None, None
+            self._release_lanes()                # blocks of frames, masks, filters and witnesses: do not keep them between videos
         self.last_compressed_frames = records
         keyframes = sum(1 for ty, _ in records if ty == KEY)
         blob = self._container(records)
@@ -300,6 +412,7 @@ class ImprovedVideoCompressor:
 
     def decompress_video(self, input_path=None, output_path=None, compressed_frames=None, metadata=None):
         start = time.time()
+        t_all = time.perf_counter()
         records = None
         if input_path and os.path.exists(input_path):
             with open(input_path, "rb") as f:
@@ -308,25 +421,66 @@ class ImprovedVideoCompressor:
             records = [r if isinstance(r, tuple) else (KEY, r) for r in compressed_frames]
         if not records:
             raise ValueError("No compressed frames provided")
-        frames = []
-        i = 0
+        for ty, _ in records:
+            if ty not in (KEY, INTER):
+                raise ValueError(f"unknown record type {ty}")
+        if records[0][0] == INTER:
+            raise ValueError("inter-frame without a preceding keyframe")
+        self.last_timing = tm = {}
+        busy = []
         # the keyframes are independent of everything else: inflate them on the host threads while the inter-frame runs go through the GPU
         key_pool = ThreadPoolExecutor(self.num_threads)
         keys = {j: key_pool.submit(self.compressor.decompress_frame, rec) for j, (ty, rec) in enumerate(records) if ty == KEY}
-        key_pool.shutdown(wait=False)
+        runs = []                                                            # (index of the keyframe in front, first record, end)
+        i = 0
         while i < len(records):
-            ty, rec = records[i]
-            if ty == KEY:
-                frames.append(keys[i].result())
+            if records[i][0] == KEY:
                 i += 1
-            elif ty == INTER:
-                if not frames:
-                    raise ValueError("inter-frame without a preceding keyframe")
+                continue
+            j = i
+            while j < len(records) and records[j][0] == INTER:
+                j += 1
+            runs.append((i - 1, i, j))
+            i = j
+        decoded = {}
+        try:
+            if self.gop_batching and runs:
+                # every run hangs off its own keyframe, so the runs are independent: they alternate over the lanes, each on its own host
+                # thread -- the inflate and upload of run r+1 under the device-side rebuild and the download of run r
+                import queue
+                lanes = self._get_lanes(min(self.gpu_lanes, len(runs)))
+                free = queue.Queue()
+                for lane in lanes:
+                    free.put(lane)
+
+                def run_job(r):
+                    k, lo, hi = runs[r]
+                    base = keys[k].result()
+                    lane = free.get()
+                    try:
+                        return self._decode_run(base, [rec for _, rec in records[lo:hi]], lane, key_pool, busy)
+                    finally:
+                        free.put(lane)
+                if len(lanes) == 1:
+                    outs = [run_job(r) for r in range(len(runs))]
+                else:
+                    with ThreadPoolExecutor(len(lanes)) as gpu_pool:
+                        outs = list(gpu_pool.map(run_job, range(len(runs))))
+                for (k, lo, hi), out in zip(runs, outs):
+                    decoded[lo] = out
+            frames = []
+            i = 0
+            while i < len(records):
+                ty, rec = records[i]
+                if ty == KEY:
+                    frames.append(keys[i].result())
+                    i += 1
+                    continue
                 j = i
                 while j < len(records) and records[j][0] == INTER:
                     j += 1
-                if self.gop_batching:
-                    frames += self._decode_run(frames[-1], [r for _, r in records[i:j]])
+                if i in decoded:
+                    frames += decoded[i]
                 else:
                     for _, r in records[i:j]:
                         base = frames[-1]
@@ -334,37 +488,54 @@ class ImprovedVideoCompressor:
                         mask, values = self.inter._decompress_frame_differences(r[1:], base.shape, dtype=dtype)
                         frames.append(self.inter._apply_frame_diff(base, mask, values))
                 i = j
-            else:
-                raise ValueError(f"unknown record type {ty}")
+        finally:
+            key_pool.shutdown(wait=True)
+            self._release_lanes()
+        tm["total"] = time.perf_counter() - t_all
+        tm["gpu_busy"] = _union_seconds(busy)
+        tm["gpu_busy_frac"] = tm["gpu_busy"] / tm["total"] if tm["total"] > 0 else 0.0
+        tm["runs"], tm["lanes"] = len(runs), min(self.gpu_lanes, max(1, len(runs)))
         if output_path:
             self.save_frames_as_video(frames, output_path)
         if self.verbose:
             print(f"Decompressed {len(frames)} frames in {time.time() - start:.2f} seconds")
         return frames
 
-    def _decode_run(self, base, recs):
+    def _decode_run(self, base, recs, lane=None, pool=None, busy=None):
         """A run of inter-frame records after `base`: the masks of all Bloom-coded frames are decoded in
         ONE rbf_bloom_decode_batch, the changed values are inflated in threads, and the frames are
-        rebuilt in sequence on the device (engine.apply_chain)."""
+        rebuilt in sequence on the device (engine.apply_chain).  lane: the context to use (default: lane 0);
+        pool: executor for the inflates (default: a temporary one)."""
         from .engine import apply_chain
-        inter = self.inter
+        if lane is None:
+            lane = self._get_lanes(1)[0]
+        t0 = time.perf_counter()
         base_arr = frame_data(base)
         n = base_arr.shape[0] * base_arr.shape[1]
         parsed = []
         for r in recs:
-            d = inter._parse_record(r[1:])
+            d = parse_record("f64", r[1:])
             if d["n"] != n:
                 raise ValueError("inter-frame record of %d pixels after a frame of %d" % (d["n"], n))
             d["dtype"] = np.uint8 if r[0] == 1 else np.uint16
             parsed.append(d)
+        inflate = lambda d: np.frombuffer(zlib.decompress(d["values_z"]), dtype=d["dtype"])[:d["value_count"]]
+        own_pool = None
+        if pool is None:
+            pool = own_pool = ThreadPoolExecutor(self.num_threads)
+        val_jobs = [pool.submit(inflate, d) for d in parsed]                 # (run under the mask decode below)
+        t1 = time.perf_counter()
         coded = [d for d in parsed if d["witness_bits"] > 0]
         if coded:
             plist = [P.filter_params(d["k"], d["bitmap_bits"]) for d in coded]
-            masks = inter._engine.decode(n, plist, [d["bitmap"] for d in coded], [d["witness"] for d in coded])
+            masks = lane.decode_engine().decode(n, plist, [d["bitmap"] for d in coded], [d["witness"] for d in coded])
             for d, m in zip(coded, masks):
                 d["mask"] = m
-        with ThreadPoolExecutor(self.num_threads) as pool:
-            vals = list(pool.map(lambda d: np.frombuffer(zlib.decompress(d["values_z"]), dtype=d["dtype"])[:d["value_count"]], parsed))
+        t2 = time.perf_counter()
+        vals = [j.result() for j in val_jobs]
+        if own_pool is not None:
+            own_pool.shutdown()
+        t3 = time.perf_counter()
         masks = [d["mask"] if "mask" in d else d["bitmap"][:(n + 7) // 8] for d in parsed]
         ch = base_arr.shape[2] if base_arr.ndim == 3 else 1
         for i, (m, v) in enumerate(zip(masks, vals)):
@@ -373,7 +544,12 @@ class ImprovedVideoCompressor:
                 if ch == 1:
                     raise ValueError("changed_values does not match the mask")
                 masks[i], vals[i] = np.zeros((n + 7) // 8, np.uint8), v[:0]      # color: frame left untouched
-        out = apply_chain(inter._ctx, base_arr, masks, vals)
+        t4 = time.perf_counter()
+        out = apply_chain(lane.ctx, base_arr, masks, vals)
+        t5 = time.perf_counter()
+        self._tm_add(parse=t1 - t0, mask_decode=t2 - t1, inflate_wait=t3 - t2, check=t4 - t3, apply_chain=t5 - t4)
+        if busy is not None:
+            busy += [(t1, t2), (t4, t5)]
         return [YUVFrame(f) for f in out] if isinstance(base, YUVFrame) else out
 
     def verify_lossless(self, original_frames, decompressed_frames):

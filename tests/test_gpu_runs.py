@@ -210,3 +210,108 @@ def test_runs_with_per_pair_thresholds(oracle, W, H):
             assert (r["k"], r["l"]) == (k, l) and np.array_equal(np.unpackbits(r["filter"])[:l], bit_array), (f, "filter")
             assert r["witness_bits"] == w and np.array_equal(np.unpackbits(r["witness"])[:w], witness[:w]), (f, "witness")
         coder.close()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
+@pytest.mark.parametrize("pairs", [1, 2, 3, 127, 128, 129, 299], ids=lambda p: "pairs%d" % p)
+def test_mask_kernel_one_long_chunk_counts_vs_oracle(oracle, dtype, pairs):
+    """The GOP mask kernel keeps a wave's per-pair counts in ONE register (two pairs per lane, two pairs per DPP tree) and files them
+    into LDS every 128 pairs: chunks of 1, 2, 3 pairs (the unrolled loop's tails), of exactly 128, of 129 and of 299 pairs (two
+    flushes + a tail) in ONE temporal chunk (force bit 8: mask_chunks = 1), masks and counts against the oracle's A1."""
+    W, H = 64, 32                                  # two whole 1024-pixel segments: the fast kernel, two waves
+    n = W * H
+    rng = np.random.default_rng(900 + pairs)
+    frames = [rng.integers(0, 1 << (8 * np.dtype(dtype).itemsize), (H, W, 3), dtype=dtype)]
+    for i in range(pairs):
+        frames.append(next_frame(rng, frames[-1], [0.0889, 0.3, 0.0, 1.0][i % 4] if i % 7 else 0.02))
+    frames = np.stack(frames)
+    with nat.Context(0) as ctx:
+        ctx.force_generic(1 << 8)
+        coder = GopCoder(ctx, W, H, pairs + 1, sample_bytes=np.dtype(dtype).itemsize, planar_luma=True, keep_interleaved=False)
+        coder.load_frames(frames)
+        coder.encode()
+        res = coder.results()
+        for f in range(pairs):
+            want = oracle.residual_mask(np.ascontiguousarray(frames[f][..., 0]), np.ascontiguousarray(frames[f + 1][..., 0]), 0.0).reshape(-1)
+            assert np.array_equal(np.unpackbits(res[f]["mask"])[:n], want), (pairs, f)
+            assert res[f]["ones"] == int(want.sum()), (pairs, f, res[f]["ones"], int(want.sum()))
+        coder.close()
+
+
+@pytest.mark.parametrize("force", [0, 1, 8], ids=["default", "generic", "barrett"])
+@pytest.mark.parametrize("W,H", [(640, 360), (322, 181)], ids=["whole_segments", "ragged"])
+def test_outputs_do_not_depend_on_what_the_buffers_held_before(oracle, force, W, H):
+    """Nobody clears witness rows any more (k_chunk_offsets zeroes the dwords the compaction's workgroups share, the compaction writes the
+    rest) and the fast insert path never touches the filter row of a pair that is not coded: so every output buffer is filled with 0xFF
+    before rbf_encode_runs, and afterwards every coded pair's filter and witness must equal the oracle's INCLUDING the zero padding up to
+    the 64-bit word that rbf_pack_records and results() rely on; masks, counts and stats likewise.  Then the same through
+    rbf_bloom_encode_batch (BloomEngine.encode)."""
+    frames, starts = make_runs(58, W, H, [[0.0889, 0.2, 0.0889], [0.05], [0.4, 0.0889]])      # one passthrough frame (p >= P_STAR) among them
+    F, n = len(frames), W * H
+    L = nat.lib()
+    with nat.Context(0) as ctx:
+        ctx.force_generic(force)
+        coder = GopCoder(ctx, W, H, F, planar_luma=True, keep_interleaved=False, run_starts=starts)
+        coder.load_frames(frames)
+        for blk in (coder.masks, coder.filters, coder.witness, coder.stats, coder.ones):
+            nat.check(L.rbf_memset(ctx.handle, blk.ptr, 0xFF, blk.nbytes))
+        ctx.sync()
+        coder.encode()
+        ctx.sync()
+        want = [dict(zip(("mask", "ones", "k", "l", "filter", "witness"), row)) for row in oracle_gop(oracle, frames)]
+        skipped = {t - 1 for t in starts}
+        pairs = F - 1
+        masks = coder.masks.numpy(ctx)[:pairs * coder.mask_stride].reshape(pairs, coder.mask_stride)
+        filt = coder.filters.numpy(ctx)[:pairs * coder.filter_stride].reshape(pairs, coder.filter_stride)
+        wit = coder.witness.numpy(ctx)[:pairs * coder.witness_stride].reshape(pairs, coder.witness_stride)
+        stats = coder.stats.numpy(ctx)[:pairs * 8 * nat.STATS_PER_FRAME].view(np.uint64).reshape(pairs, nat.STATS_PER_FRAME)
+        ones = coder.ones.numpy(ctx)[:8 * pairs].view(np.uint64)
+        coded_masks = []
+        for f in range(pairs):
+            if f in skipped:
+                assert not masks[f].any() and ones[f] == 0 and not stats[f].any(), f
+                continue
+            w = want[f]
+            mask_row = np.zeros(coder.mask_stride, np.uint8)
+            mask_row[:(n + 7) // 8] = np.packbits(w["mask"])
+            assert np.array_equal(masks[f], mask_row), (f, "mask row incl. padding")
+            assert int(ones[f]) == int(w["mask"].sum())
+            l = w["l"]
+            assert int(coder.params[f].m) == l
+            if not l:
+                assert stats[f, 0] == 0, f
+                continue
+            fb = np.zeros((l + 63) // 64 * 8, np.uint8)
+            fb[:(l + 7) // 8] = np.packbits(w["filter"])
+            assert np.array_equal(filt[f, :len(fb)], fb), (f, "filter incl. padding to the 64-bit word")
+            wb = len(w["witness"])
+            assert int(stats[f, 0]) == wb and int(stats[f, 1]) == int(w["filter"].sum())
+            wr = np.zeros((wb + 63) // 64 * 8, np.uint8)
+            wr[:(wb + 7) // 8] = np.packbits(np.asarray(w["witness"], dtype=np.uint8))
+            assert np.array_equal(wit[f, :len(wr)], wr), (f, "witness incl. padding to the 64-bit word")
+            coded_masks.append((f, w))
+        # the packed record copies whole 64-bit words: it must not carry any of the poison
+        block = coder.pack()
+        ctx.sync()
+        rows = unpack_device_record(block.numpy(ctx), n)
+        for f, w in coded_masks:
+            assert rows[f]["witness_bits"] == len(w["witness"]) and np.array_equal(np.unpackbits(rows[f]["witness"])[:len(w["witness"])], np.asarray(w["witness"], dtype=np.uint8))
+        coder.close()
+        # ---- rbf_bloom_encode_batch on poisoned filter / witness / stats buffers
+        from new_bloom_filter_repo_amd.engine import BloomEngine
+        eng = BloomEngine(ctx)
+        sel = [w for _, w in coded_masks]
+        eng.upload_masks(np.stack([np.packbits(w["mask"]) for w in sel]), n)
+        plist = [P.filter_params(w["k"], w["l"]) for w in sel]
+        fstride = max(nat.packed_stride(p[0]) for p in plist)
+        for name, nbytes in (("filters", len(sel) * fstride), ("witness", len(sel) * nat.packed_stride(n)), ("stats", len(sel) * nat.STATS_PER_FRAME * 8)):
+            b = eng._buf(name, nbytes)
+            nat.check(L.rbf_memset(ctx.handle, b.ptr, 0xFF, b.nbytes))
+        ctx.sync()
+        got = eng.encode(n, plist)
+        for g, w in zip(got, sel):
+            assert np.array_equal(np.unpackbits(g["filter"])[:w["l"]], w["filter"]) and not (np.unpackbits(g["filter"])[w["l"]:]).any()
+            wb = len(w["witness"])
+            assert g["witness_bits"] == wb and np.array_equal(np.unpackbits(g["witness"])[:wb], np.asarray(w["witness"], dtype=np.uint8))
+            assert not np.unpackbits(g["witness"])[wb:].any()
+        eng.close()
