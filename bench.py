@@ -93,22 +93,96 @@ def parse_args():
     return ap.parse_args()
 
 
-def launch_ranks(nranks, cmd, stdout0=None):
+METRIC = "Mpixels/s Bloom insert+query, 1080p residuals"
+PHASE = {"name": "start", "t0": time.time()}
+
+
+def set_phase(name):
+    """Where this rank is (init_dist, setup, warmup, settle, timed, ...): what a failure line names, and -- under bench.py's own launcher --
+    a one-line file per rank the launcher reads when a rank dies without a word."""
+    PHASE["name"] = name
+    d = os.environ.get("RBF_BENCH_LOG_DIR")
+    if d:
+        try:
+            with open(os.path.join(d, "rank%s.phase" % os.environ.get("RANK", "0")), "w") as f:
+                f.write(name)
+        except OSError:
+            pass
+
+
+def failure_line(error, rank, phase, world, **extra):
+    """The ONE JSON line of a run that failed: the contract's keys with value null, plus `error`, `rank` (the rank that failed, or that
+    noticed) and `phase`."""
+    out = {"metric": METRIC, "value": None, "unit": "Mpixel/s", "n_gpus": world, "higher_is_better": True, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "error": str(error)[:2000], "rank": rank, "phase": phase}
+    out.update(extra)
+    return out
+
+
+def print_line(out):
+    """Rank 0's one line (result or failure); leaves a marker for bench.py's own launcher."""
+    print(json.dumps(out), flush=True)
+    d = os.environ.get("RBF_BENCH_LOG_DIR")
+    if d:
+        try:
+            open(os.path.join(d, "rank0.line_printed"), "w").close()
+        except OSError:
+            pass
+
+
+def fail(exc, code=1):
+    """Any exception on any rank ends here: traceback to stderr, rank 0 prints the failure line (a rank != 0 cannot: stdout carries ONE line,
+    rank 0's -- it exits non-zero, the launcher or rank 0's next bounded collective reports it), then the process leaves WITHOUT running
+    the distributed teardown (destroy_process_group / RCCL's atexit can wait for peers that are gone)."""
+    import traceback
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    sys.stderr.write("[bench rank %d] FAILED in phase %r after %.1f s: %s\n" % (rank, PHASE["name"], time.time() - PHASE["t0"], exc))
+    traceback.print_exception(type(exc), exc, exc.__traceback__, file=sys.stderr)
+    sys.stderr.flush()
+    if rank == 0:
+        print_line(failure_line("%s: %s" % (type(exc).__name__, exc), rank, PHASE["name"], world))
+    sys.stdout.flush()
+    os._exit(code if isinstance(code, int) and code else 1)
+
+
+def install_term_handler():
+    """A launcher that lost one rank sends the others SIGTERM (torch.distributed.run does, bench.py's own does): rank 0 still says where it was."""
+    import signal
+
+    def on_term(signum, frame):
+        fail(RuntimeError("terminated by the launcher (signal %d): another rank failed or the run was cancelled" % signum), 128 + signum)
+    try:
+        signal.signal(signal.SIGTERM, on_term)
+    except ValueError:                            # not the main thread
+        pass
+
+
+def launch_ranks(nranks, cmd, stdout0=None, log_dir=None):
     """Start `cmd` once per rank (one process per GPU: RANK = LOCAL_RANK = r, WORLD_SIZE = nranks, rendezvous on a free port of
-    127.0.0.1) and wait.  Rank 0 inherits stdout (or gets `stdout0`), so its ONE JSON line is the launcher's output; the other
-    ranks' stdout (RCCL banners) goes to stderr.  A rank that dies takes the others down (exact PIDs) and its exit code is returned."""
+    127.0.0.1) and wait.  Rank 0 inherits stdout (or gets `stdout0`), so its ONE JSON line is the launcher's output; every rank's stderr
+    (RCCL banners, tracebacks) goes to <log_dir>/rank<r>.stderr, NCCL_DEBUG defaults to WARN.  A rank that dies takes the others down
+    (SIGTERM, exact PIDs); then the launcher prints the tail of every rank's stderr, and -- if rank 0 did not get to print a line -- the
+    failure line itself: which rank went first, and the phase it was in.  Returns that rank's exit code."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:                    # a free port for the rendezvous
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    log_dir = log_dir or os.environ.get("RBF_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="rbf_bench_ranks_")
+    os.makedirs(log_dir, exist_ok=True)
+    for name in os.listdir(log_dir):
+        if name.startswith("rank"):
+            os.remove(os.path.join(log_dir, name))
+    procs, logs = [], []
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RBF_BENCH_LAUNCHER="self-spawned")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RBF_BENCH_LAUNCHER="self-spawned", RBF_BENCH_LOG_DIR=log_dir)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen(cmd, env=env, stdout=stdout0 if r == 0 else sys.stderr))
-    rc = 0
+        env.setdefault("NCCL_DEBUG", "WARN")
+        logs.append(open(os.path.join(log_dir, "rank%d.stderr" % r), "wb"))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=stdout0 if r == 0 else logs[r], stderr=logs[r]))
+    rc, first_failed = 0, None
     alive = list(procs)
     while alive:
         for p in list(alive):
@@ -117,10 +191,33 @@ def launch_ranks(nranks, cmd, stdout0=None):
                 continue
             alive.remove(p)
             if code != 0 and rc == 0:
-                rc = code
-                for q in alive:                    # one rank failed: the others would wait in a collective for ever
+                rc, first_failed = code, procs.index(p)
+                for q in alive:                    # one rank failed: the others would wait in a collective until their bound runs out
                     q.terminate()
         time.sleep(0.05)
+    for f in logs:
+        f.close()
+    if rc != 0:
+        for r in range(nranks):
+            try:
+                with open(os.path.join(log_dir, "rank%d.stderr" % r), "rb") as f:
+                    tail = f.read()[-3000:].decode("utf-8", "replace")
+            except OSError:
+                tail = ""
+            sys.stderr.write("---- rank %d stderr (tail; whole file: %s) ----\n%s\n" % (r, os.path.join(log_dir, "rank%d.stderr" % r), tail))
+        if not os.path.exists(os.path.join(log_dir, "rank0.line_printed")):
+            try:
+                with open(os.path.join(log_dir, "rank%d.phase" % first_failed)) as f:
+                    phase = f.read().strip()
+            except OSError:
+                phase = "start"
+            line = json.dumps(failure_line("rank %d exited with code %d (its stderr: %s)" % (first_failed, rc, os.path.join(log_dir, "rank%d.stderr" % first_failed)),
+                                           first_failed, phase, nranks, launcher="bench.py"))
+            dest = stdout0 or sys.stdout
+            dest.write((line + "\n").encode() if "b" in getattr(dest, "mode", "") else line + "\n")
+            dest.flush()
+    else:
+        sys.stderr.write("[bench launcher] %d ranks finished; per-rank stderr in %s\n" % (nranks, log_dir))
     return rc
 
 
@@ -129,9 +226,27 @@ def spawn_ranks(args):
     sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
 
+def all_reduce_b(dist, t, op=None, what="all_reduce"):
+    """dist.all_reduce whose result the host may read afterwards: issued async, polled against dist.DEFAULT_TIMEOUT_S (a dead peer raises
+    CollectiveTimeout here instead of parking this rank in `.item()` until the watchdog kills it)."""
+    from new_bloom_filter_repo_amd.dist import wait_work
+    wait_work(dist.all_reduce(t, async_op=True) if op is None else dist.all_reduce(t, op=op, async_op=True), "%s (phase %s)" % (what, PHASE["name"]))
+
+
+def bounded_barrier(dist, device, what="barrier"):
+    """dist.barrier() that cannot outlive a dead peer: an async all_reduce of one word, polled against dist.DEFAULT_TIMEOUT_S."""
+    import torch
+    from new_bloom_filter_repo_amd.dist import wait_work
+    t = torch.zeros(1, dtype=torch.int32, device=COMM_DEVICE)
+    wait_work(dist.all_reduce(t, async_op=True), "%s (phase %s)" % (what, PHASE["name"]))
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
 def init_dist(args):
     import torch
     import torch.distributed as dist
+    set_phase("init_dist")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -157,20 +272,22 @@ def init_dist(args):
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         COMM_DEVICE = torch.device("cpu")         # control values (timings, counts) and record payloads travel through host memory
         ones = torch.ones(1, dtype=torch.int64)
-        dist.all_reduce(ones)
+        all_reduce_b(dist, ones)
         if int(ones.item()) != world:
             raise SystemExit("gloo saw %d ranks, expected %d" % (int(ones.item()), world))
     elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        import datetime
+        # (the watchdog's bound on a collective that never completes; the gathers' own host-side waits are bounded much tighter: dist.DEFAULT_TIMEOUT_S)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=600))
         # Finish RCCL's own setup (its streams, channels, proxy threads) with one collective BEFORE the
         # GOP pipelines' streams exist.  Measured (tools/dist_overhead.py): streams created between an
         # eager communicator init and its first collective end up serialised with each other
         # (260 instead of 222 us/step); created after it, or before a lazy init, they overlap.
         # ... and that collective counts the ranks RCCL really connected (reported as `rccl_ranks`)
         ones = torch.ones(1, dtype=torch.int64, device=device)
-        dist.all_reduce(ones)
+        all_reduce_b(dist, ones)
         torch.cuda.synchronize(device)
         if int(ones.item()) != world:
             raise SystemExit("RCCL saw %d ranks, expected %d" % (int(ones.item()), world))
@@ -181,11 +298,22 @@ def main():
     args = parse_args()
     if (args.gpus > 1 or args.spawn) and "RANK" not in os.environ:
         return spawn_ranks(args)
-    if args.clip_frames:
-        return clip_main(args)
+    install_term_handler()
+    try:
+        return clip_main(args) if args.clip_frames else bench_main(args)
+    except SystemExit as e:
+        if e.code in (0, None):
+            raise
+        fail(e, e.code if isinstance(e.code, int) else 1)
+    except BaseException as e:                     # (KeyboardInterrupt included: the line still says where)
+        fail(e)
+
+
+def bench_main(args):
     import torch
     import torch.distributed as dist
     world, rank, local_rank, device, use_dist = init_dist(args)
+    set_phase("setup")
     ncoders = max(1, args.streams)
     streams = [torch.cuda.Stream(device) for _ in range(ncoders)]      # none of them is the null stream
 
@@ -322,7 +450,7 @@ def main():
 
     def barrier():
         if use_dist:
-            dist.barrier()
+            bounded_barrier(dist, device)
         torch.cuda.synchronize(device)
 
     # setup (not warm-up steps): every pipeline sizes its scratch once, and for N > 1 the ranks agree on the slot
@@ -339,6 +467,7 @@ def main():
         run_steps(2 * G)                          # untimed: the first RCCL transfer of both outboxes (connection setup)
         drain()
         state["s"] = 0
+    set_phase("warmup")
     run_steps(args.warmup)
     drain()
     torch.cuda.synchronize(device)
@@ -368,7 +497,7 @@ def main():
                     kt[name] = (a[0] + ms, a[1] + cnt)
         if use_dist:
             te = torch.tensor([elapsed], dtype=torch.float64, device=COMM_DEVICE)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            all_reduce_b(dist, te, dist.ReduceOp.MAX)
             elapsed = float(te.item())
         return elapsed, kt
 
@@ -376,6 +505,7 @@ def main():
     # steady state (clocks, caches, the pipelines' queues), so windows of --steps steps are run until two consecutive ones agree within
     # 2 % -- or 30 ms have gone by.  What is then timed is what a warm service does.
     settle = {"windows": 0, "ms": 0.0}
+    set_phase("settle")
     if not args.exact_steps:
         prev, spent = None, 0.0
         while settle["windows"] < 200:
@@ -386,7 +516,7 @@ def main():
             done = spent >= 0.100 or (agree and spent >= 0.030)     # two windows within 2 % of each other and >= 30 ms behind us, or 100 ms at most
             if use_dist:                          # every rank must leave the loop in the same round
                 flag = torch.tensor([1 if done else 0], dtype=torch.int64, device=COMM_DEVICE)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                all_reduce_b(dist, flag, dist.ReduceOp.MIN)
                 done = bool(flag.item())
             prev = e
             if done:
@@ -396,6 +526,7 @@ def main():
     # is timed `REGIONS` times and the MEDIAN region is the headline (`steps` = --steps); all of them are reported.  One long region
     # (>= MIN_REGION_S) follows as `steady_state`: what the pipelines sustain without the fill and drain of a short region.
     REGIONS = 1 if args.exact_steps else 9
+    set_phase("timed")
     regions = [timed(args.steps, False) for _ in range(REGIONS)]      # (no HIP events inside the headline's regions)
     order = sorted(range(REGIONS), key=lambda i: regions[i][0])
     elapsed = regions[order[REGIONS // 2]][0]
@@ -408,7 +539,7 @@ def main():
         nlong = int(MIN_REGION_S * 1.25 / (elapsed / args.steps)) + 1
         if use_dist:                               # every rank must run the same number of steps
             tl = torch.tensor([nlong], dtype=torch.int64, device=COMM_DEVICE)
-            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            all_reduce_b(dist, tl, dist.ReduceOp.MAX)
             nlong = int(tl.item())
         e_long, _ = timed(nlong, False)
         steady = {"steps": nlong, "ms_per_step": round(e_long / nlong * 1e3, 4), "region_ms": round(e_long * 1e3, 2),
@@ -416,6 +547,7 @@ def main():
                   "note": "one long region: no fill / drain of the pipelines inside it; the headline is the median %d-step region" % args.steps}
 
     # per-kernel figures with the chip to itself: one pipeline, every kernel bracketed, ALONE_LAUNCHES steps
+    set_phase("kernel_timing")
     breakdown = None
     if not args.no_kernel_timing:
         torch.cuda.synchronize(device)
@@ -431,6 +563,7 @@ def main():
         breakdown = {k: round(v[0] / ALONE_LAUNCHES, 4) for k, v in ctx.timing_read().items() if v[1]}    # ms per step (a kernel launched in groups counts whole)
 
     # every resident GOP of every pipeline once more, for the oracle comparison: [(host frames, rows)]
+    set_phase("verify")
     checked = []
     for g in range(G_res):
         for k in range(1 if args.shared_gop else ncoders):
@@ -443,7 +576,7 @@ def main():
     value = pixels_per_step * steps_timed / elapsed / 1e6
 
     out = {
-        "metric": "Mpixels/s Bloom insert+query, 1080p residuals",
+        "metric": METRIC,
         "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": steps_timed, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps_timed * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -476,6 +609,18 @@ def main():
                    "ranks_share_one_device": bool(args.one_device),
                    "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by world-2 / world-8 runs of the real kernels on ONE device over gloo (tests/test_gpu_dist_shared.py), gloo world-2/3 CPU tests (incl. the self-spawn launcher) and RCCL world-1 tests"},
     }
+    if use_dist:
+        # who ran where, and what crossed the links: every rank's device, and the bytes the non-root ranks sent into rank 0 per step
+        # (exact-size records: over xGMI on a node, one link per peer)
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "device": "cuda:%d" % local_rank, "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "bytes_sent_to_rank0": int(og.bytes_sent) if og is not None else 0, "steps_gathered": int(og.s) if og is not None else 0}
+        infos = [None] * world
+        dist.all_gather_object(infos, mine)
+        out["config"]["ranks"] = infos
+        sent, steps_g = sum(i["bytes_sent_to_rank0"] for i in infos), max(i["steps_gathered"] for i in infos)
+        out["config"]["xgmi_bytes_per_step_into_rank0"] = round(sent / steps_g, 1) if steps_g else 0
+        out["config"]["collective_timeout_s"] = __import__("new_bloom_filter_repo_amd.dist", fromlist=["x"]).DEFAULT_TIMEOUT_S
     if rank == 0 and gather:
         out["config"]["gathered_records_parsed_on_rank0"] = check_gathered(og, world, G, pairs, n, res_all)
     if rank == 0:
@@ -540,6 +685,7 @@ def main():
     # ---- BASELINE configs[2] and [4] in the same process group: one 300-frame clip sharded by frame (strong scaling), 8- and 16-bit
     if og is not None:
         og.close()
+    set_phase("clips")
     if not args.no_clips:
         for c in coders:
             if c is not None:
@@ -560,11 +706,12 @@ def main():
             out["clip300"], out["clip300_uint16"] = c8, c16
             if proxy:
                 out["shard_proxy"] = sp
+    set_phase("shutdown")
     if use_dist:
-        dist.barrier()
+        bounded_barrier(dist, device, "final barrier")
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)        # the last thing on stdout (RCCL prints its own lines while it is alive)
+        print_line(out)                           # the last thing on stdout (RCCL prints its own lines while it is alive)
 
 
 def e2e_surface_leg(nat, local_rank, W, H, density, T=300, I=30, block_frames=None, gpu_lanes=2, profile_stages=False):
@@ -1166,7 +1313,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
 
     def barrier():
         if use_dist:
-            dist.barrier()
+            bounded_barrier(dist, device)
         torch.cuda.synchronize(device)
 
     def timed(gather):
@@ -1188,7 +1335,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
             done = spent >= 0.030
             if use_dist:
                 flag = torch.tensor([1 if done else 0], dtype=torch.int64, device=COMM_DEVICE)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                all_reduce_b(dist, flag, dist.ReduceOp.MIN)
                 done = bool(flag.item())
             if done:
                 break
@@ -1202,7 +1349,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
         elapsed = time.perf_counter() - t0
         if use_dist:
             te = torch.tensor([elapsed], dtype=torch.float64, device=COMM_DEVICE)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            all_reduce_b(dist, te, dist.ReduceOp.MAX)
             elapsed = float(te.item())
         return elapsed, got
 
@@ -1235,7 +1382,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
         res_all = res_sets[0] if nsets else []
         cnt_t = torch.tensor([frames_ok], dtype=torch.int64, device=COMM_DEVICE)
         if use_dist:
-            dist.all_reduce(cnt_t)
+            all_reduce_b(dist, cnt_t)
         want = total_pairs if proxy is None else my_pairs
         verified = {"frames": int(cnt_t.item()), "of": want, "pass_slots_checked": nsets,
                     "fields": "mask, k, l, filter, witness" + ("; frames arrive on rank 0 in clip order" if proxy is None else "; the packed record parses to the same rows")}
@@ -1372,20 +1519,22 @@ def clip_main(args):
         print(json.dumps({"metric": "one rank's share of the clip (shard proxy)", "proxy_world": parts[0], "slowest": slow,
                           "ms_per_pass_per_rank": [x["ms_per_pass"] for x in rows], "pass_latency_ms_per_rank": [x["pass_latency_ms"] for x in rows]}), flush=True)
         return
+    set_phase("clip")
     r = run_clip(args, env, args.clip_frames, args.keyframe_interval, args.bits, args.steps, args.warmup)
+    set_phase("shutdown")
     if use_dist:
-        dist.barrier()
+        bounded_barrier(dist, env[3], "final barrier")
         dist.destroy_process_group()
     if rank == 0:
-        out = {"metric": "Mpixels/s Bloom insert+query, 1080p residuals", "value": r["value"], "unit": "Mpixel/s", "n_gpus": world,
+        out = {"metric": METRIC, "value": r["value"], "unit": "Mpixel/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_pass"], "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-               "config": {"workload": r["workload"], "sharding": r["sharding"], "inter_frames_rank0": r["inter_frames_rank0"],
+               "config": {"workload": r["workload"], "sharding": r["sharding"], "inter_frames_rank0": r["inter_frames_rank0"], "pass_slots": r.get("pass_slots"), "pass_latency_ms": r.get("pass_latency_ms"),
                           "gather_to_rank0": r["gather_to_rank0"], "without_gather": r["without_gather"],
                           "gather": "exact-size: all_gather of lengths + error flag, then grouped send/recv of payloads; rank 0's own records are not sent",
                           "launcher": os.environ.get("RBF_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process"), "rccl_ranks": world if use_dist else 0},
                "verified_vs_oracle": r["verified_vs_oracle"]}
-        print(json.dumps(out), flush=True)
+        print_line(out)
 
 
 if __name__ == "__main__":

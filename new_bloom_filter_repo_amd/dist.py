@@ -8,9 +8,56 @@ which writes the container.  RCCL has no gatherv, so lengths are all-gathered fi
 travel as grouped point-to-point messages of exactly their used size (xGMI gives every peer its own link into
 rank 0); rank 0's own records never enter a collective.
 """
+import os
 import struct
+import time
 
 import numpy as np
+
+# Every host-side wait of the gathers is BOUNDED: a peer that died (or a link that does not come up) must surface as an exception on the
+# survivors -- with the phase and the ranks that did not answer -- not as a process that sits in a collective until somebody kills it.
+# RCCL enqueues its collectives on its own stream and returns; what blocks the host is the read of the result (`.cpu()`), so every
+# exchange is issued async_op=True and polled (`is_completed`) against this deadline before anything is read.  gloo blocks inside the
+# call and has its own process-group timeout; polling the async work bounds it the same way.
+DEFAULT_TIMEOUT_S = float(os.environ.get("RBF_DIST_TIMEOUT_S", "120"))
+
+
+class CollectiveTimeout(RuntimeError):
+    """A collective or point-to-point exchange did not complete within the bound (see DEFAULT_TIMEOUT_S / RBF_DIST_TIMEOUT_S)."""
+
+
+def wait_work(works, what, timeout_s=None, group=None):
+    """Host-side bounded wait for async collectives / grouped point-to-point works; re-raises what the backend recorded.
+    RCCL ("nccl"): the work is polled (`is_completed` queries its end event; the first millisecond is a plain spin, so a barrier inside a
+    timed region costs what dist.barrier() costs).  gloo: `wait(timeout)` -- gloo's send / receive works only complete inside wait()."""
+    import datetime
+    import torch.distributed as dist
+    bound = DEFAULT_TIMEOUT_S if timeout_s is None else timeout_s
+    t0 = time.monotonic()
+    deadline = t0 + bound
+    polled = dist.get_backend(group) == "nccl"
+    pause = 50e-6
+    for w in ([works] if not isinstance(works, (list, tuple)) else works):
+        if w is None:
+            continue
+        if not polled:
+            left = max(0.05, deadline - time.monotonic())
+            try:
+                if w.wait(datetime.timedelta(seconds=left)) is False:
+                    raise CollectiveTimeout("%s did not complete within %.0f s: a peer is gone or never arrived" % (what, bound))
+            except RuntimeError as e:
+                if "imeout" in str(e) or "imed out" in str(e):
+                    raise CollectiveTimeout("%s did not complete within %.0f s: a peer is gone or never arrived (%s)" % (what, bound, str(e)[:200])) from e
+                raise
+            continue
+        while not w.is_completed():
+            now = time.monotonic()
+            if now > deadline:
+                raise CollectiveTimeout("%s did not complete within %.0f s: a peer is gone or never arrived" % (what, bound))
+            if now - t0 > 1e-3:
+                time.sleep(pause)
+                pause = min(pause * 2, 2e-3)
+        w.wait()                                   # completed: a stream-side wait under RCCL, and the place where a backend error surfaces
 
 
 def shard_range(nframes, world, rank):
@@ -111,10 +158,11 @@ class OutboxGather:
         og.received(ob, rank)   # on dst: the records last received from `rank` in outbox `ob` (list of uint8 tensors)
     """
 
-    def __init__(self, slot_words, steps_per_gather, device, streams=None, group=None, dst=0, threaded=None):
+    def __init__(self, slot_words, steps_per_gather, device, streams=None, group=None, dst=0, threaded=None, timeout_s=None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist, self.group, self.dst = torch, dist, group, dst
+        self.timeout_s = timeout_s                 # bound of every host-side wait (None: DEFAULT_TIMEOUT_S)
         self.G, self.slot_words = max(1, int(steps_per_gather)), int(slot_words)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.cuda = device.type == "cuda"
@@ -173,8 +221,8 @@ class OutboxGather:
     def _settle(self, ob):
         """Wait (host) until outbox ob's last exchange has been posted; re-raise what the helper thread caught."""
         ev = self._posted[ob]
-        if ev is not None:
-            ev.wait()
+        if ev is not None and not ev.wait(2 * (DEFAULT_TIMEOUT_S if self.timeout_s is None else self.timeout_s) + 5):
+            raise CollectiveTimeout("OutboxGather: the helper thread did not post the exchange of outbox %d" % ob)
         if self.error is not None:
             raise self.error
 
@@ -188,8 +236,7 @@ class OutboxGather:
         self._settle(ob)
         if self.pend[ob] is not None:
             works, _keep, ev = self.pend[ob]
-            for w in works:
-                w.wait()
+            wait_work(works, "OutboxGather: payload exchange of outbox %d" % ob, self.timeout_s, self.group)
             if ev is not None:
                 self._torch.cuda.current_stream(self.device).wait_event(ev)
             self.pend[ob] = None
@@ -245,7 +292,7 @@ class OutboxGather:
         mine[:count] = torch.tensor(used, dtype=torch.int64, device=self.device)
         mine[self.G] = flag
         sizes = [torch.zeros(self.G + 1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
-        dist.all_gather(sizes, mine, group=self.group)
+        wait_work(dist.all_gather(sizes, mine, group=self.group, async_op=True), "OutboxGather: all_gather of the used sizes (exchange %d)" % self.sent, self.timeout_s, self.group)
         sizes = [[int(x) for x in t.cpu().tolist()] for t in sizes]
         if local is not None:
             raise local                                         # after the collective: the peers have seen the flag
@@ -311,7 +358,13 @@ class OutboxGather:
         for ob in range(2):
             self._wait(ob)
         if self.cuda:
-            self.comm.synchronize()
+            done = self._torch.cuda.Event()
+            done.record(self.comm)
+            deadline = time.monotonic() + (DEFAULT_TIMEOUT_S if self.timeout_s is None else self.timeout_s)
+            while not done.query():
+                if time.monotonic() > deadline:
+                    raise CollectiveTimeout("OutboxGather.flush: the communication stream did not drain")
+                time.sleep(1e-4)
         if self.error is not None:
             raise self.error
 
@@ -329,7 +382,7 @@ class OutboxGather:
         return out
 
 
-def gather_records(records, dst=0, group=None, device=None):
+def gather_records(records, dst=0, group=None, device=None, timeout_s=None):
     """Gather every rank's [(frame_index, type, bytes)] to `dst`; returns the merged list sorted by
     frame index on dst, None elsewhere.  Works on any backend (tensors live on `device`).  Exact sizes, like
     gather_device_records: the lengths are all-gathered, then every rank but `dst` sends its bytes as one point-to-point
@@ -345,7 +398,7 @@ def gather_records(records, dst=0, group=None, device=None):
     payload = torch.from_numpy(packed).to(device)
     length = torch.tensor([payload.numel()], dtype=torch.int64, device=device)
     lengths = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(lengths, length, group=group)
+    wait_work(dist.all_gather(lengths, length, group=group, async_op=True), "gather_records: all_gather of the record lengths", timeout_s, group)
     lengths = [int(x.item()) for x in lengths]
     ops, inbox = [], {}
     if rank == dst:
@@ -356,8 +409,7 @@ def gather_records(records, dst=0, group=None, device=None):
     else:
         ops.append(dist.P2POp(dist.isend, payload, peer(dst), group))
     if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        wait_work(dist.batch_isend_irecv(ops), "gather_records: payload exchange with rank %d" % dst, timeout_s, group)
     if rank != dst:
         return None
     merged = []
@@ -367,7 +419,7 @@ def gather_records(records, dst=0, group=None, device=None):
     return merged
 
 
-def gather_device_records(records, device, dst=0, group=None, max_records=None):
+def gather_device_records(records, device, dst=0, group=None, max_records=None, timeout_s=None):
     """Exact-size gather of device-packed records (GopCoder.pack) to `dst`, RCCL has no gatherv:
     every rank reads the used size of its records from their headers (one small D2H), the sizes are
     all-gathered, then every rank but `dst` sends the used bytes of its records as ONE message and `dst`
@@ -393,7 +445,7 @@ def gather_device_records(records, device, dst=0, group=None, max_records=None):
         used = []
     if max_records is None:                                        # callers that know the largest record count of any rank skip this round
         maxrec = torch.tensor([len(used)], dtype=torch.int64, device=device)
-        dist.all_reduce(maxrec, op=dist.ReduceOp.MAX, group=group)
+        wait_work(dist.all_reduce(maxrec, op=dist.ReduceOp.MAX, group=group, async_op=True), "gather_device_records: all_reduce of the record counts", timeout_s, group)
         max_records = int(maxrec.item())
     if len(used) > max_records:
         raise ValueError("%d records, but max_records = %d" % (len(used), max_records))
@@ -402,7 +454,7 @@ def gather_device_records(records, device, dst=0, group=None, max_records=None):
         mine[:len(used)] = torch.tensor(used, dtype=torch.int64, device=device)
     mine[max_records] = damaged                                   # sizes + error flag in ONE collective: nobody is left hanging
     sizes = [torch.zeros(max_records + 1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, mine, group=group)
+    wait_work(dist.all_gather(sizes, mine, group=group, async_op=True), "gather_device_records: all_gather of the record sizes", timeout_s, group)
     sizes = [[int(x) for x in s.cpu().tolist()] for s in sizes]
     bad = [r for r in range(world) if sizes[r][max_records]]
     if bad:
@@ -418,9 +470,9 @@ def gather_device_records(records, device, dst=0, group=None, max_records=None):
     elif used:
         payload = torch.cat(own).to(device)
         ops.append(dist.P2POp(dist.isend, payload, peer(dst), group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    if ops:                                                        # (bounded: what arrives is read by the caller right away)
+        wait_work(dist.batch_isend_irecv(ops), "gather_device_records: payload exchange with rank %d (peers with data: %s)"
+                  % (dst, [r for r in range(world) if r != dst and sum(sizes[r])]), timeout_s, group)
     if rank != dst:
         return None
     out = []
@@ -446,7 +498,10 @@ def encode_video_sharded(frames, first_index, nframes_total, keyframe_interval=3
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     start, stop = shard_range(nframes_total, world, rank)
     comp = ImprovedVideoCompressor(keyframe_interval=keyframe_interval, ctx=ctx)
-    coded = comp.encode_range(frames, first_index, start, stop)          # one GOP pass per run of inter-frames
+    try:
+        coded = comp.encode_range(frames, first_index, start, stop)      # blocks of two keyframe intervals over two GPU lanes; the lanes' memory is released inside
+    finally:
+        comp.close()
     records = [(start + i, ty, rec) for i, (ty, rec) in enumerate(coded)]
     merged = gather_records(records, dst=dst, group=group)
     if merged is None:

@@ -28,6 +28,15 @@ KEY, INTER = 1, 2
 _POPCOUNT8 = np.unpackbits(np.arange(256, dtype=np.uint8)[:, None], axis=1).sum(axis=1).astype(np.uint8)   # numpy 1.x has no bitwise_count
 
 
+def _popcount(packed):
+    """Set bits of a packed uint8 vector."""
+    if hasattr(np, "bitwise_count"):             # numpy >= 2: whole 64-bit words
+        body = packed[:packed.size // 8 * 8]
+        words = body.view(np.uint64) if body.ctypes.data % 8 == 0 else np.frombuffer(body.tobytes(), dtype=np.uint64)
+        return int(np.bitwise_count(words).sum(dtype=np.int64)) + int(np.bitwise_count(packed[body.size:]).sum(dtype=np.int64))
+    return int(_POPCOUNT8[packed].sum(dtype=np.int64))
+
+
 def _as_block(data):
     """The frames of a block as ONE contiguous (F, H, W[, C]) array for the upload: a zero-copy view when the caller's frames already lie
     back to back in memory (slices of one decoded clip), a stacked copy otherwise."""
@@ -264,13 +273,14 @@ class ImprovedVideoCompressor:
             out.append(pool.submit(job))
         return out
 
-    def encode_range(self, frames, first_index, start, stop, inter_frames=True):
+    def encode_range(self, frames, first_index, start, stop, inter_frames=True, release=True):
         """[(type, record)] for the frames with global indices [start, stop); frames[i] is global frame
         first_index + i (a shard passes its halo frame too, dist.halo_start).  Frame t is a keyframe iff
         t % keyframe_interval == 0; the inter-frames are coded in blocks of up to `block_frames` consecutive frames --
         several GOPs per block, ONE launch sequence on the GPU per block, cut at the keyframes.  The blocks alternate over
         `gpu_lanes` contexts, each block on its own host thread; the host's zlib-9 (keyframes: four jobs each; changed values:
-        one job per frame) runs on `num_threads` threads under all of it."""
+        one job per frame) runs on `num_threads` threads under all of it.  release: return the lanes' device memory as soon as the last
+        block has left the GPU (False: keep the coders for the next call of the same geometry)."""
         records = {}
         I = self.keyframe_interval
         self.last_timing = tm = {}
@@ -317,6 +327,10 @@ class ImprovedVideoCompressor:
                     with ThreadPoolExecutor(len(lanes)) as gpu_pool:
                         results = list(gpu_pool.map(run_block, range(len(blocks))))
             tm["gpu_phase"] = time.perf_counter() - t_all                    # until the last block's values were on the host
+            if release:                                                      # the lanes' blocks of frames, masks, filters and witnesses go back while the
+                t_rel = time.perf_counter()                                  # host threads still owe their zlib: not kept between videos
+                self._release_lanes()
+                tm["release"] = time.perf_counter() - t_rel
             for (lo, end, starts), inter in zip(blocks, results):
                 seg = frames[lo - first_index:end - first_index]             # predecessor + the frames lo+1..end-1
                 for j in range(1, len(seg)):
@@ -362,15 +376,17 @@ class ImprovedVideoCompressor:
         try:
             records = self.encode_range(frames, 0, 0, len(frames), inter_frames=use_inter)
         finally:
-            self._release_lanes()                # blocks of frames, masks, filters and witnesses: do not keep them between videos
+            self._release_lanes()                # (an exception in front of encode_range's own release)
         self.last_compressed_frames = records
         keyframes = sum(1 for ty, _ in records if ty == KEY)
-        blob = self._container(records)
         if output_path:
+            blob = self._container(records)
             os.makedirs(os.path.dirname(os.path.abspath(output_path)), exist_ok=True)
             with open(output_path, "wb") as f:
                 f.write(blob)
-        compressed_size = len(blob)
+            compressed_size = len(blob)
+        else:                                    # the container's size without joining ~1 MB per frame into one bytes object nobody asked for
+            compressed_size = self._container_size(records)
         ratio = compressed_size / original_size
         elapsed = time.time() - start
         results = {"frame_count": len(frames), "original_size": original_size, "compressed_size": compressed_size,
@@ -394,6 +410,12 @@ class ImprovedVideoCompressor:
             body = rec if all_key else struct.pack("<B", ty) + rec
             out += [struct.pack("<I", len(body)), body]
         return b"".join(out)
+
+    @staticmethod
+    def _container_size(records):
+        """len(_container(records)) without building it."""
+        extra = 0 if all(ty == KEY for ty, _ in records) else 1
+        return 8 + sum(4 + extra + len(rec) for _, rec in records)
 
     # ------------------------------------------------------------------ decode
     @staticmethod
@@ -539,7 +561,7 @@ class ImprovedVideoCompressor:
         masks = [d["mask"] if "mask" in d else d["bitmap"][:(n + 7) // 8] for d in parsed]
         ch = base_arr.shape[2] if base_arr.ndim == 3 else 1
         for i, (m, v) in enumerate(zip(masks, vals)):
-            ones = int(_POPCOUNT8[np.asarray(m, dtype=np.uint8)[:(n + 7) // 8]].sum(dtype=np.int64))
+            ones = _popcount(np.asarray(m, dtype=np.uint8)[:(n + 7) // 8])
             if len(v) != ones * ch:              # same rule as _apply_frame_diff (:886-903)
                 if ch == 1:
                     raise ValueError("changed_values does not match the mask")

@@ -388,3 +388,126 @@ def test_bench_gpus_without_launcher_goes_through_the_spawner(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 0 and seen["n"] == 2 and seen["cmd"][1].endswith("bench.py") and seen["cmd"][2:] == ["--gpus", "2", "--steps", "3"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A peer that dies: every host-side wait of the gathers is bounded, the survivor raises (no hang), and the run still ends in ONE JSON line
+# with `error`, `rank` and `phase` -- from rank 0 when it lives to print it, from bench.py's launcher otherwise.
+# ---------------------------------------------------------------------------------------------------------------
+def _dead_peer_worker(rank, world, port, q, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, REPO)
+    import datetime
+    import time
+    import torch
+    import torch.distributed as dist
+    from new_bloom_filter_repo_amd import dist as DD
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    recs = [torch.from_numpy(_fake_record(2, 7 + rank, 1000 * rank))]
+    t0 = time.time()
+    try:
+        if mode == "device_records":
+            DD.gather_device_records(recs, torch.device("cpu"), timeout_s=8)          # round 1: everybody is there
+            if rank == 1:
+                os._exit(7)                                                           # killed between two gathers: rank 0 is already in the next one
+            DD.gather_device_records(recs, torch.device("cpu"), timeout_s=8)
+        else:
+            og = DD.OutboxGather(400, 2, torch.device("cpu"), threaded=True, timeout_s=8)
+            for s in range(8):
+                if rank == 1 and s == 4:
+                    os._exit(7)                                                       # mid-sequence: two exchanges done, the third never gets its peer
+                slot = og.begin(0)
+                rec = torch.from_numpy(_fake_record(1, 3 + s, 1000 * s))
+                slot.zero_()
+                slot[:rec.numel()] = rec
+                og.end(0)
+            og.flush()
+        q.put((rank, None, time.time() - t0))
+    except (DD.CollectiveTimeout, RuntimeError, ValueError) as e:
+        q.put((rank, type(e).__name__ + ": " + str(e)[:300], time.time() - t0))
+    q.close()
+    q.join_thread()                                                                   # (the queue's feeder thread must have written before the process leaves)
+    os._exit(0)                                                                       # (no destroy_process_group: it can wait for the dead peer)
+
+
+@pytest.mark.parametrize("mode", ["device_records", "outbox"])
+def test_a_rank_killed_mid_gather_raises_on_the_survivor_and_does_not_hang(mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() * 5 + (1 if mode == "outbox" else 0)) % 2000
+    procs = [ctx.Process(target=_dead_peer_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rank, raised, took = q.get(timeout=90)                       # only rank 0 reports
+    for p in procs:
+        p.join(timeout=60)
+    assert rank == 0 and raised is not None, "the survivor did not notice its dead peer"
+    assert took < 45, took
+    assert procs[1].exitcode == 7
+
+
+FAIL_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(repo)r)
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench_w", os.path.join(%(repo)r, "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode = sys.argv[1]
+bench.set_phase("init_dist")
+import datetime, torch, torch.distributed as dist
+dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+bench.COMM_DEVICE = torch.device("cpu")
+if mode == "handler" or rank == 0 and mode == "raise":
+    bench.install_term_handler()
+try:
+    bench.set_phase("setup")
+    bench.bounded_barrier(dist, None)
+    bench.set_phase("timed")
+    if rank == 1:
+        if mode == "raise":
+            raise ValueError("simulated failure of rank 1")
+        os._exit(9)                                   # killed: no goodbye
+    if mode == "silent0":
+        time.sleep(120)                               # rank 0 sits in something that cannot print (the launcher has to speak)
+    from new_bloom_filter_repo_amd import dist as DD
+    DD.DEFAULT_TIMEOUT_S = 20.0
+    bench.bounded_barrier(dist, None)                 # rank 0 waits for a peer that is gone
+    bench.print_line({"value": 1})
+except SystemExit:
+    raise
+except BaseException as e:
+    bench.fail(e)
+'''
+
+
+@pytest.mark.parametrize("mode", ["handler", "silent0", "raise"])
+def test_a_failed_rank_still_ends_in_one_json_error_line(tmp_path, mode):
+    """bench.py's launcher + failure path with gloo stand-ins for the ranks: rank 1 dies (killed, or by an exception) while rank 0 waits
+    in a bounded barrier.  `handler`: rank 0 is told (SIGTERM from the launcher, or its barrier notices first) and prints the line itself, with
+    its phase; `silent0`: rank 0 cannot speak -- the launcher prints the line, naming rank 1 and rank 1's phase; `raise`: rank 1's own
+    failure path runs (stderr only: stdout is rank 0's)."""
+    import json
+    import time
+    bench = _load_bench()
+    worker = tmp_path / "fail_worker.py"
+    worker.write_text(FAIL_WORKER % {"repo": REPO})
+    out_path = tmp_path / "rank0.out"
+    logs = tmp_path / "logs"
+    t0 = time.time()
+    with open(out_path, "w") as f:
+        rc = bench.launch_ranks(2, [sys.executable, str(worker), mode], stdout0=f, log_dir=str(logs))
+    assert rc != 0 and time.time() - t0 < 100
+    lines = [ln for ln in out_path.read_text().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["error"] and d["n_gpus"] == 2 and d["metric"] == bench.METRIC
+    if mode == "silent0":
+        assert d["rank"] == 1 and d["phase"] == "timed" and d.get("launcher") == "bench.py", d
+    else:
+        assert d["rank"] == 0 and d["phase"] == "timed", d
+    assert (logs / "rank1.stderr").exists() and (logs / "rank0.stderr").exists()
+    if mode == "raise":
+        assert "simulated failure of rank 1" in (logs / "rank1.stderr").read_text()
