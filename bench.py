@@ -282,7 +282,7 @@ def init_dist(args):
         # (the watchdog's bound on a collective that never completes; the gathers' own host-side waits are bounded much tighter: dist.DEFAULT_TIMEOUT_S)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=600))
         # Finish RCCL's own setup (its streams, channels, proxy threads) with one collective BEFORE the
-        # GOP pipelines' streams exist.  Measured (tools/dist_overhead.py): streams created between an
+        # GOP pipelines' streams exist.  Measured in round 2 (the one-off tool is in the git history): streams created between an
         # eager communicator init and its first collective end up serialised with each other
         # (260 instead of 222 us/step); created after it, or before a lazy init, they overlap.
         # ... and that collective counts the ranks RCCL really connected (reported as `rccl_ranks`)
@@ -650,10 +650,10 @@ def bench_main(args):
             b_px = 2.0 * (args.bits // 8) + alg_bytes / (coded_pairs * n)
             rf["end_to_end"] = {"bytes_per_pixel": round(b_px, 3), "achieved": round(value / world * 1e6 * b_px / 1e9, 1),
                                 "unit": "GB/s per GPU", "frac": round(value / world * 1e6 * b_px / 1e9 / HBM_PEAK_GBPS, 4)}
-            rf["issue"] = None if (args.density or GPC != 1) else issue_roofline(W, H, F, args.bits, breakdown)
+            rf["issue"] = None if args.density else issue_roofline(W, H, F, args.bits, GPC, breakdown, elapsed / steps_timed * 1e3, (steady or {}).get("ms_per_step"))
             out["roofline"] = rf
             out["kernels_ms_per_step_alone"] = breakdown
-            out["kernels_alone_note"] = "HIP events around every kernel of %d steps of ONE pipeline after the timed region, nothing co-running (rocprofv3 of the same shape: profiles/r05_*)" % ALONE_LAUNCHES
+            out["kernels_alone_note"] = "HIP events around every kernel of %d steps of ONE pipeline after the timed region, nothing co-running (rocprofv3 of the same shape: profiles/r06_rocprofv3_summary.txt)" % ALONE_LAUNCHES
         else:
             out["roofline"] = None
         if world == 1:
@@ -898,6 +898,7 @@ def pipelines_leg(torch, nat, device, local_rank, W, H, F, bits, planar, G_res, 
                            "frac": round(ach / HBM_PEAK_GBPS, 5), "avg_launch_ms": alone["query"], "launches_averaged": 20,
                            "algorithmic_bytes_per_launch": int(alg_bytes), "frames_per_launch": coded_pairs}
         out["roofline"].update(measured_traffic(W, H, F, bits, False, GPC))
+        out["roofline"]["issue"] = issue_roofline(W, H, F, bits, GPC, alone, dt * 1e3)
     if verify:
         out["verified_vs_oracle"] = verify_all([h for h, _ in checked], [r for _, r in checked], n, len(checked))
     for c in coders:
@@ -909,15 +910,18 @@ def pipelines_leg(torch, nat, device, local_rank, W, H, F, bits, planar, G_res, 
     return out
 
 
+TRAFFIC = "profiles/r06_traffic.json"             # written by tools/make_traffic.py from tools/r06_profile.sh's PMC passes
+
+
 def replayed_traffic(W, H, F, bits, gpc):
-    """HBM bytes per launch of a leg's query kernel from a committed rocprofv3 PMC pass (profiles/r05_traffic.json: FETCH_SIZE / WRITE_SIZE
+    """HBM bytes per launch of a leg's query kernel from a committed rocprofv3 PMC pass (profiles/r06_traffic.json: FETCH_SIZE / WRITE_SIZE
     in separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), or None: a REPLAYED constant, tagged as such."""
-    path = os.path.join(REPO, "profiles", "r05_traffic.json")
+    path = os.path.join(REPO, TRAFFIC)
     if not os.path.exists(path):
         return None
     with open(path) as f:
         t = json.load(f).get("%dx%dx%d_%dbit_gpc%d" % (W, H, F, bits, gpc))
-    return None if t is None else {"hbm_bytes_per_launch": int(t["hbm_bytes_per_launch"]), "replayed": True, "source": "profiles/r05_traffic.json (%s)" % t.get("source", "rocprofv3 --pmc")}
+    return None if t is None else {"hbm_bytes_per_launch": int(t["hbm_bytes_per_launch"]), "replayed": True, "source": "%s (%s)" % (TRAFFIC, t.get("source", "rocprofv3 --pmc"))}
 
 
 def check_gathered(og, world, G, pairs, n, res_all):
@@ -940,24 +944,44 @@ def check_gathered(og, world, G, pairs, n, res_all):
     return parsed
 
 
-def issue_roofline(W, H, F, bits, breakdown):
+ISSUE_MODEL = "profiles/r06_issue_model.json"     # written by `python tools/make_issue_model.py` from profiles/r06_counters.json + profiles/r04_opbench2.txt + the library's ISA
+
+
+def issue_roofline(W, H, F, bits, gpc, breakdown, ms_per_step, steady_ms=None):
     """Companion to the HBM roofline ('expect the kernel to sit on the integer-ALU ceiling first; report both'): the
-    instruction-issue bound of the query kernel's frame loop -- the ISA of the in-tree library's loop priced with the per-opcode issue
-    costs measured on this chip (profiles/r04_opbench2.txt; tools/make_r04_models.py writes profiles/r04_issue_model.json).  Two bounds
-    are given because the model has one open term: whether a scalar instruction costs the SIMD issue time next to a VALU stream (it
-    does in the micro-benchmark).  Replayed constants, tagged with their source; only valid for the workload they were made for."""
-    path = os.path.join(REPO, "profiles", "r04_issue_model.json")
-    if (W, H, F, bits) != (1920, 1080, 30, 8) or not os.path.exists(path) or not breakdown or not breakdown.get("query"):
+    instruction-issue bound of the WHOLE STEP and of each of its kernels.  The bound itself is a replayed constant -- wave-instructions
+    per launch from rocprofv3 counters x the issue price of this chip's vector instructions, tools/make_issue_model.py -- the fractions
+    are computed HERE from the times this run measured: every kernel alone (HIP events) and the four-pipeline step."""
+    path = os.path.join(REPO, ISSUE_MODEL)
+    if not os.path.exists(path) or not breakdown:
         return None
     with open(path) as f:
         model = json.load(f)
-    q = breakdown["query"]
-    lo, hi = model["frame_loop_issue_bound_valu_only_ms"], model["frame_loop_issue_bound_ms"]
-    return {"replayed": True, "bound": "instruction issue (VALU, and VALU + SALU) of the 29 frame passes", "kernel": model["kernel"],
-            "frame_loop_valu_only_ms": lo, "frame_loop_valu_plus_salu_ms": hi, "launch_ms_alone": q,
-            "frac_of_launch": [round(lo / q, 3), round(hi / q, 3)],
-            "prologue_ms": model.get("prologue_ms"),
-            "source": "profiles/r04_issue_model.json (replayed constants: ISA histogram of the frame loop x profiles/r04_opbench2.txt)"}
+    shape = model["shapes"].get("%dx%dx%d_%dbit_gpc%d" % (W, H, F, bits, gpc))
+    if shape is None:
+        return None
+    per = {}
+    for name, k in shape["kernels"].items():
+        alone = breakdown.get(k["role"])
+        if k["role"] in ("hashtab", "pack", "expand") or not alone:
+            continue
+        b = k["valu_bound_us"] / 1e3
+        per[name] = {"role": k["role"], "valu_wave_instructions": k["valu"], "mean_cycles_per_valu": k["mean_valu_cycles"], "issue_bound_ms": round(b, 5),
+                     "issue_bound_with_salu_ms": round(k["valu_salu_bound_us"] / 1e3, 5), "alone_ms": alone, "frac_of_alone": round(b / alone, 3),
+                     "remainder_ms": round(alone - b, 5), "remainder_is": k.get("remainder_is")}
+    st = shape["step"]
+    out = {"bound": "instruction issue: vector wave-instructions x their issue price on 1024 SIMDs (and the same + scalar instructions)", "replayed": True,
+           "step_bound_ms": st["valu_bound_ms"], "step_bound_with_salu_ms": st["valu_salu_bound_ms"], "step_ms": round(ms_per_step, 5),
+           "step_frac": round(st["valu_bound_ms"] / ms_per_step, 3), "step_frac_with_salu": round(st["valu_salu_bound_ms"] / ms_per_step, 3),
+           "valu_wave_instructions_per_step": st["valu"], "vector_lane_instructions_per_pixel": st["valu_per_pixel"],
+           "mpixels_per_s_at_the_bound": st["mpixels_per_s_at_the_valu_bound"], "per_kernel": per,
+           "shader_clock_ghz": model["shader_clock_ghz"],
+           "source": "%s (python tools/make_issue_model.py: rocprofv3 SQ_INSTS_VALU / SQ_INSTS_SALU per launch of this shape, profiles/r06_counters.json, x per-opcode issue prices, "
+                     "profiles/r04_opbench2.txt, weighted by the opcode mix of each kernel's loops in the in-tree library's ISA) -- the bound is a replayed constant, the fractions "
+                     "use this run's times" % ISSUE_MODEL}
+    if steady_ms:
+        out["steady_state_frac"] = round(st["valu_bound_ms"] / steady_ms, 3)
+    return out
 
 
 def measured_traffic(W, H, F, bits, custom_density, gpc=1):
@@ -1161,7 +1185,7 @@ def clip_blocks(start, stop, interval, block_gops, pipelines=4, force_groups=0):
     0 (auto): the rank's frames in min(pipelines, about one block per 72 inter-frames) contiguous ranges of EQUAL length (cut anywhere, not
     only at keyframes), at most 128 frames each -- every pipeline of the rank gets one block of the same size per pass.  A share of fewer
     blocks than pipelines (N >= 2) is NOT cut smaller -- every block pays the query kernel's hashing prologue once, and the insert and query
-    kernels own their CUs, so small blocks only add prologues (profiles/r06_shard_proxy.txt) -- the idle pipelines take the NEXT pass
+    kernels own their CUs, so small blocks only add prologues (profiles/r06_shard_proxy_sweep.txt) -- the idle pipelines take the NEXT pass
     instead (run_clip's pass slots).  force_groups > 0 overrides the number of ranges (--clip-groups: the sweep behind that statement)."""
     if block_gops == 1:
         return [(f0, cnt, []) for f0, cnt in clip_pieces(start, stop, interval)]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise tools/r06_profile.sh (round 5: tools/r05_profile.sh): per-kernel time stats (rocprofv3 --stats), HBM bytes per launch from the
+"""Summarise tools/r06_profile.sh: per-kernel time stats (rocprofv3 --stats), HBM bytes per launch from the
 FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE reports half the bytes of
 16-byte-per-lane reads: doubled; both counters are in KiB), and the instruction counters per launch of every shape that has a
 pmc_insts_<shape> pass.  Writes <dir>/<round>_traffic.json and <dir>/<round>_counters.json (copied to profiles/; the second one feeds
