@@ -136,6 +136,9 @@ def test_all_keyframe_container_is_reference_compatible():
     for key, val in meta["stable"].items():
         assert res[key] == val, key
     assert comp._container(comp.last_compressed_frames) == z["container"].tobytes()
+    assert comp._container_size(comp.last_compressed_frames) == len(z["container"].tobytes())
+    mixed = [(1, b"abc"), (2, b"defgh"), (2, b"")]
+    assert comp._container_size(mixed) == len(comp._container(mixed))
     # and the reference-written container decodes
     recs = comp._parse_container(z["container"].tobytes())
     dec = comp.decompress_video(compressed_frames=recs)

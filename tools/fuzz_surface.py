@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Surface soak: random small videos through ImprovedVideoCompressor -- the GOP-batched route and the
-frame-by-frame route must write the same container, and both must decode to the original frames bit for bit.
+"""Surface soak: random small videos through ImprovedVideoCompressor -- the GOP-batched route (random block sizes over 1-3 GPU lanes) and
+the frame-by-frame route must write the same container, and both must decode to the original frames bit for bit.
 Usage: python tools/fuzz_surface.py SECONDS [SEED]"""
 import os
 import sys
@@ -33,8 +33,10 @@ while time.time() < t_end:
             frames.append(f)                                                   # chroma-only change -> keyframe fallback
         else:
             frames.append(next_frame(rng, frames[-1], float(rng.choice([0.002, 0.05, 0.0889, 0.2, 0.4, 0.9]))))
-    desc = dict(seed=seed, case=cases, W=W, H=H, dtype=np.dtype(dtype).name, F=F, interval=interval)
-    a = pkg.ImprovedVideoCompressor(keyframe_interval=interval, verbose=False)
+    lanes = int(rng.integers(1, 4))
+    block = [None, None, 2, 3, 5, 9][int(rng.integers(0, 6))]                  # blocks that do not line up with the keyframe interval too
+    desc = dict(seed=seed, case=cases, W=W, H=H, dtype=np.dtype(dtype).name, F=F, interval=interval, lanes=lanes, block=block)
+    a = pkg.ImprovedVideoCompressor(keyframe_interval=interval, verbose=False, gpu_lanes=lanes, block_frames=block)
     b = pkg.ImprovedVideoCompressor(keyframe_interval=interval, verbose=False)
     b.gop_batching = False
     a.compress_video([f.copy() for f in frames], None, input_color_space="YUV")
@@ -47,5 +49,7 @@ while time.time() < t_end:
         if len(dec) != F or not all(np.array_equal(x, np.asarray(getattr(y, "data", y))) for x, y in zip(frames, dec)):
             print("DECODE MISMATCH", desc, "batched" if comp is a else "frame-by-frame"); sys.exit(1)
     inter += sum(1 for ty, _ in a.last_compressed_frames if ty == 2)
+    a.close()
+    b.close()
     cases += 1
 print("ok: %d videos, %d inter-frames, both routes identical and lossless in %.0f s (seed %d)" % (cases, inter, budget, seed))
