@@ -610,7 +610,7 @@ def bench_main(args):
                    "launcher": os.environ.get("RBF_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process"),
                    "rccl_ranks": world if (use_dist and args.backend == "nccl") else 0, "backend": args.backend if use_dist else None,
                    "ranks_share_one_device": bool(args.one_device),
-                   "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); the N>1 path is covered by world-2 / world-8 runs of the real kernels on ONE device over gloo (tests/test_gpu_dist_shared.py), gloo world-2/3 CPU tests (incl. the self-spawn launcher) and RCCL world-1 tests"},
+                   "multi_gpu_note": "N>1 on one node was never measured by the builder (1-GPU boxes only); what exists: every rank's share of the N = 2 / 4 / 8 split timed on ONE GPU (the `shard_proxy` leg: a prediction, gather stubbed), world-2 / world-8 runs of the real kernels on ONE device over gloo (tests/test_gpu_dist_shared.py), gloo world-2/3 CPU tests (incl. the self-spawn launcher, a rank killed mid-gather, the failure line) and RCCL world-1 tests"},
     }
     if use_dist:
         # who ran where, and what crossed the links: every rank's device, and the bytes the non-root ranks sent into rank 0 per step
@@ -705,6 +705,10 @@ def bench_main(args):
         c16 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 16, args.clip_steps, 2, clip_cache=cache)
         if proxy:
             sp["clip300_uint16"] = shard_proxy_leg(args, env, args.clip_leg_frames, args.keyframe_interval, args.clip_steps, cache, 16, c16)
+        for k2 in list(cache or {}):
+            if k2[0] == "pipelines":
+                for c in cache.pop(k2)[1]:
+                    c.close()
         if rank == 0:
             out["clip300"], out["clip300_uint16"] = c8, c16
             if proxy:
@@ -1125,8 +1129,18 @@ def cpu_baseline(res, n, nframes):
     # output buffers for the whole run and touches them beforehand: allocating 2.6 MB per call (round 4) had 256 threads fight over the
     # process's address-space lock (mmap / page faults / munmap) and capped the figure at ~10x one core.
     import threading
-    threads = max(1, os.cpu_count() or 1)
-    per_thread = 2                                # frames per thread (the step's masks, cyclically): ~0.2 s of work each
+    # as many threads as the container may actually run: its cgroup CPU quota when there is one (the GPU boxes of this pool: 16 CPUs of a
+    # 256-thread host -- 256 threads under that quota measured 11x one core, round 5), else the CPUs of the affinity mask
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = _cgroup_cpu_max()
+    try:
+        q, period = quota.split()[:2]
+        if q != "max":
+            usable = max(1, min(usable, int(-(-int(q) // int(period)))))
+    except (AttributeError, ValueError):
+        pass
+    threads = max(1, usable)
+    per_thread = max(2, min(16, 512 // threads))  # frames per thread (the step's masks, cyclically): ~0.1 s of work each
     jobs = threads * per_thread
     lmax = max(r["l"] for r in frames)
     start_evt = threading.Event()
@@ -1156,7 +1170,7 @@ def cpu_baseline(res, n, nframes):
                       % (passes, len(frames), n, t_total),
             "all_cores": {"value": round(jobs * n / t_all / 1e6, 1), "unit": "Mpixel/s", "cores": threads, "host_cpus": os.cpu_count(),
                           "usable_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": _cgroup_cpu_max(),
-                          "speedup_over_one_core": round(jobs * n / t_all / (px / t_total), 1),
+                          "speedup_over_one_core": round(jobs * n / t_all / (px / t_total), 1), "threads_rule": "min(affinity, cgroup quota)",
                           "sample": "%d frames (the step's %d masks, cyclically) over %d threads with their own pre-touched buffers, %d frames each, one frame per call, %.2f s" % (jobs, len(frames), threads, per_thread, t_all)},
             "reference_python_mpixels_per_s": {"value": 0.38, "source": "BASELINE.md (recorded constant: the reference's own Python loops, build container, 1 core)"}}
 
@@ -1242,7 +1256,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
     world, rank, local_rank, device, use_dist = env
     from new_bloom_filter_repo_amd import _native as nat
     from new_bloom_filter_repo_amd.dist import shard_range, halo_start, gather_device_records, unpack_device_record
-    from new_bloom_filter_repo_amd.gop import GopCoder, torch_allocator
+    from new_bloom_filter_repo_amd.gop import GopCoder, TorchArena, torch_allocator
     from new_bloom_filter_repo_amd.synthetic import make_clip_shard, P_KSTAR_2_3
 
     if proxy is not None and (world != 1 or use_dist):
@@ -1257,7 +1271,8 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
     if clip_cache is not None:                    # frames first..stop-1 of the SAME clip on every rank (here: a view of the cached whole clip)
         key = (W, H, T, I, bits, density)
         if key not in clip_cache:
-            clip_cache.clear()                    # one clip at a time: 300 x 1080p x 16 bit is 3.7 GB of host memory
+            for k2 in [k2 for k2 in clip_cache if k2[0] != "pipelines"]:
+                del clip_cache[k2]                # one clip at a time: 300 x 1080p x 16 bit is 3.7 GB of host memory (the shared pipelines stay)
             clip_cache[key] = make_clip_shard(3000, W, H, 0, T, I, p=density, dtype=dtype)
         shard = clip_cache[key][first:stop]
     else:
@@ -1273,16 +1288,42 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
     nblocks = len(pieces)
     nsets = 1 if not nblocks else max(1, min(args.clip_pass_slots or NP, NP // nblocks))
     nstreams = max(1, min(NP, nblocks * nsets))
-    streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
-    ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
+    if clip_cache is not None:
+        # The calls that share a cache (the N = 1 leg and every rank of the proxies) also share their pipelines -- streams, library contexts
+        # (scratch, the process-wide hash table) -- and carve their coders' buffers out of ONE arena: where a call's buffers land in HBM
+        # decided its speed by up to 15 % (the same calls of every run, fast in a process of their own), and a rank's work is what is measured.
+        pk = ("pipelines", NP)
+        if pk not in clip_cache:
+            st = [torch.cuda.Stream(device) for _ in range(NP)]
+            clip_cache[pk] = (st, [nat.Context(local_rank, x.cuda_stream) for x in st], TorchArena(device, 1536 << 20))
+        all_streams, all_ctxs, arena = clip_cache[pk]
+        streams, ctxs = all_streams[:nstreams], all_ctxs[:nstreams]
+        arena.used = 0
+        alloc = arena
+    else:
+        streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
+        ctxs = [nat.Context(local_rank, s.cuda_stream) for s in streams]
+        alloc = torch_allocator(device)
     if args.force_bits:
         for c in ctxs:
             c.force_generic(args.force_bits)
     planar = not args.interleaved
     frame_bytes = n * (1 if planar else 3) * (bits // 8)
-    resident = np.ascontiguousarray(shard[..., 0]) if planar else np.ascontiguousarray(shard)       # planar: only the Y planes of the shard (+ halo) are resident in HBM
-    frames_t = torch.from_numpy(resident.reshape(-1).view(np.uint8)).to(device)
-    del resident
+    if clip_cache is not None:
+        # ONE resident copy of the whole clip for every call that shares the cache (the N = 1 leg and all the proxies): a rank's share is a
+        # view of it, as a rank's frames are views of what its loader left in HBM -- and every measurement sees the same placement in HBM
+        # (re-uploading per call made single ranks 15 % slower, reproducibly the same calls of a run: the allocator's luck, not the rank's work)
+        dkey = ("device",) + key + (planar,)
+        if dkey not in clip_cache:
+            whole = clip_cache[key]
+            res = np.ascontiguousarray(whole[..., 0]) if planar else np.ascontiguousarray(whole)
+            clip_cache[dkey] = torch.from_numpy(res.reshape(-1).view(np.uint8)).to(device)
+            del res
+        frames_t = clip_cache[dkey][first * frame_bytes:stop * frame_bytes]
+    else:
+        resident = np.ascontiguousarray(shard[..., 0]) if planar else np.ascontiguousarray(shard)       # planar: only the Y planes of the shard (+ halo) are resident in HBM
+        frames_t = torch.from_numpy(resident.reshape(-1).view(np.uint8)).to(device)
+        del resident
 
     class View:                                   # a run's frames inside the shard buffer
         def __init__(self, off, nbytes):
@@ -1293,7 +1334,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
         coders = []
         for i, (f0, cnt, rs) in enumerate(pieces):
             view = View((f0 - first) * frame_bytes, cnt * frame_bytes)
-            coders.append(GopCoder(ctxs[(s * nblocks + i) % nstreams], W, H, cnt, channels=3, sample_bytes=bits // 8, allocator=torch_allocator(device),
+            coders.append(GopCoder(ctxs[(s * nblocks + i) % nstreams], W, H, cnt, channels=3, sample_bytes=bits // 8, allocator=alloc,
                                    frames_block=None if planar else view, planar_luma=planar, keep_interleaved=False, luma_block=view if planar else None, run_starts=rs))
         sets.append(coders)
     for b in range(NREC):
@@ -1366,22 +1407,30 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
                 done = bool(flag.item())
             if done:
                 break
-        barrier()
+        # REGIONS regions of exactly `steps` passes, each between barrier + synchronize, max over ranks; the MEDIAN region counts (as in the
+        # headline): something on these boxes stalls a process for 10-20 ms every second or two (a 45 ms region that catches it reads 15-50 %
+        # slow, reproducibly for whichever call is running at that moment) and a median of five shrugs one hit off
+        REGIONS = 5
+        times, got = [], None
         gc.collect()
-        gc.disable()                              # (a generation-2 collection of this process's heap -- the clip, the other legs' results -- is a millisecond the GPU starves)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step(gather)
-        got = finish_gather()                     # the last pass's records (every pass was gathered inside the region: `steps` exchanges)
-        torch.cuda.synchronize(device)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        gc.enable()
-        if use_dist:
-            te = torch.tensor([elapsed], dtype=torch.float64, device=COMM_DEVICE)
-            all_reduce_b(dist, te, dist.ReduceOp.MAX)
-            elapsed = float(te.item())
-        return elapsed, got
+        for _ in range(REGIONS):
+            barrier()
+            gc.disable()                          # (a generation-2 collection of this process's heap -- the clip, the other legs' results -- is a millisecond the GPU starves)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(gather)
+            got = finish_gather()                 # the last pass's records (every pass was gathered inside the region: `steps` exchanges)
+            torch.cuda.synchronize(device)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            gc.enable()
+            if use_dist:
+                te = torch.tensor([elapsed], dtype=torch.float64, device=COMM_DEVICE)
+                all_reduce_b(dist, te, dist.ReduceOp.MAX)
+                elapsed = float(te.item())
+            times.append(elapsed)
+        state["regions_ms"] = [round(t * 1e3, 3) for t in times]
+        return sorted(times)[REGIONS // 2], got
 
     elapsed_plain, _ = timed(False)
     # one pass ALONE (nothing of a neighbouring pass under it): what a caller waits for who has only this one clip
@@ -1472,7 +1521,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
                "pass_latency_ms": round(latency * 1e3, 4),
                "gather_to_rank0": elapsed_gather is not None,
                "without_gather": {"value": round(pairs_timed * n * steps / elapsed_plain / 1e6, 2), "ms_per_pass": round(elapsed_plain / steps * 1e3, 4)},
-               "passes": steps, "scaling": "strong", "n_gpus": world,
+               "passes": steps, "regions_ms": state.get("regions_ms"), "timing": "median of 5 regions of `passes` passes each", "scaling": "strong", "n_gpus": world,
                "workload": "%dx%d YUV444 %d-bit synthetic clip of %d frames, keyframe every %d (%d inter-frames/pass over %d GPU%s), k*=2.3, threshold 0"
                            % (W, H, bits, T, I, total_pairs, s_world, "s" if s_world > 1 else ""),
                "sharding": "contiguous frame ranges + 1 halo frame (dist.shard_range)", "inter_frames_rank0": my_pairs,
@@ -1487,8 +1536,9 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
     for coders in sets:
         for c in coders:
             c.close()
-    for c in ctxs:
-        c.close()
+    if clip_cache is None:
+        for c in ctxs:
+            c.close()
     del sets, records, frames_t, ctxs
     torch.cuda.empty_cache()
     return out
