@@ -90,6 +90,7 @@ def parse_args():
     ap.add_argument("--clip-groups", type=int, default=0, help="clip mode: force the number of equal blocks a rank cuts its frames into per pass (0 = auto, see clip_blocks)")
     ap.add_argument("--proxy", default="", help="clip mode, single process: 'N,r' = run what rank r of an N-way split would run (gather stubbed), 'N' = every rank of the split in turn")
     ap.add_argument("--no-shard-proxy", action="store_true", help="skip the shard_proxy leg (one rank's share of configs 3 / 5 at N = 2, 4, 8, timed on this GPU)")
+    ap.add_argument("--ballast", type=int, default=0, help="diagnostic: allocate a dummy device block of random size (this seed) in front of every pipeline's first step, so that the contexts' scratch lands elsewhere in HBM (profiles/r06_placement.txt)")
     ap.add_argument("--clip-block-gops", type=int, default=0, help="clip mode: keyframe intervals a rank hands to the GPU in ONE rbf_encode_runs launch sequence; 0 = auto (one block per pipeline and pass, see clip_blocks), 1 = one call per run of inter-frames (round 4)")
     return ap.parse_args()
 
@@ -455,7 +456,11 @@ def bench_main(args):
         torch.cuda.synchronize(device)
 
     # setup (not warm-up steps): every pipeline sizes its scratch once, and for N > 1 the ranks agree on the slot
+    ballast = []
     for k in range(ncoders):
+        if args.ballast:
+            brng = np.random.default_rng(args.ballast * 100 + k)
+            ballast.append(ctxs[k].alloc(int(brng.integers(1, 96)) * (1 << 19) + int(brng.integers(0, 2048)) * 256))
         coders[k].encode()
         if gather:
             coders[k].pack(probe[k])
