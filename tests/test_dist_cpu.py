@@ -323,6 +323,33 @@ def test_clip_blocks_cover_every_inter_frame_once_in_order():
                 assert all((f0 + x) % I == 0 and 0 < x < cnt for x in rs)
                 coded += [f0 + 1 + j for j in range(cnt - 1) if (j + 1) not in rs]
         assert coded == [t for t in range(T) if t % I], (T, I, world, BG)
+    # --clip-groups (the shard sweep's forced partition): K equal blocks per rank, same coverage
+    for world, K in [(8, 2), (8, 4), (4, 2), (1, 6), (8, 64)]:
+        coded = []
+        for r in range(world):
+            a, b = D.shard_range(300, world, r)
+            blocks = bench.clip_blocks(a, b, 30, 0, 4, K)
+            assert len(blocks) <= max(K, 1) and (K >= 37 or len(blocks) == K or world == 1), (world, K, r, len(blocks))
+            for f0, cnt, rs in blocks:
+                coded += [f0 + 1 + j for j in range(cnt - 1) if (j + 1) not in rs]
+        assert coded == [t for t in range(300) if t % 30], (world, K)
+
+
+def test_bench_without_a_gpu_ends_in_the_failure_line():
+    """bench.py on a box without an MI355X: no CPU fallback -- ONE JSON line with value null, the error, rank 0 and the phase, exit code 1."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the run would succeed")
+    assert p.returncode == 1, (p.returncode, p.stderr[-500:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and "MI355X" in d["error"] and d["rank"] == 0 and d["phase"] == "init_dist" and d["n_gpus"] == 1
+    assert "FAILED in phase 'init_dist'" in p.stderr
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -43,6 +43,18 @@ def test_clip_sharded_over_ranks_on_one_device(world, bits, frames):
     assert v["bytes_gathered_on_rank0"] > 0 and res["value"] > 0
 
 
+def test_shard_proxy_mode_small_clip():
+    """bench.py --clip-frames F --proxy N: every rank of an N-way split of a small clip in turn, single process, gather stubbed -- the
+    `shard_proxy` leg's code path (pass slots, shared resident clip / pipelines / arena, packed record parsed, every rank verified)."""
+    res = run_json([sys.executable, "bench.py", "--clip-frames", "64", "--keyframe-interval", "8", "--proxy", "4", "--steps", "3", "--warmup", "1",
+                    "--width", "640", "--height", "360"], timeout=900)
+    assert res["proxy_world"] == 4 and len(res["ms_per_pass_per_rank"]) == 4 and all(x > 0 for x in res["ms_per_pass_per_rank"])
+    s = res["slowest"]
+    v = s["verified_vs_oracle"]
+    assert s["pass_slots"] >= 2 and s["proxy_of"]["world"] == 4 and v["frames"] == v["of"] == v["records_parsed"] == s["inter_frames_rank0"]
+    assert len(s["regions_ms"]) == 5
+
+
 def test_weak_mode_two_ranks_on_one_device():
     """The driver's `--gpus N` line (weak scaling: every rank codes its own GOPs) at N = 2 on one device over gloo: both ranks run the
     pipelines through the settle / region protocol in step with each other, rank 0 verifies its GOPs against the oracle and prints the aggregate.  (The record gather of the weak mode posts device
