@@ -703,16 +703,17 @@ def bench_main(args):
         env = (world, rank, local_rank, device, use_dist)
         proxy = world == 1 and not use_dist and not args.no_shard_proxy and (W, H, args.bits) == (1920, 1080, 8) and not args.density
         cache = {} if proxy else None             # (N > 1: every rank makes its own shard)
-        c8 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 8, args.clip_steps, 2, clip_cache=cache)
+        pool = cache if cache is not None else {}  # the pipelines and the arena are shared by the two clip legs at any N
+        c8 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 8, args.clip_steps, 2, clip_cache=cache, pool=pool)
         sp = dict(SHARD_PROXY_WHAT)
         if proxy:                                 # 8-bit proxies while the 8-bit clip is cached, then the 16-bit clip
             sp["clip300"] = shard_proxy_leg(args, env, args.clip_leg_frames, args.keyframe_interval, args.clip_steps, cache, 8, c8)
-        c16 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 16, args.clip_steps, 2, clip_cache=cache)
+        c16 = run_clip(args, env, args.clip_leg_frames, args.keyframe_interval, 16, args.clip_steps, 2, clip_cache=cache, pool=pool)
         if proxy:
             sp["clip300_uint16"] = shard_proxy_leg(args, env, args.clip_leg_frames, args.keyframe_interval, args.clip_steps, cache, 16, c16)
-        for k2 in list(cache or {}):
+        for k2 in list(pool):
             if k2[0] == "pipelines":
-                for c in cache.pop(k2)[1]:
+                for c in pool.pop(k2)[1]:
                     c.close()
         if rank == 0:
             out["clip300"], out["clip300_uint16"] = c8, c16
@@ -1238,7 +1239,7 @@ def clip_blocks(start, stop, interval, block_gops, pipelines=4, force_groups=0):
     return blocks
 
 
-def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip_cache=None):
+def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip_cache=None, pool=None):
     """One clip of T frames (W x H YUV444, `bits` per sample), keyframe every I: the inter-frames shard over the ranks by
     CONTIGUOUS FRAME RANGE with one halo frame (dist.shard_range / halo_start), every rank codes its frames in blocks of one
     rbf_encode_runs launch sequence each (clip_blocks) and packs each block's record on the device; with N > 1 the records travel to
@@ -1255,7 +1256,8 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
 
     proxy = (N, r): this single process runs what rank r of an N-way split would run (the shard arithmetic, blocks, pass slots and the
     packed record of that rank; the gather is stubbed) -- bench.py's `shard_proxy` leg.  clip_cache: dict that keeps the whole synthetic
-    clip of a bit depth between calls.  Returns the result dict on rank 0 (None elsewhere)."""
+    clip of a bit depth (host and HBM) between calls; pool (default: clip_cache): dict that keeps the pipelines (streams, contexts) and the
+    arena of the coders' buffers between calls.  Returns the result dict on rank 0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
     world, rank, local_rank, device, use_dist = env
@@ -1293,15 +1295,17 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
     nblocks = len(pieces)
     nsets = 1 if not nblocks else max(1, min(args.clip_pass_slots or NP, NP // nblocks))
     nstreams = max(1, min(NP, nblocks * nsets))
-    if clip_cache is not None:
-        # The calls that share a cache (the N = 1 leg and every rank of the proxies) also share their pipelines -- streams, library contexts
+    if pool is None:
+        pool = clip_cache
+    if pool is not None:
+        # The calls that share a pool (the clip legs of one process, every rank of the proxies) share their pipelines -- streams, library contexts
         # (scratch, the process-wide hash table) -- and carve their coders' buffers out of ONE arena: where a call's buffers land in HBM
         # decided its speed by up to 15 % (the same calls of every run, fast in a process of their own), and a rank's work is what is measured.
         pk = ("pipelines", NP)
-        if pk not in clip_cache:
+        if pk not in pool:
             st = [torch.cuda.Stream(device) for _ in range(NP)]
-            clip_cache[pk] = (st, [nat.Context(local_rank, x.cuda_stream) for x in st], TorchArena(device, 1536 << 20))
-        all_streams, all_ctxs, arena = clip_cache[pk]
+            pool[pk] = (st, [nat.Context(local_rank, x.cuda_stream) for x in st], TorchArena(device, 1536 << 20))
+        all_streams, all_ctxs, arena = pool[pk]
         streams, ctxs = all_streams[:nstreams], all_ctxs[:nstreams]
         arena.used = 0
         alloc = arena
@@ -1541,7 +1545,7 @@ def run_clip(args, env, T, I, bits, steps, warmup, verify=True, proxy=None, clip
     for coders in sets:
         for c in coders:
             c.close()
-    if clip_cache is None:
+    if pool is None:
         for c in ctxs:
             c.close()
     del sets, records, frames_t, ctxs
